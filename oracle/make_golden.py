@@ -1,0 +1,211 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own modules.
+
+Runs only in the build container (needs /root/reference). Imports the reference files by path (package
+import dies on `omegaconf`, model/lavis/__init__.py:11), loads our deterministic synthetic weights into the
+reference modules, runs them on CPU and stores small inputs/outputs as .npz. The weights themselves are NOT
+stored -- tests regenerate them from `radialog_amd.synth`. The reference's source never enters this repo.
+
+    python oracle/make_golden.py            # rewrites tests/golden/*.npz
+
+Pinned here:
+  llama_*    modeling_llama_imgemb.py: LlamaForCausalLM.forward / prepare_inputs_for_generation driven by a
+             hand greedy loop (HF 4.28.1 rule), image splice via the `dicom` side channel, left padding,
+             the no-<IMG> quirk; fp32, fp16 and bf16.
+  qformer_*  Qformer.py: BertLMHeadModel(...).bert(query_embeds, encoder_hidden_states, encoder_attention_mask)
+  projector  biovil_t/modules.py MLP(use_1x1_convs=True) in eval mode (+ the reshape scramble + LayerNorm restated
+             with torch ops exactly as blip2_qformer.py:469 writes them)
+  rope/rms   LlamaRotaryEmbedding tables, LlamaRMSNorm rows
+"""
+import importlib.util
+import os
+import pickle
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+
+from radialog_amd import synth                                   # noqa: E402
+from radialog_amd.config import LlamaCfg, QFormerCfg, VisionCfg  # noqa: E402
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, path))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def golden_llama_cfg():
+    return LlamaCfg(vocab=512, hidden=128, inter=256, layers=2, heads=4, qformer_dim=48)
+
+
+def golden_qformer_cfg():
+    return QFormerCfg(hidden=192, layers=4, heads=3, inter=384, enc_width=96, n_query=32)
+
+
+def make_llama():
+    import transformers
+    from transformers import LlamaConfig
+    c = golden_llama_cfg()
+    work = tempfile.mkdtemp()
+    os.makedirs(os.path.join(work, "pretraining", "embs"))
+    qf = synth.synth("golden.qformer_embs", (3, 32, c.qformer_dim), -1.0, 1.0)
+    dic = {f"dicom{i}": qf[i].numpy() for i in range(3)}
+    with open(os.path.join(work, "pretraining/embs/stage1_pt_instruct_blip_origlr_img448_embeddings_test.pkl"), "wb") as f:
+        pickle.dump(dic, f)
+    cwd = os.getcwd()
+    W = synth.make_weights(synth.llama_specs(c, lora=False))
+
+    def build(dt):
+        """A fresh reference model per dtype: `.to(dt)` rounds parameters AND the cached rope tables, so
+        chaining casts on one instance would double-round them."""
+        os.chdir(work)                         # the reference opens the pkl relative to CWD (:461)
+        try:
+            ref = _load("model/lavis/models/blip2_models/modeling_llama_imgemb.py", "ref_llama")
+            hcfg = LlamaConfig(vocab_size=c.vocab, hidden_size=c.hidden, intermediate_size=c.inter,
+                               num_hidden_layers=c.layers, num_attention_heads=c.heads,
+                               max_position_embeddings=c.max_pos, rms_norm_eps=c.rms_eps, pad_token_id=0,
+                               hidden_act="silu")
+            mdl = ref.LlamaForCausalLM(hcfg)
+        finally:
+            os.chdir(cwd)
+        mdl.model.img_proj_layer = torch.nn.Linear(c.qformer_dim, c.hidden)      # demo.py:229
+        missing, unexpected = mdl.load_state_dict(dict(W), strict=False)
+        assert not unexpected, unexpected
+        assert all("inv_freq" in k for k in missing), missing
+        return mdl.eval().to(dt)
+
+    T = 44
+    ids = synth.synth_prompt_ids(3, T, vocab=c.vocab, img_offset=5, seed=11)
+    ids[1, :6] = 0                                   # left padding on row 1 (pad id 0)
+    ids[1, 6] = 1
+    ids[1, 7:] = synth.synth_prompt_ids(1, T - 7, vocab=c.vocab, img_offset=4, seed=12)[0][: T - 7]
+    ids[1, 7] = 5
+    ids[2] = synth.synth_prompt_ids(1, T, vocab=c.vocab, img_offset=3, seed=13)[0]
+    ids[2][ids[2] == 32000] = 77                     # row 2: no <IMG> -> the drop-32-tokens quirk
+    dicom = ["dicom0", "dicom1", "dicom2"]
+    out = {"ids": ids.numpy(), "qformer_embs": qf.numpy()}
+
+    n_new = 8
+    for tag, dt in (("f32", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)):
+        m = build(dt)      # rotary tables follow .half() like every floating buffer (demo.py:234)
+        with torch.no_grad():
+            am = ids.ne(0).long()
+            seq, past = ids.clone(), None
+            toks, step_logits = [], []
+            unfinished = torch.ones(ids.shape[0], dtype=torch.long)
+            for step in range(n_new):
+                mi = m.prepare_inputs_for_generation(seq, past_key_values=past, attention_mask=am,
+                                                     use_cache=True, dicom=dicom)
+                o = m(**mi, return_dict=True)
+                if step == 0:
+                    out[f"prefill_logits_{tag}"] = o.logits.float().numpy()
+                    out[f"prefill_k0_{tag}"] = o.past_key_values[0][0].float().numpy()
+                    out[f"prefill_v1_{tag}"] = o.past_key_values[1][1].float().numpy()
+                past = o.past_key_values
+                row = o.logits[:, -1, :]
+                step_logits.append(row.float().numpy())
+                nxt = row.argmax(-1)
+                nxt = nxt * unfinished + 0 * (1 - unfinished)
+                toks.append(nxt.numpy())
+                seq = torch.cat([seq, nxt[:, None]], dim=-1)
+                am = torch.cat([am, am.new_ones(am.shape[0], 1)], dim=-1)
+                unfinished = unfinished * (nxt != 2).long()
+            out[f"tokens_{tag}"] = np.stack(toks, 1)
+            out[f"step_logits_{tag}"] = np.stack(step_logits, 0)
+    # pieces
+    m = build(torch.float32)
+    rot = m.model.layers[0].self_attn.rotary_emb
+    cos, sin = rot(torch.zeros(1, 1, 1, c.head_dim), seq_len=64)
+    out["rope_cos_f32"] = cos[0, 0].numpy()
+    out["rope_sin_f32"] = sin[0, 0].numpy()
+    xr = synth.synth("golden.rms_in", (5, c.hidden), -3.0, 3.0)
+    out["rms_in"] = xr.numpy()
+    out["rms_out_f32"] = m.model.norm(xr).detach().numpy()
+    out["rms_out_f16"] = build(torch.float16).model.norm(xr.half()).float().detach().numpy()
+    # split_at_img quirks (:498-520)
+    left, right = m.model.split_at_img(ids)
+    out["split_left_len"] = np.array([len(t) for t in left])
+    out["split_right_len"] = np.array([len(t) for t in right])
+    np.savez_compressed(os.path.join(OUT, "llama_tiny.npz"), **out)
+    print("llama_tiny:", {k: v.shape for k, v in out.items()})
+
+
+def make_qformer():
+    import transformers
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    # shims for transformers 5.x: names moved / removed since 4.28
+    for nm in ("apply_chunking_to_forward", "prune_linear_layer"):
+        if not hasattr(mu, nm):
+            setattr(mu, nm, getattr(pu, nm))
+    if not hasattr(mu, "find_pruneable_heads_and_indices"):
+        mu.find_pruneable_heads_and_indices = lambda *a, **k: (set(), torch.zeros(0))
+    mu.PreTrainedModel.get_head_mask = lambda self, m, n, *a, **k: [None] * n
+    ref = _load("model/lavis/models/blip2_models/Qformer.py", "ref_qformer")
+    if hasattr(ref.BertPreTrainedModel, "init_weights"):
+        ref.BertPreTrainedModel.init_weights = lambda self: None
+    q = golden_qformer_cfg()
+    bc = ref.BertConfig(vocab_size=64, hidden_size=q.hidden, num_hidden_layers=q.layers,
+                        num_attention_heads=q.heads, intermediate_size=q.inter, max_position_embeddings=64,
+                        layer_norm_eps=q.ln_eps, hidden_act="gelu", hidden_dropout_prob=0.1,
+                        attention_probs_dropout_prob=0.1)
+    bc.encoder_width = q.enc_width
+    bc.add_cross_attention = True
+    bc.cross_attention_freq = q.cross_freq
+    bc.query_length = q.n_query
+    model = ref.BertLMHeadModel(bc)
+    W = synth.make_weights(synth.qformer_specs(q))
+    sd = {k[len("Qformer."):]: v for k, v in W.items() if k.startswith("Qformer.")}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    # everything on the query-only path must have been provided
+    for mk in missing:
+        assert any(s in mk for s in ("word_embeddings", "position_embeddings", "position_ids", ".intermediate.dense",
+                                     ".output.dense", ".output.LayerNorm", "cls.")), mk
+    model.eval()
+    B, P = 2, 20
+    img = synth.synth("golden.qf_img", (B, P, q.enc_width), -2.0, 2.0)
+    with torch.no_grad():
+        qt = W["query_tokens"].expand(B, -1, -1)
+        o = model.bert(query_embeds=qt, encoder_hidden_states=img,
+                       encoder_attention_mask=torch.ones(B, P, dtype=torch.long), return_dict=True)
+    np.savez_compressed(os.path.join(OUT, "qformer_small.npz"), img=img.numpy(),
+                        out=o.last_hidden_state.numpy())
+    print("qformer_small:", o.last_hidden_state.shape, float(o.last_hidden_state.abs().mean()))
+
+
+def make_projector():
+    ref = _load("biovil_t/modules.py", "ref_modules")
+    v = VisionCfg(img=128, stem=32, planes=(32, 64, 128, 256), blocks=(1, 2, 2, 1), b2v=64, proj=352)
+    mlp = ref.MLP(input_dim=2 * v.b2v, output_dim=v.proj, hidden_dim=v.proj, use_1x1_convs=True)
+    W = synth.make_weights(synth.vision_specs(v))
+    J = "visual_encoder.projector."
+    sd = {k[len(J):]: t for k, t in W.items() if k.startswith(J)}
+    sd["model.1.num_batches_tracked"] = torch.tensor(0)
+    mlp.load_state_dict(sd)
+    mlp.eval()
+    x = synth.synth("golden.patch_fused", (2, 2 * v.b2v, v.grid, v.grid), -1.5, 1.5)
+    with torch.no_grad():
+        pp = mlp(x)
+        # blip2_qformer.py:469 + blip2.py:199-205, with torch's own LayerNorm as the reference uses it
+        ln = torch.nn.LayerNorm(v.proj)
+        ln.weight.data.copy_(W["ln_vision.weight"])
+        ln.bias.data.copy_(W["ln_vision.bias"])
+        emb = ln(pp.reshape(2, -1, v.proj).float())
+    np.savez_compressed(os.path.join(OUT, "projector.npz"), x=x.numpy(), projected=pp.numpy(), image_embeds=emb.numpy())
+    print("projector:", pp.shape, emb.shape)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    make_llama()
+    make_qformer()
+    make_projector()

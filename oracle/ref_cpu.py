@@ -1,0 +1,335 @@
+"""CPU ORACLE for the RaDialog hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this module, and only
+as the checker / the reported CPU baseline. Nothing under `radialog_amd/` imports it; the product path fails
+loudly when the HIP library is missing.
+
+What it is: a torch-CPU restatement (written from the reference's op sequence, not copied) of
+  image encode -> Q-Former -> img_proj + <IMG> splice -> Llama prefill/decode -> greedy loop,
+executed in a caller-chosen dtype exactly as the reference executes it: the encoder and Q-Former in fp32
+(demo.py:269-270 moves the fp32 BLIP model to the device with no autocast) and the decoder in fp16
+(`torch_dtype=torch.float16`, demo.py:225) or bf16 -- i.e. every torch op rounds its output to that dtype,
+which is what the HIP kernels reproduce (same rounding points, fp32 accumulation inside each op).
+
+Pinning:
+  * decoder (a8-a18), Q-Former (a6), projector MLP (a4): PINNED against the reference's own modules, imported
+    by file path in the build container by `oracle/make_golden.py`; `tests/test_oracle_golden.py` checks this
+    file against the committed vectors in `tests/golden/`.
+  * greedy loop (a19): third-party `transformers==4.28.1 GenerationMixin.greedy_search` (not vendored in the
+    reference, and `generate` is not callable on the vendored class under the installed transformers) --
+    rule restated from the published algorithm; the per-step forward it drives IS pinned (hand loop over the
+    reference's `prepare_inputs_for_generation` + `forward`, see make_golden.py). "parity unpinned" at the
+    loop level only.
+  * ResNet-50 trunk / Bottleneck (a2): arithmetic lives in `torchvision==0.14.0` (requirements.txt:18), which
+    is absent here and un-vendored -> PARITY UNPINNED; restated from the published v1.5 architecture
+    (stride on the 3x3 conv) with `torch.nn.functional.conv2d / batch_norm` as ground truth.
+  * LoRA linear (peft@e536616, requirements.txt:20, absent) -> PARITY UNPINNED; restated:
+    y = W x + (alpha/r) * B(A x), un-merged, dropout inactive in eval.
+  * ViT pooler two-image mode (a3'): timm==0.4.12 `Mlp` absent -> PARITY UNPINNED, restated from
+    biovil_t/transformer.py:73-266.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+IMG_TOKEN_ID = 32000
+N_IMG = 32
+
+
+# =====================================================================================================
+# Image encoder (fp32)           reference: biovil_t/resnet.py:25-47, encoder.py:110-136, model.py:76-91
+# =====================================================================================================
+def _bn(x, W, pre, eps):
+    return F.batch_norm(x, W[pre + ".running_mean"], W[pre + ".running_var"], W[pre + ".weight"], W[pre + ".bias"],
+                        training=False, eps=eps)
+
+
+def resnet50_trunk(x: torch.Tensor, W: Dict[str, torch.Tensor], vcfg) -> torch.Tensor:
+    """torchvision ResNet-50 v1.5 without avgpool/fc (ResNetHIML.forward, biovil_t/resnet.py:25-47).
+    x: [B,3,S,S] fp32 -> [B, 4*planes[-1], S/32, S/32]."""
+    P = "visual_encoder.encoder.encoder."
+    eps = vcfg.bn_eps
+    x = F.conv2d(x, W[P + "conv1.weight"], stride=2, padding=3)
+    x = F.relu(_bn(x, W, P + "bn1", eps))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    for li, nblk in enumerate(vcfg.blocks, start=1):
+        for b in range(nblk):
+            pre = f"{P}layer{li}.{b}."
+            stride = 2 if (b == 0 and li > 1) else 1
+            idt = x
+            o = F.relu(_bn(F.conv2d(x, W[pre + "conv1.weight"]), W, pre + "bn1", eps))
+            o = F.relu(_bn(F.conv2d(o, W[pre + "conv2.weight"], stride=stride, padding=1), W, pre + "bn2", eps))
+            o = _bn(F.conv2d(o, W[pre + "conv3.weight"]), W, pre + "bn3", eps)
+            if b == 0:
+                idt = _bn(F.conv2d(x, W[pre + "downsample.0.weight"], stride=stride), W, pre + "downsample.1", eps)
+            x = F.relu(o + idt)
+    return x
+
+
+def patch_fused(images: torch.Tensor, W, vcfg) -> torch.Tensor:
+    """MultiImageEncoder.forward, single-image branch (biovil_t/encoder.py:124-130): trunk -> 1x1 conv
+    -> concat with the learned constant `missing_previous_emb`."""
+    E = "visual_encoder.encoder."
+    x = resnet50_trunk(images, W, vcfg)
+    patch_x = F.conv2d(x, W[E + "backbone_to_vit.weight"])
+    B, _, h, w = patch_x.shape
+    diff_x = W[E + "missing_previous_emb"].repeat(B, 1, h, w)
+    return torch.cat([patch_x, diff_x], dim=1)
+
+
+def projector(patch: torch.Tensor, W, vcfg) -> torch.Tensor:
+    """MLP(use_1x1_convs=True): conv(no bias) -> BN2d -> ReLU -> conv(bias) (biovil_t/modules.py:30-47,:51-54)."""
+    J = "visual_encoder.projector.model."
+    x = F.conv2d(patch, W[J + "0.weight"])
+    x = F.relu(_bn(x, W, J + "1", vcfg.bn_eps))
+    return F.conv2d(x, W[J + "3.weight"], W[J + "3.bias"])
+
+
+def image_embeds(images: torch.Tensor, W, vcfg) -> torch.Tensor:
+    """ln_vision(projected_patch_embeddings.reshape(B,-1,1408)) -- the raw NCHW reshape WITHOUT a permute
+    (blip2_qformer.py:469) and the fp32 LayerNorm (blip2.py:199-205)."""
+    pp = projector(patch_fused(images, W, vcfg), W, vcfg)                 # [B, C, g, g] NCHW
+    B, C = pp.shape[0], pp.shape[1]
+    tok = pp.reshape(B, -1, C)                                           # flat re-chunking (finding 4)
+    return F.layer_norm(tok.float(), (C,), W["ln_vision.weight"], W["ln_vision.bias"], vcfg.ln_eps)
+
+
+# =====================================================================================================
+# Q-Former query-only path (fp32)                      reference: Qformer.py:78-108,:169-275,:402-484
+# =====================================================================================================
+def _lin(x, W, name):
+    return F.linear(x, W[name + ".weight"], W[name + ".bias"])
+
+
+def _bert_attn(q_in, kv_in, W, pre, heads, eps):
+    """BertSelfAttention (+BertSelfOutput): softmax(QK^T/sqrt(d)) V, dense, residual, LayerNorm.
+    Masks are all-zero on this path (image_atts = ones, query-only self-attention)."""
+    B, Tq, H = q_in.shape
+    d = H // heads
+    q = _lin(q_in, W, pre + "self.query").view(B, Tq, heads, d).permute(0, 2, 1, 3)
+    k = _lin(kv_in, W, pre + "self.key").view(B, -1, heads, d).permute(0, 2, 1, 3)
+    v = _lin(kv_in, W, pre + "self.value").view(B, -1, heads, d).permute(0, 2, 1, 3)
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d)
+    p = torch.softmax(s, dim=-1)
+    ctx = torch.matmul(p, v).permute(0, 2, 1, 3).contiguous().view(B, Tq, H)
+    o = _lin(ctx, W, pre + "output.dense")
+    return F.layer_norm(o + q_in, (H,), W[pre + "output.LayerNorm.weight"], W[pre + "output.LayerNorm.bias"], eps)
+
+
+def qformer(img_emb: torch.Tensor, W, qcfg) -> torch.Tensor:
+    """Qformer.bert(query_embeds=query_tokens, encoder_hidden_states=img_emb) -> last_hidden_state
+    [B, n_query, hidden] (blip2_qformer.py:476-484)."""
+    B = img_emb.shape[0]
+    H, eps = qcfg.hidden, qcfg.ln_eps
+    x = W["query_tokens"].expand(B, -1, -1)
+    x = F.layer_norm(x, (H,), W["Qformer.bert.embeddings.LayerNorm.weight"],
+                     W["Qformer.bert.embeddings.LayerNorm.bias"], eps)
+    for l in range(qcfg.layers):
+        L = f"Qformer.bert.encoder.layer.{l}."
+        x = _bert_attn(x, x, W, L + "attention.", qcfg.heads, eps)
+        if qcfg.has_cross(l):
+            x = _bert_attn(x, img_emb, W, L + "crossattention.", qcfg.heads, eps)
+        h = F.gelu(_lin(x, W, L + "intermediate_query.dense"))            # exact erf GELU (hidden_act="gelu")
+        o = _lin(h, W, L + "output_query.dense")
+        x = F.layer_norm(o + x, (H,), W[L + "output_query.LayerNorm.weight"], W[L + "output_query.LayerNorm.bias"], eps)
+    return x
+
+
+def forward_image(images: torch.Tensor, W, cfg) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Blip2Qformer.forward_image (blip2_qformer.py:467-484): (last_hidden_state, image_embeds)."""
+    emb = image_embeds(images, W, cfg.vision)
+    return qformer(emb, W, cfg.qformer), emb
+
+
+# =====================================================================================================
+# Llama decoder with the image splice          reference: modeling_llama_imgemb.py:76-318,:433-843
+# =====================================================================================================
+def rope_tables(head_dim: int, max_pos: int, base: float, dtype) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cos/sin [max_pos, head_dim]: built in fp32, then rounded to the model dtype (:99-109,:122-125)."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2).float() / head_dim))
+    t = torch.arange(max_pos, dtype=inv_freq.dtype)
+    freqs = torch.einsum("i,j->ij", t, inv_freq)
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def rmsnorm(x, w, eps):
+    var = x.to(torch.float32).pow(2).mean(-1, keepdim=True)
+    h = x * torch.rsqrt(var + eps)                     # fp32 (type promotion)
+    if w.dtype in (torch.float16, torch.bfloat16):
+        h = h.to(w.dtype)
+    return w * h
+
+
+def _rot_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+def split_positions(ids: torch.Tensor) -> torch.Tensor:
+    """First index of <IMG> per row, 0 when absent (split_at_img, :498-520: the no-<IMG> quirk keeps
+    left=[] and drops tokens 0..31)."""
+    B, T = ids.shape
+    pos = torch.zeros(B, dtype=torch.long)
+    for b in range(B):
+        hit = (ids[b] == IMG_TOKEN_ID).nonzero()
+        if hit.numel():
+            pos[b] = int(hit[0])
+    return pos
+
+
+def positions_from_mask(mask: torch.Tensor) -> torch.Tensor:
+    """prepare_inputs_for_generation (:805-810): cumsum(mask)-1, masked slots -> 1."""
+    pos = mask.long().cumsum(-1) - 1
+    return pos.masked_fill(mask == 0, 1)
+
+
+class LlamaOracle:
+    def __init__(self, W: Dict[str, torch.Tensor], cfg, dtype=torch.float16, lora: bool = True):
+        """W: fp32 (or already-rounded) tensors keyed by reference state_dict names; cast to `dtype` here
+        the way `.half()` does for every floating parameter/buffer (demo.py:234)."""
+        self.cfg, self.dtype = cfg, dtype
+        self.W = {k: v.to(dtype) for k, v in W.items()}
+        self.lora = lora and any("lora_A" in k for k in W)
+        self.cos, self.sin = rope_tables(cfg.head_dim, cfg.max_pos, cfg.rope_base, dtype)
+
+    # -- pieces ---------------------------------------------------------------------------------------
+    def _proj(self, x, L, nm):
+        W = self.W
+        y = F.linear(x, W[L + f"self_attn.{nm}.weight"])
+        a_key = L + f"self_attn.{nm}.lora_A.weight"
+        if self.lora and a_key in W:
+            y = y + F.linear(F.linear(x, W[a_key]), W[L + f"self_attn.{nm}.lora_B.weight"]) * self.cfg.lora_scale
+        return y
+
+    def embed(self, ids: torch.Tensor, qformer_embs: Optional[torch.Tensor]) -> torch.Tensor:
+        """embed_tokens + img_proj_layer + splice (:571-594). qformer_embs [B,32,768] float or None."""
+        W = self.W
+        E = W["model.embed_tokens.weight"]
+        if qformer_embs is None:
+            return F.embedding(ids.clamp(max=E.shape[0] - 1), E)
+        img = F.linear(qformer_embs.to(self.dtype), W["model.img_proj_layer.weight"], W["model.img_proj_layer.bias"])
+        pos = split_positions(ids)
+        rows = []
+        for b in range(ids.shape[0]):
+            p = int(pos[b])
+            rows.append(torch.cat([F.embedding(ids[b, :p], E), img[b], F.embedding(ids[b, p + N_IMG:], E)], dim=0))
+        return torch.stack(rows, dim=0)
+
+    def _mask(self, key_mask: torch.Tensor, Tq: int, past: int) -> torch.Tensor:
+        """_prepare_decoder_attention_mask (:475-496): causal(finfo.min) + padding(finfo.min)."""
+        dt = self.dtype
+        mn = torch.finfo(dt).min
+        B, Tk = key_mask.shape
+        inv = 1.0 - key_mask[:, None, None, :].expand(B, 1, Tq, Tk).to(dt)
+        m = inv.masked_fill(inv.to(torch.bool), mn)
+        if Tq > 1:
+            c = torch.full((Tq, Tq), mn)
+            idx = torch.arange(Tq)
+            c.masked_fill_(idx < (idx + 1).view(Tq, 1), 0)
+            c = c.to(dt)
+            if past:
+                c = torch.cat([torch.zeros(Tq, past, dtype=dt), c], dim=-1)
+            m = m + c[None, None]
+        return m
+
+    def layer(self, l: int, x, mask, pos_ids, past):
+        c, W = self.cfg, self.W
+        L = f"model.layers.{l}."
+        B, T, H = x.shape
+        nh, d = c.heads, c.head_dim
+        h = rmsnorm(x, W[L + "input_layernorm.weight"], c.rms_eps)
+        q = self._proj(h, L, "q_proj").view(B, T, nh, d).transpose(1, 2)
+        k = self._proj(h, L, "k_proj").view(B, T, nh, d).transpose(1, 2)
+        v = self._proj(h, L, "v_proj").view(B, T, nh, d).transpose(1, 2)
+        cos = self.cos[pos_ids][:, None]                     # [B,1,T,d]
+        sin = self.sin[pos_ids][:, None]
+        q = (q * cos) + (_rot_half(q) * sin)
+        k = (k * cos) + (_rot_half(k) * sin)
+        if past is not None:
+            k = torch.cat([past[0], k], dim=2)
+            v = torch.cat([past[1], v], dim=2)
+        s = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(d)
+        s = s + mask
+        s = torch.max(s, torch.tensor(torch.finfo(s.dtype).min))
+        p = F.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
+        o = torch.matmul(p, v).transpose(1, 2).reshape(B, T, H)
+        x = x + F.linear(o, W[L + "self_attn.o_proj.weight"])
+        h = rmsnorm(x, W[L + "post_attention_layernorm.weight"], c.rms_eps)
+        g = F.silu(F.linear(h, W[L + "mlp.gate_proj.weight"])) * F.linear(h, W[L + "mlp.up_proj.weight"])
+        x = x + F.linear(g, W[L + "mlp.down_proj.weight"])
+        return x, (k, v)
+
+    def forward(self, x, key_mask, pos_ids, past=None, all_logits=False, n_layers=None):
+        """x: embeddings [B,T,H]; key_mask [B, past+T] (1 = attend); pos_ids [B,T]. Returns
+        (logits [B,T or 1,V], new_past, hidden)."""
+        T = x.shape[1]
+        pl = 0 if past is None else past[0][0].shape[2]
+        mask = self._mask(key_mask, T, pl)
+        new_past = []
+        nl = self.cfg.layers if n_layers is None else n_layers
+        for l in range(nl):
+            x, kv = self.layer(l, x, mask, pos_ids, None if past is None else past[l])
+            new_past.append(kv)
+        h = rmsnorm(x, self.W["model.norm.weight"], self.cfg.rms_eps)
+        hl = h if all_logits else h[:, -1:]
+        logits = F.linear(hl, self.W["lm_head.weight"])
+        return logits, new_past, h
+
+    # -- greedy loop (transformers==4.28.1 GenerationMixin.greedy_search, restated) --------------------
+    def generate_greedy(self, ids: torch.Tensor, qformer_embs: Optional[torch.Tensor], max_new: int,
+                        eos_id: int = 2, pad_id: int = 0, key_mask: Optional[torch.Tensor] = None):
+        """ids int64 [B,T] left-padded with pad_id; mask inferred as ids.ne(pad_id) like HF. Returns dict with
+        tokens [B,n], scores list of [B,V] (model dtype), margins [n,B] (top1-top2 gap in fp32), n steps."""
+        B, T = ids.shape
+        if key_mask is None:
+            key_mask = ids.ne(pad_id).long()
+        x = self.embed(ids, qformer_embs)
+        pos = positions_from_mask(key_mask)
+        logits, past, _ = self.forward(x, key_mask, pos)
+        unfinished = torch.ones(B, dtype=torch.long)
+        toks, scores, margins = [], [], []
+        E = self.W["model.embed_tokens.weight"]
+        for step in range(max_new):
+            row = logits[:, -1, :]
+            scores.append(row.clone())
+            top2 = row.float().topk(2, dim=-1).values
+            margins.append(top2[:, 0] - top2[:, 1])
+            nxt = row.argmax(dim=-1)
+            if eos_id >= 0:
+                nxt = nxt * unfinished + pad_id * (1 - unfinished)
+            toks.append(nxt)
+            if eos_id >= 0:
+                unfinished = unfinished * (nxt != eos_id).long()
+            key_mask = torch.cat([key_mask, key_mask.new_ones(B, 1)], dim=-1)
+            if (eos_id >= 0 and unfinished.max() == 0) or step == max_new - 1:
+                break
+            pos = positions_from_mask(key_mask)[:, -1:]
+            x = F.embedding(nxt[:, None].clamp(max=E.shape[0] - 1), E)
+            logits, past, _ = self.forward(x, key_mask, pos, past)
+        return {"tokens": torch.stack(toks, dim=1), "scores": scores, "margins": torch.stack(margins, 0)}
+
+
+# =====================================================================================================
+# optional two-image mode: VisionTransformerPooler       reference: biovil_t/transformer.py:73-266
+# =====================================================================================================
+def sine_pos_embed(grid: int, dim: int, temperature: float = 10000.0) -> torch.Tensor:
+    """SinePositionEmbedding(normalize=True) (transformer.py:248-266) -> [1, grid*grid, dim]."""
+    npf = dim // 2
+    scale = 2 * math.pi
+    ones = torch.ones(1, grid, grid)
+    y = ones.cumsum(1, dtype=torch.float32)
+    x = ones.cumsum(2, dtype=torch.float32)
+    y = y / (y[:, -1:, :] + 1e-6) * scale
+    x = x / (x[:, :, -1:] + 1e-6) * scale
+    dim_t = torch.arange(npf, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / npf)
+    px = x[:, :, :, None] / dim_t
+    py = y[:, :, :, None] / dim_t
+    px = torch.stack((px[:, :, :, 0::2].sin(), px[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[:, :, :, 0::2].sin(), py[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3).view(1, grid * grid, dim)

@@ -1,0 +1,96 @@
+"""The CPU oracle (oracle/ref_cpu.py) against golden vectors produced by the REFERENCE's own modules
+(oracle/make_golden.py, run in the build container). This is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from oracle.make_golden import golden_llama_cfg, golden_qformer_cfg
+from radialog_amd import synth
+from radialog_amd.config import VisionCfg
+
+DT = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module")
+def llama_gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "llama_tiny.npz"))
+
+
+@pytest.fixture(scope="module")
+def llama_weights():
+    return synth.make_weights(synth.llama_specs(golden_llama_cfg(), lora=False))
+
+
+@pytest.mark.parametrize("tag", ["f32", "f16", "bf16"])
+def test_llama_prefill_and_greedy_match_reference(llama_gold, llama_weights, tag):
+    g = llama_gold
+    c = golden_llama_cfg()
+    orc = ref_cpu.LlamaOracle(llama_weights, c, DT[tag], lora=False)
+    ids = torch.from_numpy(g["ids"])
+    qf = torch.from_numpy(g["qformer_embs"])
+    km = ids.ne(0).long()
+    x = orc.embed(ids, qf)
+    logits, past, _ = orc.forward(x, km, ref_cpu.positions_from_mask(km), all_logits=True)
+    # same torch ops in the same order on the same machine: bit-exact, in every dtype
+    assert np.array_equal(logits.float().numpy(), g[f"prefill_logits_{tag}"])
+    assert np.array_equal(past[0][0].float().numpy(), g[f"prefill_k0_{tag}"])
+    assert np.array_equal(past[1][1].float().numpy(), g[f"prefill_v1_{tag}"])
+    out = orc.generate_greedy(ids, qf, max_new=8, eos_id=2, pad_id=0)
+    assert np.array_equal(out["tokens"].numpy(), g[f"tokens_{tag}"])
+    got = np.stack([s.float().numpy() for s in out["scores"]], 0)
+    # the oracle's greedy loop computes the prefill lm_head for the last position only (the reference computes
+    # all T positions): a different GEMM shape on the same operands -> last-bit differences only
+    atol = {"f32": 2e-6, "f16": 2e-3, "bf16": 1.6e-2}[tag]
+    np.testing.assert_allclose(got, g[f"step_logits_{tag}"], rtol=0, atol=atol)
+
+
+def test_split_at_img_quirks(llama_gold):
+    ids = torch.from_numpy(llama_gold["ids"])
+    pos = ref_cpu.split_positions(ids)
+    T = ids.shape[1]
+    assert np.array_equal(pos.numpy(), llama_gold["split_left_len"])
+    assert np.array_equal(T - pos.numpy() - 32, llama_gold["split_right_len"])
+    assert int(pos[2]) == 0          # row without <IMG>: left = [], tokens 0..31 dropped
+
+
+def test_rope_and_rmsnorm(llama_gold):
+    c = golden_llama_cfg()
+    cos, sin = ref_cpu.rope_tables(c.head_dim, 64, c.rope_base, torch.float32)
+    assert np.array_equal(cos.numpy(), llama_gold["rope_cos_f32"])
+    assert np.array_equal(sin.numpy(), llama_gold["rope_sin_f32"])
+    w = synth.make_weights({k: v for k, v in synth.llama_specs(c, lora=False).items() if k == "model.norm.weight"})
+    x = torch.from_numpy(llama_gold["rms_in"])
+    assert np.array_equal(ref_cpu.rmsnorm(x, w["model.norm.weight"], c.rms_eps).numpy(), llama_gold["rms_out_f32"])
+    y16 = ref_cpu.rmsnorm(x.half(), w["model.norm.weight"].half(), c.rms_eps)
+    assert np.array_equal(y16.float().numpy(), llama_gold["rms_out_f16"])
+
+
+def test_positions_left_padded():
+    m = torch.tensor([[0, 0, 1, 1, 1, 1]])
+    assert ref_cpu.positions_from_mask(m).tolist() == [[1, 1, 0, 1, 2, 3]]
+
+
+def test_qformer_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "qformer_small.npz"))
+    q = golden_qformer_cfg()
+    W = synth.make_weights(synth.qformer_specs(q))
+    out = ref_cpu.qformer(torch.from_numpy(g["img"]), W, q)
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=2e-6)
+
+
+def test_projector_scramble_layernorm(golden_dir):
+    g = np.load(os.path.join(golden_dir, "projector.npz"))
+    v = VisionCfg(img=128, stem=32, planes=(32, 64, 128, 256), blocks=(1, 2, 2, 1), b2v=64, proj=352)
+    W = synth.make_weights(synth.vision_specs(v))
+    x = torch.from_numpy(g["x"])
+    pp = ref_cpu.projector(x, W, v)
+    np.testing.assert_allclose(pp.numpy(), g["projected"], rtol=0, atol=1e-5)
+    emb = torch.nn.functional.layer_norm(pp.reshape(2, -1, v.proj), (v.proj,), W["ln_vision.weight"],
+                                         W["ln_vision.bias"], v.ln_eps)
+    np.testing.assert_allclose(emb.numpy(), g["image_embeds"], rtol=0, atol=1e-5)
+    # the scramble: row r of the token matrix is flat elements r*C..(r+1)*C-1 of the [C, g*g] matrix
+    flat = pp[0].reshape(-1)
+    assert torch.equal(pp.reshape(2, -1, v.proj)[0, 3], flat[3 * v.proj: 4 * v.proj])
