@@ -1,0 +1,99 @@
+/* librdx -- C ABI of the MI355X-native RaDialog inference path (image encode -> prompt project -> Llama greedy decode).
+ *
+ * The reference (ChantalMP/RaDialog) has no FFI: its boundary for this path is the Python object API that demo.py /
+ * test.py call. librdx sits directly underneath radialog_amd's mirror of that API; each entry point below names the
+ * reference interface it replaces. Conventions:
+ *   - extern "C", plain pointers and sizes, no torch types. Every data pointer is a DEVICE pointer on the context's
+ *     GPU (what torch.Tensor.data_ptr() returns) unless the name ends in _host.
+ *   - every function returns 0 on success or a negative error code; rdx_last_error() returns the message. Nothing
+ *     throws across the boundary; the library never frees caller memory; outputs are written to caller buffers.
+ *   - one rdx_ctx per (process, device); not thread-safe (callers serialise per context). All work is enqueued on
+ *     the context's own HIP stream; rdx_sync() blocks until it has drained. Functions that return host-visible
+ *     results (rdx_generate's n_steps) synchronise internally.
+ */
+#ifndef RDX_H
+#define RDX_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rdx_ctx rdx_ctx;
+
+enum { RDX_DTYPE_F16 = 0, RDX_DTYPE_BF16 = 1 };
+enum { RDX_W_GEMM = 0,   /* [rows=N][cols=K] fp32 -> model dtype, re-laid-out into MFMA fragment order            */
+       RDX_W_TENSOR = 1, /* [rows][cols] fp32 -> model dtype, row-major (embeddings, norm weights, LoRA B, RoPE)    */
+       RDX_W_F32 = 2 };  /* [rows][cols] fp32 kept as fp32 (biases, LayerNorm gamma/beta)                           */
+
+typedef struct rdx_config {
+    int dtype;                                     /* RDX_DTYPE_* : arithmetic type of weights/activations         */
+    /* Llama decoder (modeling_llama_imgemb.py:433-843; dims of lmsys/vicuna-7b-v1.3) */
+    int vocab, hidden, inter, layers, heads, max_pos;
+    float rms_eps;
+    int lora_r; float lora_scale;                  /* 0 = no adapter; peft LoRA on q_proj,v_proj (finetune.py:167) */
+    int qformer_dim;                               /* img_proj_layer input width (demo.py:229)                     */
+    /* Q-Former (Qformer.py; blip2.py:47-62) */
+    int q_hidden, q_layers, q_heads, q_inter, q_enc_width, q_nquery, q_cross_freq;
+    float q_ln_eps;
+    /* BioViL-T image encoder (biovil_t/encoder.py:86-136, resnet.py:15-47, model.py:33-91) */
+    int v_img, v_stem, v_planes[4], v_blocks[4], v_b2v, v_proj;
+    float v_ln_eps;
+    /* capacities */
+    int max_batch;                                 /* decode rows held in the KV cache                             */
+    int max_len;                                   /* KV slots per row (prompt + generated), multiple of 32        */
+    int enable_vision, enable_llama;               /* build only one half if 0                                     */
+} rdx_config;
+
+/* lifecycle -- replaces model construction (demo.py:149-153 init_blip, :221-236 init_vicuna) */
+int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg);
+void rdx_destroy(rdx_ctx* ctx);
+const char* rdx_last_error(rdx_ctx* ctx);          /* ctx may be NULL: last error of a failed rdx_create           */
+int rdx_sync(rdx_ctx* ctx);
+void* rdx_stream(rdx_ctx* ctx);                    /* hipStream_t of the context                                   */
+
+/* weights -- replaces load_checkpoint / from_pretrained / PeftModel.from_pretrained (base_model.py:29-56,
+ * demo.py:224-234). `name` is an engine tensor name (radialog_amd/weights.py maps reference state_dict keys to them);
+ * `data` is a device fp32 tensor, copied/converted into library-owned storage (the caller may free it afterwards). */
+int rdx_set_weight(rdx_ctx* ctx, const char* name, const float* data, int64_t rows, int64_t cols, int kind);
+int rdx_finalize_weights(rdx_ctx* ctx);            /* resolves names, checks completeness, allocates workspaces    */
+
+/* Blip2Qformer.forward_image (blip2_qformer.py:467-484): image float32[B,3,S,S] ->
+ *   qformer_out float32[B,n_query,q_hidden] (last_hidden_state), image_embeds float32[B,P,v_proj] (nullable). */
+int rdx_encode_image(rdx_ctx* ctx, const float* image, int batch, float* qformer_out, float* image_embeds);
+
+/* LlamaForCausalLM.generate(..., num_beams=1) as the reference calls it (demo.py:290-297, test.py:339-348):
+ * greedy search (transformers 4.28.1 GenerationMixin.greedy_search) over LlamaForCausalLM.forward with the image
+ * splice (modeling_llama_imgemb.py:571-594).
+ *   ids          int32[B,T]   left-padded prompt token ids
+ *   mask         int32[B,T]   attention mask, or NULL -> ids != pad_id (HF's inferred mask)
+ *   qformer_embs float32[B,32,qformer_dim] or NULL (no image splice: `dicom is None and not use_img`)
+ *   eos_id       -1 = never stop (throughput runs)
+ *   out_tokens   int32[B,max_new]  generated ids; finished rows emit pad_id
+ *   scores       model-dtype [max_new][B][vocab] per-step logits (`output_scores=True`), or NULL
+ *   n_steps_host host int: number of steps executed (< max_new when every row hit EOS)
+ *   use_graph    replay one captured hipGraph per decode step instead of ~160 eager launches */
+int rdx_generate(rdx_ctx* ctx, const int32_t* ids, const int32_t* mask, int batch, int T, const float* qformer_embs,
+                 int max_new, int eos_id, int pad_id, int32_t* out_tokens, void* scores, int* n_steps_host,
+                 int use_graph);
+
+/* The two halves of rdx_generate, for callers that drive the loop themselves (prepare_inputs_for_generation +
+ * forward, modeling_llama_imgemb.py:705-836). rdx_prefill runs the prompt and selects token 0; each rdx_decode_step
+ * consumes the previously selected token and selects the next. logits: model-dtype [B][vocab] of that step or NULL. */
+int rdx_prefill(rdx_ctx* ctx, const int32_t* ids, const int32_t* mask, int batch, int T, const float* qformer_embs,
+                int max_new, int eos_id, int pad_id, int32_t* out_tokens, void* logits);
+int rdx_decode_step(rdx_ctx* ctx, void* logits);
+
+/* introspection for tests / benchmarks */
+int rdx_kv_read(rdx_ctx* ctx, int layer, int which /*0=K,1=V*/, void* dst /*model dtype [B][heads][max_len][D]*/);
+int rdx_hidden_read(rdx_ctx* ctx, void* dst /*model dtype [B][hidden]: decoder output rows of the last call*/);
+/* average duration (ms) of one hot-path unit, measured with HIP events on the context's stream:
+ *   what = 0: one decode step (whole graph) at the current state, `iters` replays
+ *   what = 1: the gate/up SwiGLU weight-streaming GEMV of every layer in turn, `iters` sweeps -> ms per launch
+ *   what = 2: ... the QKV GEMV, 3: o_proj, 4: down_proj, 5: lm_head */
+int rdx_time(rdx_ctx* ctx, int what, int iters, float* ms_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDX_H */

@@ -1,0 +1,95 @@
+"""ctypes binding of librdx.so (the C ABI declared in include/rdx.h).
+
+There is NO CPU fallback: if the HIP library is missing or cannot be loaded, importing callers get an
+`RdxLibraryError` -- the product path never routes around the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librdx.so")
+
+RDX_DTYPE_F16, RDX_DTYPE_BF16 = 0, 1
+RDX_W_GEMM, RDX_W_TENSOR, RDX_W_F32 = 0, 1, 2
+
+
+class RdxLibraryError(RuntimeError):
+    pass
+
+
+class RdxError(RuntimeError):
+    pass
+
+
+class RdxConfig(C.Structure):
+    _fields_ = [
+        ("dtype", C.c_int),
+        ("vocab", C.c_int), ("hidden", C.c_int), ("inter", C.c_int), ("layers", C.c_int), ("heads", C.c_int),
+        ("max_pos", C.c_int),
+        ("rms_eps", C.c_float),
+        ("lora_r", C.c_int), ("lora_scale", C.c_float),
+        ("qformer_dim", C.c_int),
+        ("q_hidden", C.c_int), ("q_layers", C.c_int), ("q_heads", C.c_int), ("q_inter", C.c_int),
+        ("q_enc_width", C.c_int), ("q_nquery", C.c_int), ("q_cross_freq", C.c_int),
+        ("q_ln_eps", C.c_float),
+        ("v_img", C.c_int), ("v_stem", C.c_int), ("v_planes", C.c_int * 4), ("v_blocks", C.c_int * 4),
+        ("v_b2v", C.c_int), ("v_proj", C.c_int),
+        ("v_ln_eps", C.c_float),
+        ("max_batch", C.c_int), ("max_len", C.c_int),
+        ("enable_vision", C.c_int), ("enable_llama", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes): every symbol include/rdx.h declares
+_P = C.c_void_p
+SYMBOLS = {
+    "rdx_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(RdxConfig)]),
+    "rdx_destroy": (None, [_P]),
+    "rdx_last_error": (C.c_char_p, [_P]),
+    "rdx_sync": (C.c_int, [_P]),
+    "rdx_stream": (_P, [_P]),
+    "rdx_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.c_int64, C.c_int]),
+    "rdx_finalize_weights": (C.c_int, [_P]),
+    "rdx_encode_image": (C.c_int, [_P, _P, C.c_int, _P, _P]),
+    "rdx_generate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P,
+                               C.POINTER(C.c_int), C.c_int]),
+    "rdx_prefill": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rdx_decode_step": (C.c_int, [_P, _P]),
+    "rdx_kv_read": (C.c_int, [_P, C.c_int, C.c_int, _P]),
+    "rdx_hidden_read": (C.c_int, [_P, _P]),
+    "rdx_time": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librdx.so and bind every C-ABI symbol; raises RdxLibraryError if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RdxLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m radialog_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the RaDialog hot path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise RdxLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RdxLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx, rc: int, what: str):
+    if rc != 0:
+        msg = load().rdx_last_error(ctx)
+        raise RdxError(f"{what} failed ({rc}): {msg.decode() if msg else '?'}")

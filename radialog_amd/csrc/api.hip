@@ -1,0 +1,716 @@
+// librdx C ABI: context, weight registry, and the host-side orchestration of the hot path
+// (image encode -> Q-Former -> img_proj + <IMG> splice -> Llama prefill -> hipGraph-captured greedy decode).
+// Kernels live in gemm.hip / attn.hip / elem.hip; this file only sequences launches on the context's stream.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rdx.h"
+#include "rdx_common.h"
+#include "rdx_kernels.h"
+
+using namespace rdx;
+
+namespace {
+
+struct GemmW { void* w = nullptr; int N = 0, K = 0, Npad = 0; };
+struct RawW { void* p = nullptr; int64_t rows = 0, cols = 0; };
+
+struct LlamaLayer {
+    const void *attn_norm, *mlp_norm, *lora_bq, *lora_bv;
+    GemmW wqkv, wo, wgu, wdown;
+};
+struct QLayer {
+    GemmW s_wqkv, s_wo, c_wq, c_wo, w1, w2;
+    const float *s_bqkv, *s_bo, *s_g, *s_b, *c_bq, *c_bo, *c_g, *c_b, *b1, *b2, *f_g, *f_b;
+    int cross_idx;     // -1 = no cross attention in this layer
+};
+struct VBlock {
+    GemmW c1, c2, c3, ds;
+    const float *b1, *b2, *b3, *bds;
+    bool has_ds;
+    int planes, stride;
+};
+
+struct GraphKey {
+    int B = -1, max_new = 0, eos = 0, pad = 0;
+    const void* tokens = nullptr; const void* scores = nullptr;
+    bool operator==(const GraphKey& o) const {
+        return B == o.B && max_new == o.max_new && eos == o.eos && pad == o.pad && tokens == o.tokens && scores == o.scores;
+    }
+};
+
+}  // namespace
+
+struct rdx_ctx {
+    rdx_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool finalized = false;
+    std::vector<void*> allocs;
+
+    std::map<std::string, GemmW> gemm;
+    std::map<std::string, RawW> tens;     // model dtype
+    std::map<std::string, RawW> f32;
+
+    // ---- llama ----
+    std::vector<LlamaLayer> ll;
+    const void *embed = nullptr, *final_norm = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+    GemmW lm_head, img_proj_w;
+    const float* img_proj_b = nullptr;
+    LlamaDims ld;
+    void *kcache = nullptr, *vcache = nullptr;     // [layers][B][heads][max_len][D]
+    size_t kv_layer_elems = 0;
+    uint8_t* key_mask = nullptr;                   // [B][max_len]
+    int *d_img_pos = nullptr, *d_pos_ids = nullptr, *d_pos = nullptr, *d_slot = nullptr, *d_step = nullptr, *d_unf = nullptr;
+    float* part_val = nullptr; int* part_idx = nullptr; int n_vtiles = 0;
+    // decode-step activations ([max_batch] rows) and prefill activations (grown on demand)
+    void *dx = nullptr, *dqkv = nullptr, *datt = nullptr, *dgu = nullptr;
+    void *px = nullptr, *pxn = nullptr, *pqkv = nullptr, *pq = nullptr, *patt = nullptr, *pgu = nullptr, *pqe = nullptr, *pimg = nullptr;
+    size_t prefill_rows = 0;
+    int cur_B = 0, cur_T = 0, cur_max_new = 0, cur_eos = -1, cur_pad = 0;
+    int32_t* cur_tokens = nullptr;
+    hipGraphExec_t graph = nullptr;
+    GraphKey gkey;
+
+    // ---- q-former ----
+    std::vector<QLayer> ql;
+    const void* q_query_ln = nullptr;
+    GemmW q_wkv; const float* q_bkv = nullptr; int n_cross = 0;
+    // ---- vision ----
+    GemmW v_conv1, v_b2v, v_p1, v_p2;
+    const float *v_conv1_b = nullptr, *v_p1_b = nullptr, *v_p2_b = nullptr, *v_ln_g = nullptr, *v_ln_b = nullptr;
+    std::vector<VBlock> vb;
+    int enc_batch = 0;
+    void *vin = nullptr, *vbuf[4] = {nullptr, nullptr, nullptr, nullptr}, *v_imgemb = nullptr;
+    void *qx = nullptr, *qt = nullptr, *qqkv = nullptr, *qctx = nullptr, *qh = nullptr, *qkvx = nullptr;
+};
+
+static std::string g_create_err;
+
+static int fail(rdx_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) return fail((c), -2, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static size_t esz(const rdx_ctx* c) { (void)c; return 2; }
+
+static int dalloc(rdx_ctx* c, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail(c, -3, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    c->allocs.push_back(*p);
+    return 0;
+}
+#define ALLOC(c, ptr, bytes) do { int rc_ = dalloc((c), (void**)&(ptr), (bytes)); if (rc_) return rc_; } while (0)
+
+// ------------------------------------------------------------------------------------------------------------------
+// GEMM dispatch
+// ------------------------------------------------------------------------------------------------------------------
+static GemmArgs gargs(const void* X, int ldx, const GemmW& W, const float* bias, void* out, int ldo, int M) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = X; a.ldx = ldx; a.W = W.w; a.bias = bias; a.out = out; a.ldo = ldo;
+    a.M = M; a.N = W.N; a.K = W.K; a.n_valid = W.N;
+    return a;
+}
+
+static void run_gemm(rdx_ctx* c, GemmArgs a, int epi) {
+    ConvGeom cg;
+    memset(&cg, 0, sizeof(cg));
+    if (a.M <= 32) launch_skinny_gemm(c->cfg.dtype, a, epi == EPI_RESID_RELU ? EPI_RESID : epi, c->stream);
+    else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// lifecycle
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
+    if (!out || !cfg) return fail(nullptr, -1, "rdx_create: null argument");
+    if (cfg->dtype != RDX_DTYPE_F16 && cfg->dtype != RDX_DTYPE_BF16) return fail(nullptr, -1, "rdx_create: bad dtype %d", cfg->dtype);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, -2, "rdx_create: no HIP device (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, -1, "rdx_create: device %d out of range (%d devices)", device_id, ndev);
+    if (cfg->enable_llama) {
+        if (cfg->hidden % cfg->heads || cfg->hidden / cfg->heads != 128)
+            return fail(nullptr, -1, "rdx_create: Llama head_dim must be 128 (hidden %d / heads %d)", cfg->hidden, cfg->heads);
+        if (cfg->hidden % 32 || cfg->inter % 32 || cfg->inter % 8 || cfg->qformer_dim % 32)
+            return fail(nullptr, -1, "rdx_create: hidden/inter/qformer_dim must be multiples of 32");
+        if (cfg->max_len % 32 || cfg->max_len <= 0 || cfg->max_len > 1536)
+            return fail(nullptr, -1, "rdx_create: max_len must be a multiple of 32 in (0, 1536]");
+        if (cfg->max_batch <= 0 || cfg->max_batch > 32) return fail(nullptr, -1, "rdx_create: max_batch must be in [1, 32]");
+        if (cfg->lora_r != 0 && cfg->lora_r != 8) return fail(nullptr, -1, "rdx_create: lora_r must be 0 or 8");
+    }
+    if (cfg->enable_vision) {
+        if (cfg->q_hidden / cfg->q_heads != 64 || cfg->q_hidden % cfg->q_heads)
+            return fail(nullptr, -1, "rdx_create: Q-Former head_dim must be 64");
+        if (cfg->v_img % 32) return fail(nullptr, -1, "rdx_create: image size must be a multiple of 32");
+    }
+    rdx_ctx* c = new rdx_ctx();
+    c->cfg = *cfg;
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return fail(nullptr, -2, "rdx_create: cannot create stream on device %d", device_id);
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void rdx_destroy(rdx_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (c->graph) hipGraphExecDestroy(c->graph);
+    for (void* p : c->allocs) hipFree(p);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* rdx_last_error(rdx_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int rdx_sync(rdx_ctx* c) {
+    if (!c) return -1;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+extern "C" void* rdx_stream(rdx_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int rdx_set_weight(rdx_ctx* c, const char* name, const float* data, int64_t rows, int64_t cols, int kind) {
+    if (!c || !name || !data) return fail(c, -1, "rdx_set_weight: null argument");
+    if (c->finalized) return fail(c, -1, "rdx_set_weight(%s): weights already finalized", name);
+    if (rows <= 0 || cols <= 0) return fail(c, -1, "rdx_set_weight(%s): bad shape [%lld,%lld]", name, (long long)rows, (long long)cols);
+    HIPCHK(c, hipSetDevice(c->device));
+    const std::string key(name);
+    if (kind == RDX_W_GEMM) {
+        if (cols % 32) return fail(c, -1, "rdx_set_weight(%s): GEMM K=%lld must be a multiple of 32", name, (long long)cols);
+        if (c->gemm.count(key)) return fail(c, -1, "rdx_set_weight(%s): duplicate", name);
+        GemmW w;
+        w.N = (int)rows; w.K = (int)cols; w.Npad = (int)((rows + 15) / 16 * 16);
+        ALLOC(c, w.w, (size_t)w.Npad * w.K * esz(c));
+        launch_pack_weight(c->cfg.dtype, data, w.w, w.N, w.K, w.Npad, nullptr, c->stream);
+        c->gemm[key] = w;
+    } else if (kind == RDX_W_TENSOR) {
+        if (c->tens.count(key)) return fail(c, -1, "rdx_set_weight(%s): duplicate", name);
+        RawW r; r.rows = rows; r.cols = cols;
+        ALLOC(c, r.p, (size_t)rows * cols * esz(c) + 16);
+        launch_from_f32(c->cfg.dtype, data, r.p, (size_t)rows * cols, c->stream);
+        c->tens[key] = r;
+    } else if (kind == RDX_W_F32) {
+        if (c->f32.count(key)) return fail(c, -1, "rdx_set_weight(%s): duplicate", name);
+        RawW r; r.rows = rows; r.cols = cols;
+        ALLOC(c, r.p, (size_t)rows * cols * sizeof(float));
+        HIPCHK(c, hipMemcpyAsync(r.p, data, (size_t)rows * cols * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        c->f32[key] = r;
+    } else {
+        return fail(c, -1, "rdx_set_weight(%s): unknown kind %d", name, kind);
+    }
+    // the caller may free `data` as soon as we return
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+namespace {
+struct Resolver {
+    rdx_ctx* c;
+    int rc = 0;
+    GemmW g(const std::string& n, int N, int K) {
+        auto it = c->gemm.find(n);
+        if (it == c->gemm.end()) { if (!rc) rc = fail(c, -4, "missing GEMM weight '%s'", n.c_str()); return GemmW(); }
+        if (it->second.N != N || it->second.K != K) {
+            if (!rc) rc = fail(c, -4, "weight '%s' has shape [%d,%d], expected [%d,%d]", n.c_str(), it->second.N, it->second.K, N, K);
+        }
+        return it->second;
+    }
+    const void* t(const std::string& n, int64_t elems) {
+        auto it = c->tens.find(n);
+        if (it == c->tens.end()) { if (!rc) rc = fail(c, -4, "missing tensor '%s'", n.c_str()); return nullptr; }
+        if (it->second.rows * it->second.cols != elems) { if (!rc) rc = fail(c, -4, "tensor '%s' has %lld elements, expected %lld", n.c_str(), (long long)(it->second.rows * it->second.cols), (long long)elems); }
+        return it->second.p;
+    }
+    const float* f(const std::string& n, int64_t elems) {
+        auto it = c->f32.find(n);
+        if (it == c->f32.end()) { if (!rc) rc = fail(c, -4, "missing fp32 tensor '%s'", n.c_str()); return nullptr; }
+        if (it->second.rows * it->second.cols != elems) { if (!rc) rc = fail(c, -4, "fp32 tensor '%s' has %lld elements, expected %lld", n.c_str(), (long long)(it->second.rows * it->second.cols), (long long)elems); }
+        return (const float*)it->second.p;
+    }
+};
+std::string S(const char* fmt, ...) {
+    char buf[128];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    return buf;
+}
+}  // namespace
+
+extern "C" int rdx_finalize_weights(rdx_ctx* c) {
+    if (!c) return -1;
+    if (c->finalized) return fail(c, -1, "rdx_finalize_weights: already finalized");
+    HIPCHK(c, hipSetDevice(c->device));
+    const rdx_config& f = c->cfg;
+    Resolver R{c};
+    if (f.enable_llama) {
+        const int H = f.hidden, I = f.inter, r2 = 2 * f.lora_r;
+        c->embed = R.t("embed", (int64_t)f.vocab * H);
+        c->final_norm = R.t("final_norm", H);
+        c->rope_cos = R.t("rope.cos", (int64_t)f.max_pos * 128);
+        c->rope_sin = R.t("rope.sin", (int64_t)f.max_pos * 128);
+        c->lm_head = R.g("lm_head", f.vocab, H);
+        c->img_proj_w = R.g("img_proj.w", H, f.qformer_dim);
+        c->img_proj_b = R.f("img_proj.b", H);
+        c->ll.resize(f.layers);
+        for (int l = 0; l < f.layers; ++l) {
+            LlamaLayer& L = c->ll[l];
+            L.attn_norm = R.t(S("l%d.attn_norm", l), H);
+            L.mlp_norm = R.t(S("l%d.mlp_norm", l), H);
+            L.wqkv = R.g(S("l%d.wqkv", l), 3 * H + r2, H);
+            L.wo = R.g(S("l%d.wo", l), H, H);
+            L.wgu = R.g(S("l%d.wgu", l), 2 * I, H);
+            L.wdown = R.g(S("l%d.wdown", l), H, I);
+            L.lora_bq = L.lora_bv = nullptr;
+            if (f.lora_r) {
+                L.lora_bq = R.t(S("l%d.lora_bq", l), (int64_t)H * f.lora_r);
+                L.lora_bv = R.t(S("l%d.lora_bv", l), (int64_t)H * f.lora_r);
+            }
+        }
+        if (R.rc) return R.rc;
+        c->ld.hidden = H; c->ld.heads = f.heads; c->ld.head_dim = 128; c->ld.qkv_ld = c->ll[0].wqkv.Npad;
+        c->ld.lora_r = f.lora_r; c->ld.lora_scale = f.lora_scale; c->ld.max_len = f.max_len; c->ld.max_pos = f.max_pos;
+        const int B = f.max_batch;
+        c->kv_layer_elems = (size_t)B * f.heads * f.max_len * 128;
+        ALLOC(c, c->kcache, c->kv_layer_elems * f.layers * 2);
+        ALLOC(c, c->vcache, c->kv_layer_elems * f.layers * 2);
+        ALLOC(c, c->key_mask, (size_t)B * f.max_len);
+        ALLOC(c, c->d_img_pos, B * sizeof(int)); ALLOC(c, c->d_pos, B * sizeof(int)); ALLOC(c, c->d_slot, B * sizeof(int));
+        ALLOC(c, c->d_step, B * sizeof(int)); ALLOC(c, c->d_unf, B * sizeof(int));
+        ALLOC(c, c->d_pos_ids, (size_t)B * f.max_len * sizeof(int));
+        c->n_vtiles = c->lm_head.Npad / 16;
+        ALLOC(c, c->part_val, (size_t)B * c->n_vtiles * sizeof(float));
+        ALLOC(c, c->part_idx, (size_t)B * c->n_vtiles * sizeof(int));
+        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
+        ALLOC(c, c->datt, (size_t)B * H * 2); ALLOC(c, c->dgu, (size_t)B * I * 2);
+    }
+    if (f.enable_vision) {
+        const int H = f.q_hidden, I = f.q_inter;
+        c->q_query_ln = R.t("q.query_ln", (int64_t)f.q_nquery * H);
+        c->n_cross = 0;
+        c->ql.resize(f.q_layers);
+        for (int l = 0; l < f.q_layers; ++l) {
+            QLayer& L = c->ql[l];
+            L.s_wqkv = R.g(S("q%d.self.wqkv", l), 3 * H, H); L.s_bqkv = R.f(S("q%d.self.bqkv", l), 3 * H);
+            L.s_wo = R.g(S("q%d.self.wo", l), H, H); L.s_bo = R.f(S("q%d.self.bo", l), H);
+            L.s_g = R.f(S("q%d.self.ln_g", l), H); L.s_b = R.f(S("q%d.self.ln_b", l), H);
+            L.cross_idx = -1;
+            if (l % f.q_cross_freq == 0) {
+                L.cross_idx = c->n_cross++;
+                L.c_wq = R.g(S("q%d.cross.wq", l), H, H); L.c_bq = R.f(S("q%d.cross.bq", l), H);
+                L.c_wo = R.g(S("q%d.cross.wo", l), H, H); L.c_bo = R.f(S("q%d.cross.bo", l), H);
+                L.c_g = R.f(S("q%d.cross.ln_g", l), H); L.c_b = R.f(S("q%d.cross.ln_b", l), H);
+            }
+            L.w1 = R.g(S("q%d.ffn.w1", l), I, H); L.b1 = R.f(S("q%d.ffn.b1", l), I);
+            L.w2 = R.g(S("q%d.ffn.w2", l), H, I); L.b2 = R.f(S("q%d.ffn.b2", l), H);
+            L.f_g = R.f(S("q%d.ffn.ln_g", l), H); L.f_b = R.f(S("q%d.ffn.ln_b", l), H);
+        }
+        c->q_wkv = R.g("q.cross.wkv", c->n_cross * 2 * H, f.q_enc_width);
+        c->q_bkv = R.f("q.cross.bkv", (int64_t)c->n_cross * 2 * H);
+        // vision trunk
+        c->v_conv1 = R.g("v.conv1.w", f.v_stem, 7 * 8 * 4); c->v_conv1_b = R.f("v.conv1.b", f.v_stem);
+        int cin = f.v_stem;
+        for (int li = 0; li < 4; ++li) {
+            for (int b = 0; b < f.v_blocks[li]; ++b) {
+                VBlock vb;
+                vb.planes = f.v_planes[li];
+                vb.stride = (b == 0 && li > 0) ? 2 : 1;
+                vb.has_ds = (b == 0);
+                const std::string p = S("v.l%d.%d.", li + 1, b);
+                vb.c1 = R.g(p + "c1.w", vb.planes, cin); vb.b1 = R.f(p + "c1.b", vb.planes);
+                vb.c2 = R.g(p + "c2.w", vb.planes, 9 * vb.planes); vb.b2 = R.f(p + "c2.b", vb.planes);
+                vb.c3 = R.g(p + "c3.w", 4 * vb.planes, vb.planes); vb.b3 = R.f(p + "c3.b", 4 * vb.planes);
+                vb.bds = nullptr;
+                if (vb.has_ds) { vb.ds = R.g(p + "ds.w", 4 * vb.planes, cin); vb.bds = R.f(p + "ds.b", 4 * vb.planes); }
+                cin = 4 * vb.planes;
+                c->vb.push_back(vb);
+            }
+        }
+        c->v_b2v = R.g("v.b2v.w", f.v_b2v, cin);
+        c->v_p1 = R.g("v.proj1.w", f.v_proj, f.v_b2v); c->v_p1_b = R.f("v.proj1.b", f.v_proj);
+        c->v_p2 = R.g("v.proj2.w", f.v_proj, f.v_proj); c->v_p2_b = R.f("v.proj2.b", f.v_proj);
+        c->v_ln_g = R.f("v.ln.g", f.v_proj); c->v_ln_b = R.f("v.ln.b", f.v_proj);
+        if (f.q_enc_width != f.v_proj) return fail(c, -1, "q_enc_width %d != v_proj %d", f.q_enc_width, f.v_proj);
+    }
+    if (R.rc) return R.rc;
+    c->finalized = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// image encode
+// ------------------------------------------------------------------------------------------------------------------
+static int ensure_enc_ws(rdx_ctx* c, int B) {
+    if (B <= c->enc_batch) return 0;
+    const rdx_config& f = c->cfg;
+    const int S_ = f.v_img, Hp = S_ + 6;
+    // buffers are re-allocated (old ones stay in allocs until destroy; batch growth is rare)
+    const size_t act = (size_t)B * (S_ / 2) * (S_ / 2) * (size_t)std::max(f.v_stem, 1) * 2;   // conv1 output
+    size_t act2 = (size_t)B * (S_ / 4) * (S_ / 4) * (size_t)f.v_planes[0] * 4 * 2;           // layer1 output
+    size_t mx = std::max(act, act2);
+    const int P = (S_ / 32) * (S_ / 32);
+    mx = std::max(mx, (size_t)B * P * f.v_proj * 2);
+    ALLOC(c, c->vin, (size_t)B * Hp * Hp * 4 * 2);
+    for (int i = 0; i < 4; ++i) ALLOC(c, c->vbuf[i], mx);
+    ALLOC(c, c->v_imgemb, (size_t)B * P * f.v_proj * 2);
+    const size_t M = (size_t)B * f.q_nquery;
+    ALLOC(c, c->qx, M * f.q_hidden * 2); ALLOC(c, c->qt, M * f.q_hidden * 2);
+    ALLOC(c, c->qqkv, M * 3 * f.q_hidden * 2); ALLOC(c, c->qctx, M * f.q_hidden * 2);
+    ALLOC(c, c->qh, M * f.q_inter * 2);
+    ALLOC(c, c->qkvx, (size_t)B * P * c->n_cross * 2 * f.q_hidden * 2);
+    c->enc_batch = B;
+    return 0;
+}
+
+static void conv_gemm(rdx_ctx* c, const void* X, const GemmW& W, const float* bias, const void* resid, void* out, int B,
+                      int Hin, int Win, int Cin, int KH, int KW, int stride, int pad, int Hout, int Wout, int epi) {
+    GemmArgs a = gargs(X, Cin, W, bias, out, W.N, B * Hout * Wout);
+    a.resid = resid; a.ldr = W.N;
+    ConvGeom cg;
+    cg.mode = 1; cg.Hin = Hin; cg.Win = Win; cg.Cin = Cin; cg.Hout = Hout; cg.Wout = Wout;
+    cg.KH = KH; cg.KW = KW; cg.stride = stride; cg.pad = pad;
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0) cg.mode = 0;
+    // conv GEMMs always have M >= 16 rows of real work; route everything through the tiled kernel (gather support)
+    launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
+}
+
+extern "C" int rdx_encode_image(rdx_ctx* c, const float* image, int B, float* qformer_out, float* image_embeds) {
+    if (!c) return -1;
+    if (!c->finalized || !c->cfg.enable_vision) return fail(c, -1, "rdx_encode_image: vision weights not finalized");
+    if (!image || !qformer_out || B <= 0) return fail(c, -1, "rdx_encode_image: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_enc_ws(c, B);
+    if (rc) return rc;
+    const rdx_config& f = c->cfg;
+    const int dt = f.dtype, S_ = f.v_img, Hp = S_ + 6;
+    hipStream_t s = c->stream;
+
+    // a1/a2: stem. 7x7/2 conv as implicit GEMM over a zero-padded NHWC4 image: K = 7 x 8(kw, last is zero) x 4(c, last is zero)
+    launch_img_prep(dt, image, c->vin, B, S_, 3, Hp, Hp, s);
+    int Hc = S_ / 2;
+    conv_gemm(c, c->vin, c->v_conv1, c->v_conv1_b, nullptr, c->vbuf[0], B, Hp, Hp, 4, 7, 8, 2, 0, Hc, Hc, EPI_RELU);
+    launch_maxpool(dt, c->vbuf[0], c->vbuf[1], B, Hc, Hc, f.v_stem, s);
+    Hc = S_ / 4;
+    int C = f.v_stem;
+    void *cur = c->vbuf[1], *t1 = c->vbuf[0], *t2 = c->vbuf[2], *t3 = c->vbuf[3];
+    for (const VBlock& vb : c->vb) {
+        const int Ho = Hc / vb.stride;
+        conv_gemm(c, cur, vb.c1, vb.b1, nullptr, t1, B, Hc, Hc, C, 1, 1, 1, 0, Hc, Hc, EPI_RELU);
+        conv_gemm(c, t1, vb.c2, vb.b2, nullptr, t2, B, Hc, Hc, vb.planes, 3, 3, vb.stride, 1, Ho, Ho, EPI_RELU);
+        const void* idt = cur;
+        if (vb.has_ds) {
+            conv_gemm(c, cur, vb.ds, vb.bds, nullptr, t3, B, Hc, Hc, C, 1, 1, vb.stride, 0, Ho, Ho, EPI_NONE);
+            idt = t3;
+        }
+        conv_gemm(c, t2, vb.c3, vb.b3, idt, t1, B, Ho, Ho, vb.planes, 1, 1, 1, 0, Ho, Ho, EPI_RESID_RELU);
+        std::swap(cur, t1);
+        Hc = Ho; C = 4 * vb.planes;
+    }
+    // a3/a4: backbone_to_vit, projector (missing_previous_emb + BN folded into proj1's bias), NHWC output
+    const int P = Hc * Hc, MP = B * P;
+    { GemmArgs a = gargs(cur, C, c->v_b2v, nullptr, t1, f.v_b2v, MP); launch_tiled_gemm(dt, a, ConvGeom{0}, EPI_NONE, s); }
+    { GemmArgs a = gargs(t1, f.v_b2v, c->v_p1, c->v_p1_b, t2, f.v_proj, MP); launch_tiled_gemm(dt, a, ConvGeom{0}, EPI_RELU, s); }
+    { GemmArgs a = gargs(t2, f.v_proj, c->v_p2, c->v_p2_b, t3, f.v_proj, MP); launch_tiled_gemm(dt, a, ConvGeom{0}, EPI_NONE, s); }
+    // a5: NCHW reshape scramble + ln_vision
+    launch_scramble_layernorm(dt, t3, c->v_ln_g, c->v_ln_b, c->v_imgemb, image_embeds, B, P, f.v_proj, f.v_ln_eps, s);
+
+    // a6: Q-Former, query-only path
+    const int H = f.q_hidden, NQ = f.q_nquery, M = B * NQ, KVW = c->n_cross * 2 * H;
+    launch_broadcast_rows(dt, c->q_query_ln, c->qx, NQ, H, B, s);
+    { GemmArgs a = gargs(c->v_imgemb, f.v_proj, c->q_wkv, c->q_bkv, c->qkvx, KVW, MP); run_gemm(c, a, EPI_NONE); }
+    for (const QLayer& L : c->ql) {
+        { GemmArgs a = gargs(c->qx, H, L.s_wqkv, L.s_bqkv, c->qqkv, 3 * H, M); run_gemm(c, a, EPI_NONE); }
+        AttnArgs at;
+        memset(&at, 0, sizeof(at));
+        at.Q = c->qqkv; at.K = (const char*)c->qqkv + (size_t)H * 2; at.V = (const char*)c->qqkv + (size_t)2 * H * 2; at.O = c->qctx;
+        at.q_bs = at.k_bs = at.v_bs = (long)NQ * 3 * H; at.q_ts = at.k_ts = at.v_ts = 3 * H; at.q_hs = at.k_hs = at.v_hs = 64;
+        at.o_bs = (long)NQ * H; at.o_ts = H; at.o_hs = 64;
+        at.B = B; at.H = f.q_heads; at.Tq = NQ; at.Tk = NQ;
+        launch_attention(dt, 64, at, s);
+        { GemmArgs a = gargs(c->qctx, H, L.s_wo, L.s_bo, c->qt, H, M); a.resid = c->qx; a.ldr = H; run_gemm(c, a, EPI_RESID); }
+        launch_layernorm(dt, c->qt, L.s_g, L.s_b, c->qx, nullptr, M, H, f.q_ln_eps, s);
+        if (L.cross_idx >= 0) {
+            { GemmArgs a = gargs(c->qx, H, L.c_wq, L.c_bq, c->qqkv, H, M); run_gemm(c, a, EPI_NONE); }
+            memset(&at, 0, sizeof(at));
+            at.Q = c->qqkv; at.q_bs = (long)NQ * H; at.q_ts = H; at.q_hs = 64;
+            at.K = (const char*)c->qkvx + (size_t)L.cross_idx * 2 * H * 2; at.V = (const char*)at.K + (size_t)H * 2;
+            at.k_bs = at.v_bs = (long)P * KVW; at.k_ts = at.v_ts = KVW; at.k_hs = at.v_hs = 64;
+            at.O = c->qctx; at.o_bs = (long)NQ * H; at.o_ts = H; at.o_hs = 64;
+            at.B = B; at.H = f.q_heads; at.Tq = NQ; at.Tk = P;
+            launch_attention(dt, 64, at, s);
+            { GemmArgs a = gargs(c->qctx, H, L.c_wo, L.c_bo, c->qt, H, M); a.resid = c->qx; a.ldr = H; run_gemm(c, a, EPI_RESID); }
+            launch_layernorm(dt, c->qt, L.c_g, L.c_b, c->qx, nullptr, M, H, f.q_ln_eps, s);
+        }
+        { GemmArgs a = gargs(c->qx, H, L.w1, L.b1, c->qh, f.q_inter, M); run_gemm(c, a, EPI_GELU); }
+        { GemmArgs a = gargs(c->qh, f.q_inter, L.w2, L.b2, c->qt, H, M); a.resid = c->qx; a.ldr = H; run_gemm(c, a, EPI_RESID); }
+        const bool last = (&L == &c->ql.back());
+        launch_layernorm(dt, c->qt, L.f_g, L.f_b, c->qx, last ? qformer_out : nullptr, M, H, f.q_ln_eps, s);
+    }
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Llama prefill / decode
+// ------------------------------------------------------------------------------------------------------------------
+static int ensure_prefill_ws(rdx_ctx* c, size_t rows) {
+    if (rows <= c->prefill_rows) return 0;
+    const rdx_config& f = c->cfg;
+    ALLOC(c, c->px, rows * f.hidden * 2); ALLOC(c, c->pxn, rows * f.hidden * 2);
+    ALLOC(c, c->pqkv, rows * c->ld.qkv_ld * 2); ALLOC(c, c->pq, rows * f.hidden * 2);
+    ALLOC(c, c->patt, rows * f.hidden * 2); ALLOC(c, c->pgu, rows * f.inter * 2);
+    ALLOC(c, c->pqe, (size_t)f.max_batch * 32 * f.qformer_dim * 2);
+    ALLOC(c, c->pimg, (size_t)f.max_batch * 32 * f.hidden * 2);
+    c->prefill_rows = rows;
+    return 0;
+}
+
+static void* kv_ptr(rdx_ctx* c, void* base, int layer) { return (char*)base + (size_t)layer * c->kv_layer_elems * 2; }
+
+static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, const int* out_step, long step_stride,
+                               int advance) {
+    const rdx_config& f = c->cfg;
+    GemmArgs a = gargs(x, f.hidden, c->lm_head, nullptr, logits, f.vocab, B);
+    a.N = c->lm_head.Npad; a.n_valid = f.vocab;
+    a.norm_w = c->final_norm; a.eps = f.rms_eps;
+    a.part_val = c->part_val; a.part_idx = c->part_idx;
+    a.out_step = out_step; a.out_step_stride = step_stride;
+    launch_skinny_gemm(f.dtype, a, EPI_LOGITS, c->stream);
+    launch_greedy_step(f.dtype, c->part_val, c->part_idx, c->n_vtiles, B, c->cur_eos, c->cur_pad, c->cur_max_new,
+                       c->cur_tokens, c->d_unf, advance ? c->d_pos : nullptr, advance ? c->d_slot : nullptr, c->d_step,
+                       c->embed, f.vocab, c->dx, f.hidden, c->stream);
+}
+
+extern "C" int rdx_prefill(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int T, const float* qformer_embs,
+                           int max_new, int eos_id, int pad_id, int32_t* out_tokens, void* logits) {
+    if (!c) return -1;
+    if (!c->finalized || !c->cfg.enable_llama) return fail(c, -1, "rdx_prefill: llama weights not finalized");
+    const rdx_config& f = c->cfg;
+    if (!ids || !out_tokens || B <= 0 || B > f.max_batch) return fail(c, -1, "rdx_prefill: batch %d outside [1, %d]", B, f.max_batch);
+    if (T <= 0 || T + max_new > f.max_len) return fail(c, -1, "rdx_prefill: T (%d) + max_new (%d) exceeds max_len %d", T, max_new, f.max_len);
+    if (T + max_new > f.max_pos) return fail(c, -1, "rdx_prefill: sequence exceeds max_position_embeddings %d", f.max_pos);
+    if (qformer_embs && T < 32) return fail(c, -1, "rdx_prefill: image splice needs T >= 32");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t M = (size_t)B * T;
+    int rc = ensure_prefill_ws(c, M);
+    if (rc) return rc;
+    const int dt = f.dtype, H = f.hidden;
+    hipStream_t s = c->stream;
+    c->cur_B = B; c->cur_T = T; c->cur_max_new = max_new; c->cur_eos = eos_id; c->cur_pad = pad_id; c->cur_tokens = out_tokens;
+
+    launch_prep_prompt(ids, mask, B, T, 32000, pad_id, c->d_img_pos, c->d_pos_ids, c->key_mask, f.max_len, c->d_pos, c->d_slot,
+                       c->d_step, c->d_unf, s);
+    if (qformer_embs) {
+        // a8: img_proj_layer on the model-dtype copy of the Q-Former output (".half()", modeling_llama_imgemb.py:576-579)
+        launch_from_f32(dt, qformer_embs, c->pqe, (size_t)B * 32 * f.qformer_dim, s);
+        GemmArgs a = gargs(c->pqe, f.qformer_dim, c->img_proj_w, c->img_proj_b, c->pimg, H, B * 32);
+        run_gemm(c, a, EPI_NONE);
+    }
+    launch_embed_splice(dt, ids, c->d_img_pos, c->embed, f.vocab, c->pimg, 32, c->px, B, T, H, qformer_embs ? 1 : 0, s);
+
+    for (int l = 0; l < f.layers; ++l) {
+        const LlamaLayer& L = c->ll[l];
+        void* kc = kv_ptr(c, c->kcache, l);
+        void* vc = kv_ptr(c, c->vcache, l);
+        launch_rmsnorm(dt, c->px, L.attn_norm, c->pxn, (int)M, H, f.rms_eps, s);
+        { GemmArgs a = gargs(c->pxn, H, L.wqkv, nullptr, c->pqkv, c->ld.qkv_ld, (int)M); a.N = L.wqkv.Npad; run_gemm(c, a, EPI_NONE); }
+        launch_rope_kv_prefill(dt, c->ld, c->pqkv, L.lora_bq, L.lora_bv, c->rope_cos, c->rope_sin, c->d_pos_ids, c->pq, kc, vc, B, T, s);
+        AttnArgs at;
+        memset(&at, 0, sizeof(at));
+        at.Q = c->pq; at.q_bs = (long)T * H; at.q_ts = H; at.q_hs = 128;
+        at.K = kc; at.V = vc; at.k_bs = at.v_bs = (long)f.heads * f.max_len * 128; at.k_ts = at.v_ts = 128; at.k_hs = at.v_hs = (long)f.max_len * 128;
+        at.O = c->patt; at.o_bs = (long)T * H; at.o_ts = H; at.o_hs = 128;
+        at.B = B; at.H = f.heads; at.Tq = T; at.Tk = T; at.causal = 1; at.key_mask = c->key_mask; at.km_bs = f.max_len;
+        launch_attention(dt, 128, at, s);
+        { GemmArgs a = gargs(c->patt, H, L.wo, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H; run_gemm(c, a, EPI_RESID); }
+        launch_rmsnorm(dt, c->px, L.mlp_norm, c->pxn, (int)M, H, f.rms_eps, s);
+        { GemmArgs a = gargs(c->pxn, H, L.wgu, nullptr, c->pgu, f.inter, (int)M); run_gemm(c, a, EPI_SILU_MUL); }
+        { GemmArgs a = gargs(c->pgu, f.inter, L.wdown, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H; run_gemm(c, a, EPI_RESID); }
+    }
+    launch_gather_last(dt, c->px, c->datt, B, T, H, s);      // datt doubles as the [B][H] last-position buffer
+    lm_head_and_greedy(c, c->datt, B, logits, nullptr, 0, /*advance=*/0);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, long step_stride) {
+    const rdx_config& f = c->cfg;
+    const int dt = f.dtype, H = f.hidden, B = c->cur_B;
+    hipStream_t s = c->stream;
+    for (int l = 0; l < f.layers; ++l) {
+        const LlamaLayer& L = c->ll[l];
+        { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps;
+          launch_skinny_gemm(dt, a, EPI_NONE, s); }
+        launch_decode_attention(dt, c->ld, c->dqkv, L.lora_bq, L.lora_bv, c->rope_cos, c->rope_sin, c->d_pos, c->d_slot, c->key_mask,
+                                kv_ptr(c, c->kcache, l), kv_ptr(c, c->vcache, l), c->datt, B, s);
+        { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; launch_skinny_gemm(dt, a, EPI_RESID, s); }
+        { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps;
+          launch_skinny_gemm(dt, a, EPI_SILU_MUL, s); }
+        { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; launch_skinny_gemm(dt, a, EPI_RESID, s); }
+    }
+    lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
+}
+
+extern "C" int rdx_decode_step(rdx_ctx* c, void* logits) {
+    if (!c) return -1;
+    if (!c->finalized || c->cur_B <= 0) return fail(c, -1, "rdx_decode_step: no prefill has run");
+    HIPCHK(c, hipSetDevice(c->device));
+    decode_step_launch(c, logits, nullptr, 0);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
+static int build_graph(rdx_ctx* c, void* scores) {
+    const rdx_config& f = c->cfg;
+    GraphKey k;
+    k.B = c->cur_B; k.max_new = c->cur_max_new; k.eos = c->cur_eos; k.pad = c->cur_pad; k.tokens = c->cur_tokens; k.scores = scores;
+    if (c->graph && k == c->gkey) return 0;
+    if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+    hipGraph_t g = nullptr;
+    HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+    decode_step_launch(c, scores, scores ? c->d_step : nullptr, (long)c->cur_B * f.vocab);
+    HIPCHK(c, hipStreamEndCapture(c->stream, &g));
+    HIPCHK(c, hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
+    HIPCHK(c, hipGraphDestroy(g));
+    c->gkey = k;
+    return 0;
+}
+
+extern "C" int rdx_generate(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int T, const float* qformer_embs,
+                            int max_new, int eos_id, int pad_id, int32_t* out_tokens, void* scores, int* n_steps_host,
+                            int use_graph) {
+    if (!c) return -1;
+    if (max_new <= 0) return fail(c, -1, "rdx_generate: max_new must be positive");
+    int rc = rdx_prefill(c, ids, mask, B, T, qformer_embs, max_new, eos_id, pad_id, out_tokens, scores);
+    if (rc) return rc;
+    const rdx_config& f = c->cfg;
+    int done = 1;
+    std::vector<int> unf(B, 1);
+    auto all_finished = [&]() -> int {
+        if (eos_id < 0) return 0;
+        if (hipMemcpyAsync(unf.data(), c->d_unf, B * sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 0;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+        for (int b = 0; b < B; ++b) if (unf[b]) return 0;
+        return 1;
+    };
+    if (max_new > 1 && !all_finished()) {
+        if (use_graph) {
+            rc = build_graph(c, scores);
+            if (rc) return rc;
+        }
+        const int check_every = 16;
+        while (done < max_new) {
+            if (use_graph) {
+                HIPCHK(c, hipGraphLaunch(c->graph, c->stream));
+            } else {
+                void* lg = scores ? (char*)scores + (size_t)done * B * f.vocab * 2 : nullptr;
+                decode_step_launch(c, lg, nullptr, 0);
+            }
+            ++done;
+            if (eos_id >= 0 && (done % check_every == 0) && done < max_new && all_finished()) break;
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    if (n_steps_host) *n_steps_host = done;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// introspection
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int rdx_kv_read(rdx_ctx* c, int layer, int which, void* dst) {
+    if (!c || !c->finalized || !c->cfg.enable_llama) return fail(c, -1, "rdx_kv_read: no llama state");
+    if (layer < 0 || layer >= c->cfg.layers || !dst) return fail(c, -1, "rdx_kv_read: bad arguments");
+    HIPCHK(c, hipMemcpyAsync(dst, kv_ptr(c, which ? c->vcache : c->kcache, layer), c->kv_layer_elems * 2, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int rdx_hidden_read(rdx_ctx* c, void* dst) {
+    if (!c || !c->finalized || !c->cfg.enable_llama || c->cur_B <= 0) return fail(c, -1, "rdx_hidden_read: no llama state");
+    HIPCHK(c, hipMemcpyAsync(dst, c->datt, (size_t)c->cur_B * c->cfg.hidden * 2, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
+    if (!c || !c->finalized || !c->cfg.enable_llama || c->cur_B <= 0) return fail(c, -1, "rdx_time: run a prefill first");
+    if (!ms_host || iters <= 0) return fail(c, -1, "rdx_time: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const rdx_config& f = c->cfg;
+    const int dt = f.dtype, H = f.hidden, B = c->cur_B;
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    int launches = 0;
+    if (what == 0) {
+        int rc = build_graph(c, nullptr);
+        if (rc) return rc;
+        // state advances with every replay: keep the KV slot inside the cache
+        std::vector<int> slot(B);
+        HIPCHK(c, hipMemcpyAsync(slot.data(), c->d_slot, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (slot[0] + iters >= f.max_len) return fail(c, -1, "rdx_time: %d replays would overflow the KV cache (slot %d, max_len %d)", iters, slot[0], f.max_len);
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        for (int i = 0; i < iters; ++i) HIPCHK(c, hipGraphLaunch(c->graph, c->stream));
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        launches = iters;
+    } else {
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        for (int i = 0; i < iters; ++i) {
+            if (what == 5) {
+                GemmArgs a = gargs(c->dx, H, c->lm_head, nullptr, nullptr, f.vocab, B);
+                a.N = c->lm_head.Npad; a.n_valid = f.vocab; a.norm_w = c->final_norm; a.eps = f.rms_eps;
+                a.part_val = c->part_val; a.part_idx = c->part_idx;
+                launch_skinny_gemm(dt, a, EPI_LOGITS, c->stream);
+                ++launches;
+                continue;
+            }
+            for (int l = 0; l < f.layers; ++l) {
+                const LlamaLayer& L = c->ll[l];
+                if (what == 1) { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; launch_skinny_gemm(dt, a, EPI_SILU_MUL, c->stream); }
+                else if (what == 2) { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps; launch_skinny_gemm(dt, a, EPI_NONE, c->stream); }
+                else if (what == 3) { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dqkv, H, B); launch_skinny_gemm(dt, a, EPI_NONE, c->stream); }
+                else if (what == 4) { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); launch_skinny_gemm(dt, a, EPI_NONE, c->stream); }
+                else return fail(c, -1, "rdx_time: unknown unit %d", what);
+                ++launches;
+            }
+        }
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+    }
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms_host = ms / (float)launches;
+    return 0;
+}

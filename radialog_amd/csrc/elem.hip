@@ -1,0 +1,316 @@
+// Normalisation, layout and bookkeeping kernels (HBM-bound, vectorised where the layout allows).
+#include "rdx_common.h"
+#include "rdx_kernels.h"
+
+namespace rdx {
+
+// ---- LlamaRMSNorm (modeling_llama_imgemb.py:85-93): fp32 statistics, (x*rstd).to(T), then weight*h in T ---------------
+template <typename T>
+__global__ __launch_bounds__(256) void rmsnorm_k(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ out,
+                                                 int H, float eps) {
+    typedef typename Vec8<T>::type V8;
+    __shared__ float red[32];
+    const size_t row = blockIdx.x;
+    const T* xr = x + row * H;
+    float ss = 0.f;
+    for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {
+        V8 v = as_vec8<T>(ldg16(xr + i));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = tof<T>(v[j]); ss += f * f; }
+    }
+    ss = block_sum(ss, red);
+    const float rs = rsqrtf(ss / (float)H + eps);
+    for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {
+        V8 v = as_vec8<T>(ldg16(xr + i));
+        V8 wv = as_vec8<T>(ldg16(w + i));
+        V8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof<T>(wv[j]) * rnd<T>(tof<T>(v[j]) * rs));
+        stg16(out + row * H + i, as_u4<T>(o));
+    }
+}
+
+void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T>), dim3(rows), dim3(256), 0, s, (const T*)x, (const T*)w,
+                                                (T*)out, H, eps));
+}
+
+// ---- LayerNorm over the last dim (Q-Former post-LN, eps 1e-12; fp32 statistics, two-pass variance) -------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_k(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, T* __restrict__ out,
+                                                   float* __restrict__ out_f32, int H, float eps) {
+    __shared__ float red[32];
+    const size_t row = blockIdx.x;
+    const T* xr = x + row * H;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) s += tof<T>(xr[i]);
+    const float mean = block_sum(s, red) / (float)H;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) { const float d = tof<T>(xr[i]) - mean; v += d * d; }
+    const float rstd = rsqrtf(block_sum(v, red) / (float)H + eps);
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        const float y = (tof<T>(xr[i]) - mean) * rstd * gamma[i] + beta[i];
+        if (out) out[row * H + i] = fromf<T>(y);
+        if (out_f32) out_f32[row * H + i] = y;
+    }
+}
+
+void launch_layernorm(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* out_f32, int rows,
+                      int H, float eps, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((layernorm_k<T>), dim3(rows), dim3(256), 0, s, (const T*)x, gamma, beta,
+                                                (T*)out, out_f32, H, eps));
+}
+
+// ---- the NCHW reshape scramble + ln_vision (blip2_qformer.py:469, blip2.py:199-205) ----------------------------------
+// The projector output is produced NHWC ([B][P][C]); the reference reshapes its NCHW tensor [B][C][P] to [B][P][C] without a
+// permute, so token row r, column c is flat element f = r*C + c of the [C][P] matrix: channel f / P, position f % P.
+template <typename T>
+__global__ __launch_bounds__(256) void scramble_layernorm_k(const T* __restrict__ pp, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ out,
+                                                            float* __restrict__ out_f32, int P, int C, float eps) {
+    __shared__ float red[32];
+    extern __shared__ float rowbuf[];
+    const int rrow = blockIdx.x, b = blockIdx.y;
+    const T* src = pp + (size_t)b * P * C;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const size_t f = (size_t)rrow * C + c;
+        const int ch = (int)(f / P), pos = (int)(f % P);
+        const float v = tof<T>(src[(size_t)pos * C + ch]);
+        rowbuf[c] = v;
+        s += v;
+    }
+    const float mean = block_sum(s, red) / (float)C;
+    float v2 = 0.f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) { const float d = rowbuf[c] - mean; v2 += d * d; }
+    const float rstd = rsqrtf(block_sum(v2, red) / (float)C + eps);
+    const size_t o = ((size_t)b * P + rrow) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float y = (rowbuf[c] - mean) * rstd * gamma[c] + beta[c];
+        if (out) out[o + c] = fromf<T>(y);
+        if (out_f32) out_f32[o + c] = y;
+    }
+}
+
+void launch_scramble_layernorm(int dtype, const void* pp_nhwc, const float* gamma, const float* beta, void* out,
+                               float* out_f32, int B, int P, int C, float eps, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((scramble_layernorm_k<T>), dim3(P, B), dim3(256), (size_t)C * sizeof(float), s,
+                                                (const T*)pp_nhwc, gamma, beta, (T*)out, out_f32, P, C, eps));
+}
+
+// ---- image prep: float32 NCHW [B,3,S,S] -> T NHWC, zero-padded spatially, 4 channels (4th = 0) -------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void img_prep_k(const float* __restrict__ img, T* __restrict__ out, int S, int pad, int Hp,
+                                                  int Wp) {
+    const int b = blockIdx.z, y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= Wp) return;
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    T4 o;
+    o[0] = o[1] = o[2] = o[3] = fromf<T>(0.f);
+    const int iy = y - pad, ix = x - pad;
+    if (iy >= 0 && iy < S && ix >= 0 && ix < S) {
+        const size_t plane = (size_t)S * S;
+        const float* p = img + (size_t)b * 3 * plane + (size_t)iy * S + ix;
+        o[0] = fromf<T>(p[0]); o[1] = fromf<T>(p[plane]); o[2] = fromf<T>(p[2 * plane]);
+    }
+    *reinterpret_cast<T4*>(out + (((size_t)b * Hp + y) * Wp + x) * 4) = o;
+}
+
+void launch_img_prep(int dtype, const float* img, void* out, int B, int S, int pad, int Hp, int Wp, hipStream_t s) {
+    dim3 grid((Wp + 255) / 256, Hp, B), block(256);
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((img_prep_k<T>), grid, block, 0, s, img, (T*)out, S, pad, Hp, Wp));
+}
+
+// ---- 3x3 stride-2 pad-1 max pool, NHWC, 8 channels per thread -------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_k(const T* __restrict__ in, T* __restrict__ out, int H, int W, int C, int Ho,
+                                                 int Wo, size_t total) {
+    typedef typename Vec8<T>::type V8;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int C8 = C >> 3;
+    const int c8 = (int)(idx % C8);
+    size_t rest = idx / C8;
+    const int ow = (int)(rest % Wo); rest /= Wo;
+    const int oh = (int)(rest % Ho);
+    const int b = (int)(rest / Ho);
+    float m[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * 2 - 1 + kh;
+        if (ih < 0 || ih >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = ow * 2 - 1 + kw;
+            if (iw < 0 || iw >= W) continue;
+            V8 v = as_vec8<T>(ldg16(in + (((size_t)b * H + ih) * W + iw) * C + c8 * 8));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], tof<T>(v[j]));
+        }
+    }
+    V8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = fromf<T>(m[j]);
+    stg16(out + (((size_t)b * Ho + oh) * Wo + ow) * C + c8 * 8, as_u4<T>(o));
+}
+
+void launch_maxpool(int dtype, const void* in, void* out, int B, int H, int W, int C, hipStream_t s) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)B * Ho * Wo * (C >> 3);
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((maxpool_k<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                                                (const T*)in, (T*)out, H, W, C, Ho, Wo, total));
+}
+
+// ---- small copies / conversions --------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void broadcast_rows_k(const T* __restrict__ src, T* __restrict__ dst, size_t per, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) dst[i] = src[i % per];
+}
+void launch_broadcast_rows(int dtype, const void* src, void* dst, int rows, int H, int B, hipStream_t s) {
+    const size_t per = (size_t)rows * H, total = per * B;
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((broadcast_rows_k<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s,
+                                                (const T*)src, (T*)dst, per, total));
+}
+
+template <typename T> __global__ void to_f32_k(const T* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = tof<T>(src[i]);
+}
+template <typename T> __global__ void from_f32_k(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = fromf<T>(src[i]);
+}
+void launch_to_f32(int dtype, const void* src, float* dst, size_t n, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((to_f32_k<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)src, dst, n));
+}
+void launch_from_f32(int dtype, const float* src, void* dst, size_t n, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((from_f32_k<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, (T*)dst, n));
+}
+
+// ---- prompt preparation: split_at_img position, attention mask, position ids (:498-520, :805-810) ---------------------
+__global__ void prep_prompt_k(const int* __restrict__ ids, const int* __restrict__ mask_in, int T_, int img_id, int pad_id,
+                              int* __restrict__ img_pos, int* __restrict__ pos_ids, uint8_t* __restrict__ key_mask, long km_bs,
+                              int max_len_fill, int* __restrict__ pos_next, int* __restrict__ slot_b, int* __restrict__ step_b,
+                              int* __restrict__ unfinished) {
+    const int b = blockIdx.x;
+    const int* row = ids + (size_t)b * T_;
+    uint8_t* km = key_mask + (size_t)b * km_bs;
+    if (threadIdx.x == 0) {
+        int first = -1, cum = 0;
+        for (int t = 0; t < T_; ++t) {
+            if (first < 0 && row[t] == img_id) first = t;
+            const int m = mask_in ? (mask_in[(size_t)b * T_ + t] != 0) : (row[t] != pad_id);
+            cum += m;
+            pos_ids[(size_t)b * T_ + t] = m ? (cum - 1) : 1;
+            km[t] = (uint8_t)m;
+        }
+        img_pos[b] = first < 0 ? 0 : first;
+        pos_next[b] = cum;        // position id of the first generated token = cumsum(mask) - 1 after appending a 1
+        slot_b[b] = T_;
+        step_b[b] = 0;
+        unfinished[b] = 1;
+    }
+    for (int t = T_ + threadIdx.x; t < max_len_fill; t += blockDim.x) km[t] = 1;   // generated tokens are always attended
+}
+void launch_prep_prompt(const int* ids, const int* mask_in, int B, int T_, int img_id, int pad_id, int* img_pos, int* pos_ids,
+                        uint8_t* key_mask, long km_bs, int* pos_next, int* slot_b, int* step_b, int* unfinished, hipStream_t s) {
+    hipLaunchKernelGGL(prep_prompt_k, dim3(B), dim3(256), 0, s, ids, mask_in, T_, img_id, pad_id, img_pos, pos_ids, key_mask,
+                       km_bs, (int)km_bs, pos_next, slot_b, step_b, unfinished);
+}
+
+// ---- embedding gather + image splice (:571-594): rows [p, p+32) take the projected image embedding ----------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_splice_k(const int* __restrict__ ids, const int* __restrict__ img_pos,
+                                                      const T* __restrict__ embed, int vocab, const T* __restrict__ img_emb,
+                                                      int n_img, T* __restrict__ out, int T_, int H, int use_img) {
+    const int t = blockIdx.x, b = blockIdx.y;
+    const T* src;
+    const int p = img_pos[b];
+    if (use_img && t >= p && t < p + n_img) {
+        src = img_emb + ((size_t)b * n_img + (t - p)) * H;
+    } else {
+        int id = ids[(size_t)b * T_ + t];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        src = embed + (size_t)id * H;
+    }
+    T* dst = out + ((size_t)b * T_ + t) * H;
+    for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) stg16(dst + i, ldg16(src + i));
+}
+void launch_embed_splice(int dtype, const int* ids, const int* img_pos, const void* embed, int vocab, const void* img_emb,
+                         int n_img, void* out, int B, int T_, int H, int use_img, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((embed_splice_k<T>), dim3(T_, B), dim3(256), 0, s, ids, img_pos, (const T*)embed,
+                                                vocab, (const T*)img_emb, n_img, (T*)out, T_, H, use_img));
+}
+
+template <typename T>
+__global__ void gather_last_k(const T* __restrict__ x, T* __restrict__ out, int T_, int H) {
+    const int b = blockIdx.x;
+    const T* src = x + ((size_t)b * T_ + (T_ - 1)) * H;
+    for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) stg16(out + (size_t)b * H + i, ldg16(src + i));
+}
+void launch_gather_last(int dtype, const void* x, void* out, int B, int T_, int H, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((gather_last_k<T>), dim3(B), dim3(256), 0, s, (const T*)x, (T*)out, T_, H));
+}
+
+// ---- greedy step (transformers 4.28.1 greedy_search rule) ----------------------------------------------------------------
+// next = argmax(logits) (lowest index wins ties); finished rows emit pad; a row finishes when it emits eos.
+// Also advances the per-row decode state and gathers the next input embedding, so the whole step stays on the device.
+template <typename T>
+__global__ __launch_bounds__(256) void greedy_step_k(const float* __restrict__ part_val, const int* __restrict__ part_idx,
+                                                     int n_tiles, int eos_id, int pad_id, int max_new, int* __restrict__ out_tokens,
+                                                     int* __restrict__ unfinished, int* __restrict__ pos, int* __restrict__ slot_b,
+                                                     int* __restrict__ step_b, const T* __restrict__ embed, int vocab,
+                                                     T* __restrict__ x_next, int H) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    __shared__ int tok_s;
+    const int b = blockIdx.x;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
+        const float v = part_val[(size_t)b * n_tiles + i];
+        const int ix = part_idx[(size_t)b * n_tiles + i];
+        if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+    }
+    sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float v = sv[threadIdx.x + o];
+            const int ix = si[threadIdx.x + o];
+            if (v > sv[threadIdx.x] || (v == sv[threadIdx.x] && ix < si[threadIdx.x])) { sv[threadIdx.x] = v; si[threadIdx.x] = ix; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int tok = si[0];
+        const int step = step_b[b];
+        if (eos_id >= 0) {
+            const int unf = unfinished[b];
+            tok = unf ? tok : pad_id;
+            if (tok == eos_id) unfinished[b] = 0;
+        }
+        if (step < max_new) out_tokens[(size_t)b * max_new + step] = tok;
+        step_b[b] = step + 1;
+        if (slot_b) slot_b[b] += 1;      // null on the prefill call: token 0 is consumed by the first decode step
+        if (pos) pos[b] += 1;
+        tok_s = tok;
+    }
+    __syncthreads();
+    int id = tok_s;
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    const T* src = embed + (size_t)id * H;
+    for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) stg16(x_next + (size_t)b * H + i, ldg16(src + i));
+}
+void launch_greedy_step(int dtype, const float* part_val, const int* part_idx, int n_tiles, int B, int eos_id, int pad_id,
+                        int max_new, int* out_tokens, int* unfinished, int* pos, int* slot_b, int* step_b, const void* embed,
+                        int vocab, void* x_next, int H, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((greedy_step_k<T>), dim3(B), dim3(256), 0, s, part_val, part_idx, n_tiles, eos_id,
+                                                pad_id, max_new, out_tokens, unfinished, pos, slot_b, step_b, (const T*)embed, vocab,
+                                                (T*)x_next, H));
+}
+
+}  // namespace rdx

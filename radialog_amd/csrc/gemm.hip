@@ -1,0 +1,450 @@
+// MFMA GEMM kernels over fragment-packed weights (gfx950, mfma_f32_16x16x32_{f16,bf16}).
+//
+// Every dense contraction on the RaDialog hot path is  out[M,N] = X[M,K] . W[N,K]^T (+ epilogue)  with W a fixed
+// model weight, so weights are re-laid-out ONCE at load time into the MFMA operand order
+//     Wp[n_tile16][k_chunk32][lane 0..63][8 elems],  lane = (g<<4)|r  holds  W[n_tile*16+r][k_chunk*32+g*8 .. +8]
+// -> one wave-wide 16-byte load is a fully coalesced 1 KiB read that lands directly in the MFMA A operand.
+// Activations are the MFMA B operand, so D[i][j] = out[m = j][n = i]: lane (r = m_local, g) ends up with 4 CONSECUTIVE
+// output columns n = g*4 .. g*4+3 of row m -> 8-byte stores, no LDS transpose.
+//
+//   skinny_gemm : M <= 32 (single-token decode at batch 1..32, Q-Former at batch 1). HBM-bound weight streaming:
+//                 one workgroup per 16 output columns, its 8 waves split K, partial tiles reduced through LDS,
+//                 fused RMSNorm prologue and fused bias / residual / SwiGLU / logits+argmax epilogues.
+//                 Replaces the reference's nn.Linear GEMVs in LlamaAttention / LlamaMLP / lm_head
+//                 (modeling_llama_imgemb.py:158-159,:198-200,:245,:768) and LlamaRMSNorm (:85-93).
+//   tiled_gemm  : M > 32 (prefill, ResNet convs as implicit GEMM, Q-Former at batch > 1). 128x128 block tile,
+//                 2x2 waves x (4x4) MFMA tiles, activations staged through LDS in fragment order (conflict-free
+//                 ds_read_b128), weights straight from global in packed order. Conv mode gathers the im2col row
+//                 on the fly from an NHWC tensor (torchvision Bottleneck convs behind biovil_t/resnet.py:34-42).
+#include "rdx_common.h"
+#include "rdx_kernels.h"
+
+namespace rdx {
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weight_k(const float* __restrict__ src, T* __restrict__ dst, int N, int K, int Npad,
+                              const int* __restrict__ rowmap) {
+    const int K8 = K >> 3;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)Npad * K8) return;
+    const int i = (int)(idx / K8), k8 = (int)(idx % K8);
+    int srow = rowmap ? rowmap[i] : i;
+    if (srow >= N) srow = -1;
+    typename Vec8<T>::type v;
+    if (srow >= 0) {
+        const float4* s = reinterpret_cast<const float4*>(src + (size_t)srow * K + (size_t)k8 * 8);
+        float4 a = s[0], b = s[1];
+        v[0] = fromf<T>(a.x); v[1] = fromf<T>(a.y); v[2] = fromf<T>(a.z); v[3] = fromf<T>(a.w);
+        v[4] = fromf<T>(b.x); v[5] = fromf<T>(b.y); v[6] = fromf<T>(b.z); v[7] = fromf<T>(b.w);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fromf<T>(0.f);
+    }
+    const int KC = K >> 5;
+    const int nt = i >> 4, r = i & 15, kc = k8 >> 2, g = k8 & 3;
+    u4* d = reinterpret_cast<u4*>(dst) + ((size_t)nt * KC + kc) * 64 + (g * 16 + r);
+    *d = as_u4<T>(v);
+}
+
+void launch_pack_weight(int dtype, const float* src, void* dst, int N, int K, int Npad, const int* rowmap,
+                        hipStream_t s) {
+    const size_t total = (size_t)Npad * (K >> 3);
+    const int blocks = (int)((total + 255) / 256);
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((pack_weight_k<T>), dim3(blocks), dim3(256), 0, s, src, (T*)dst, N, K,
+                                                Npad, rowmap));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// shared epilogue math (rounding points follow the reference's fp16/bf16 op sequence, see oracle/ref_cpu.py)
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float swiglu(float gate_acc, float up_acc) {
+    const float gt = rnd<T>(gate_acc), up = rnd<T>(up_acc);   // gate_proj(x), up_proj(x) as model-dtype tensors
+    const float s = rnd<T>(silu(gt));                          // act_fn output rounded
+    return s * up;                                             // product rounded by the caller's store
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// skinny GEMM
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int SK_WAVES = 8;
+constexpr int SK_UNROLL = 8;
+
+template <typename T, int MT, int EPI, bool NORM>
+__global__ __launch_bounds__(SK_WAVES * 64) void skinny_gemm_k(GemmArgs a) {
+    typedef typename Vec8<T>::type V8;
+    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][MT][256];   // [wave][mt][m_local*16 + n_local]
+    __shared__ float ssq[SK_WAVES][MT * 16];
+    __shared__ float rstd_s[MT * 16];
+
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int KC = a.K >> 5;
+    const int c0 = (KC * w) / SK_WAVES, c1 = (KC * (w + 1)) / SK_WAVES;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* NW = reinterpret_cast<const T*>(a.norm_w);
+
+    const T* xrow[MT];
+    bool xok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + r;
+        xok[mt] = m < a.M;
+        xrow[mt] = X + (size_t)(xok[mt] ? m : 0) * a.ldx + g * 8;
+    }
+    const u4* wp = reinterpret_cast<const u4*>(a.W) + ((size_t)blockIdx.x * KC + c0) * 64 + lane;
+
+    float rs[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) rs[mt] = 1.f;
+    if (NORM) {
+        // LlamaRMSNorm statistics: mean of squares in fp32 over the whole row; each wave sums its own K slice.
+        float ss[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ss[mt] = 0.f;
+        for (int c = c0; c < c1; ++c) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if (xok[mt]) {
+                    V8 xv = as_vec8<T>(ldg16(xrow[mt] + (size_t)c * 32));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float f = tof<T>(xv[j]); ss[mt] += f * f; }
+                }
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            ss[mt] += __shfl_xor(ss[mt], 16, 64);
+            ss[mt] += __shfl_xor(ss[mt], 32, 64);
+            if (g == 0) ssq[w][mt * 16 + r] = ss[mt];
+        }
+        __syncthreads();
+        if (threadIdx.x < MT * 16) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < SK_WAVES; ++i) t += ssq[i][threadIdx.x];
+            rstd_s[threadIdx.x] = rsqrtf(t / (float)a.K + a.eps);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) rs[mt] = rstd_s[mt * 16 + r];
+    }
+
+    v4f acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    for (int cb = c0; cb < c1; cb += SK_UNROLL) {
+        u4 wv[SK_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SK_UNROLL; ++u)
+            if (cb + u < c1) wv[u] = ldg16_nt(wp + (size_t)u * 64);
+        wp += (size_t)SK_UNROLL * 64;
+#pragma unroll
+        for (int u = 0; u < SK_UNROLL; ++u) {
+            const int c = cb + u;
+            if (c < c1) {
+                u4 nwv = (u4){0u, 0u, 0u, 0u};
+                if (NORM) nwv = ldg16(NW + (size_t)c * 32 + g * 8);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    V8 xv;
+                    if (xok[mt]) {
+                        xv = as_vec8<T>(ldg16(xrow[mt] + (size_t)c * 32));
+                        if (NORM) {
+                            V8 nw = as_vec8<T>(nwv);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float h = rnd<T>(tof<T>(xv[j]) * rs[mt]);    // (x * rsqrt(var+eps)).to(dtype)
+                                xv[j] = fromf<T>(tof<T>(nw[j]) * h);               // weight * hidden  (dtype mult)
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) xv[j] = fromf<T>(0.f);
+                    }
+                    acc[mt] = mfma16(as_vec8<T>(wv[u]), xv, acc[mt]);
+                }
+            }
+        }
+    }
+    // D[i = n_local = g*4+reg][j = m_local = r]  ->  red[w][mt][m_local*16 + n_local]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<float4*>(&red[w][mt][r * 16 + g * 4]) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+    __syncthreads();
+
+    const int t = threadIdx.x;
+    if (t >= MT * 256) return;
+    const int mt = t >> 8, idx = t & 255, m_local = idx >> 4, n_local = idx & 15;
+    const int m = mt * 16 + m_local;
+    const int n = blockIdx.x * 16 + n_local;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < SK_WAVES; ++i) v += red[i][mt][idx];
+    if (a.bias && n < a.N) v += a.bias[n];
+    T* out = reinterpret_cast<T*>(a.out);
+    if (a.out_step && out) out += (size_t)(*a.out_step) * a.out_step_stride;
+    const bool ok = (m < a.M) && (n < a.N);
+
+    if (EPI == EPI_NONE) {
+        if (ok) out[(size_t)m * a.ldo + n] = fromf<T>(v);
+    } else if (EPI == EPI_RELU) {
+        if (ok) out[(size_t)m * a.ldo + n] = fromf<T>(fmaxf(v, 0.f));
+    } else if (EPI == EPI_GELU) {
+        if (ok) out[(size_t)m * a.ldo + n] = fromf<T>(gelu_erf(v));
+    } else if (EPI == EPI_RESID) {
+        if (ok) {
+            const float rsd = tof<T>(reinterpret_cast<const T*>(a.resid)[(size_t)m * a.ldr + n]);
+            out[(size_t)m * a.ldo + n] = fromf<T>(rsd + rnd<T>(v));
+        }
+    } else if (EPI == EPI_SILU_MUL) {
+        // rows of a tile: 0..7 = gate_proj rows 8t..8t+7, 8..15 = up_proj rows 8t..8t+7
+        float u = 0.f;
+#pragma unroll
+        for (int i = 0; i < SK_WAVES; ++i) u += red[i][mt][(idx + 8) & 255];
+        if (n_local < 8 && ok) out[(size_t)m * a.ldo + blockIdx.x * 8 + n_local] = fromf<T>(swiglu<T>(v, u));
+    } else if (EPI == EPI_LOGITS) {
+        float lv = rnd<T>(v);
+        int li = n;
+        const bool valid = n < a.n_valid;
+        if (valid && m < a.M && out) out[(size_t)m * a.ldo + n] = fromf<T>(lv);
+        if (!valid) { lv = -INFINITY; li = 0x7fffffff; }
+        // argmax over the tile's 16 columns (16 consecutive lanes share m); ties -> lowest index (torch.argmax)
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(lv, o, 64);
+            const int oi = __shfl_xor(li, o, 64);
+            if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
+        }
+        if (n_local == 0 && m < a.M) {
+            a.part_val[(size_t)m * gridDim.x + blockIdx.x] = lv;
+            a.part_idx[(size_t)m * gridDim.x + blockIdx.x] = li;
+        }
+    }
+}
+
+template <typename T, int MT, bool NORM>
+static void launch_skinny_epi(const GemmArgs& a, int epi, hipStream_t s) {
+    const int nt = (a.N + 15) / 16;
+    dim3 grid(nt), block(SK_WAVES * 64);
+#define RDX_SK(E) hipLaunchKernelGGL((skinny_gemm_k<T, MT, E, NORM>), grid, block, 0, s, a)
+    switch (epi) {
+        case EPI_NONE: RDX_SK(EPI_NONE); break;
+        case EPI_RELU: RDX_SK(EPI_RELU); break;
+        case EPI_GELU: RDX_SK(EPI_GELU); break;
+        case EPI_RESID: RDX_SK(EPI_RESID); break;
+        case EPI_SILU_MUL: RDX_SK(EPI_SILU_MUL); break;
+        case EPI_LOGITS: RDX_SK(EPI_LOGITS); break;
+        default: break;
+    }
+#undef RDX_SK
+}
+
+void launch_skinny_gemm(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
+    const bool norm = a.norm_w != nullptr;
+    RDX_DISPATCH_T(dtype, T, {
+        if (a.M <= 16) {
+            if (norm) launch_skinny_epi<T, 1, true>(a, epi, s); else launch_skinny_epi<T, 1, false>(a, epi, s);
+        } else {
+            if (norm) launch_skinny_epi<T, 2, true>(a, epi, s); else launch_skinny_epi<T, 2, false>(a, epi, s);
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// tiled GEMM (plain or implicit-GEMM conv gather)
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int TG_BM = 128, TG_BN = 128;
+
+template <typename T>
+__device__ __forceinline__ u4 gather_a(const T* X, const GemmArgs& a, const ConvGeom& cg, bool rowok, size_t rowbase,
+                                       int ih0, int iw0, int k) {
+    if (!rowok) return (u4){0u, 0u, 0u, 0u};
+    if (cg.mode == 0) return ldg16(X + rowbase + k);
+    const int kpos = k / cg.Cin, c0 = k - kpos * cg.Cin;
+    const int kh = kpos / cg.KW, kw = kpos - kh * cg.KW;
+    const int ih = ih0 + kh, iw = iw0 + kw;
+    if (ih < 0 || ih >= cg.Hin || iw < 0 || iw >= cg.Win) return (u4){0u, 0u, 0u, 0u};
+    return ldg16(X + rowbase + ((size_t)ih * cg.Win + iw) * cg.Cin + c0);
+}
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void tiled_gemm_k(GemmArgs a, ConvGeom cg) {
+    typedef typename Vec8<T>::type V8;
+    __shared__ __attribute__((aligned(16))) u4 Xs[2][8][64];      // [buf][m_tile][lane] fragment order, 16 KiB
+
+    // XCD-aware tile order: ids that land on one XCD (id % 8) walk consecutive m-blocks of one n-block, so the
+    // weight panel is re-read from that XCD's own L2.
+    const int MB = (a.M + TG_BM - 1) / TG_BM, NB = (a.N + TG_BN - 1) / TG_BN;
+    const int nwg = MB * NB;
+    int tile;
+    {
+        const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, rr = nwg & 7;
+        tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+    }
+    const int bn = tile / MB, bm = tile - bn * MB;
+    const int M0 = bm * TG_BM, N0 = bn * TG_BN;
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int KC = a.K >> 5;
+    const int NT16 = (a.N + 15) >> 4;
+    const T* X = reinterpret_cast<const T*>(a.X);
+
+    // staging rows of this thread: pass p -> m_tile = p*4 + w, row = M0 + m_tile*16 + r, k segment g
+    bool s_ok[2];
+    size_t s_base[2];
+    int s_ih0[2], s_iw0[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int row = M0 + (p * 4 + w) * 16 + r;
+        s_ok[p] = row < a.M;
+        s_base[p] = 0; s_ih0[p] = 0; s_iw0[p] = 0;
+        if (s_ok[p]) {
+            if (cg.mode == 0) {
+                s_base[p] = (size_t)row * a.ldx;
+            } else {
+                const int hw = cg.Hout * cg.Wout;
+                const int b = row / hw, rem = row - b * hw;
+                const int oh = rem / cg.Wout, ow = rem - oh * cg.Wout;
+                s_base[p] = (size_t)b * cg.Hin * cg.Win * cg.Cin;
+                s_ih0[p] = oh * cg.stride - cg.pad;
+                s_iw0[p] = ow * cg.stride - cg.pad;
+            }
+        }
+    }
+    // weight fragment pointers (4 n-tiles of this wave)
+    const u4* wptr[4];
+    bool w_ok[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int tile16 = (N0 >> 4) + wn * 4 + nt;
+        w_ok[nt] = tile16 < NT16;
+        wptr[nt] = reinterpret_cast<const u4*>(a.W) + ((size_t)(w_ok[nt] ? tile16 : 0) * KC) * 64 + lane;
+    }
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    u4 xa[2], wf[4], wf_n[4];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) xa[p] = gather_a<T>(X, a, cg, s_ok[p], s_base[p], s_ih0[p], s_iw0[p], g * 8);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) wf[nt] = w_ok[nt] ? ldg16(wptr[nt]) : (u4){0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int p = 0; p < 2; ++p) Xs[0][p * 4 + w][lane] = xa[p];
+    __syncthreads();
+
+    for (int c = 0; c < KC; ++c) {
+        const int buf = c & 1;
+        const bool more = (c + 1) < KC;
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                xa[p] = gather_a<T>(X, a, cg, s_ok[p], s_base[p], s_ih0[p], s_iw0[p], (c + 1) * 32 + g * 8);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf_n[nt] = w_ok[nt] ? ldg16(wptr[nt] + (size_t)(c + 1) * 64) : (u4){0u, 0u, 0u, 0u};
+        }
+        V8 xf[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) xf[mt] = as_vec8<T>(Xs[buf][wm * 4 + mt][lane]);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(as_vec8<T>(wf[nt]), xf[mt], acc[nt][mt]);
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) Xs[buf ^ 1][p * 4 + w][lane] = xa[p];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf[nt] = wf_n[nt];
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane (r = m_local, g) holds out[m][n0 + g*4 + 0..3]
+    T* out = reinterpret_cast<T*>(a.out);
+    const T* resid = reinterpret_cast<const T*>(a.resid);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = N0 + (wn * 4 + nt) * 16 + g * 4;
+        if (n >= a.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n);
+            bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+        }
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = M0 + (wm * 4 + mt) * 16 + r;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[nt][mt][e] + bv[e];
+            if (EPI == EPI_SILU_MUL) {
+                // gate rows live at n_local 0..7 (g = 0,1), up rows at 8..15 (g = 2,3): partner lane = lane ^ 32
+                float u[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] = __shfl_xor(v[e], 32, 64);
+                if (g < 2 && m < a.M) {
+                    typedef T T4 __attribute__((ext_vector_type(4)));
+                    T4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fromf<T>(swiglu<T>(v[e], u[e]));
+                    const int oc = (N0 >> 1) + (wn * 4 + nt) * 8 + g * 4;
+                    *reinterpret_cast<T4*>(out + (size_t)m * a.ldo + oc) = o;
+                }
+                continue;
+            }
+            if (m >= a.M) continue;
+            if (EPI == EPI_RELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            } else if (EPI == EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            } else if (EPI == EPI_RESID || EPI == EPI_RESID_RELU) {
+                typedef T T4 __attribute__((ext_vector_type(4)));
+                const T4 rv = *reinterpret_cast<const T4*>(resid + (size_t)m * a.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = tof<T>(rv[e]) + rnd<T>(v[e]);
+                    if (EPI == EPI_RESID_RELU) v[e] = fmaxf(v[e], 0.f);
+                }
+            }
+            typedef T T4 __attribute__((ext_vector_type(4)));
+            T4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fromf<T>(v[e]);
+            *reinterpret_cast<T4*>(out + (size_t)m * a.ldo + n) = o;
+        }
+    }
+}
+
+template <typename T>
+static void launch_tiled_T(const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s) {
+    const int MB = (a.M + TG_BM - 1) / TG_BM, NB = (a.N + TG_BN - 1) / TG_BN;
+    dim3 grid(MB * NB), block(256);
+#define RDX_TG(E) hipLaunchKernelGGL((tiled_gemm_k<T, E>), grid, block, 0, s, a, cg)
+    switch (epi) {
+        case EPI_NONE: RDX_TG(EPI_NONE); break;
+        case EPI_RELU: RDX_TG(EPI_RELU); break;
+        case EPI_GELU: RDX_TG(EPI_GELU); break;
+        case EPI_RESID: RDX_TG(EPI_RESID); break;
+        case EPI_RESID_RELU: RDX_TG(EPI_RESID_RELU); break;
+        case EPI_SILU_MUL: RDX_TG(EPI_SILU_MUL); break;
+        default: break;
+    }
+#undef RDX_TG
+}
+
+void launch_tiled_gemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, launch_tiled_T<T>(a, cg, epi, s));
+}
+
+}  // namespace rdx

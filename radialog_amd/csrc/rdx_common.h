@@ -1,0 +1,90 @@
+// Shared device/host helpers for librdx (gfx950 / CDNA4 only: 64-wide wavefronts, MFMA 16x16x32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+namespace rdx {
+
+typedef _Float16 f16;
+typedef __bf16 bf16;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef __bf16 v8b __attribute__((ext_vector_type(8)));
+
+enum DType { DT_F16 = 0, DT_BF16 = 1 };
+
+// ---- scalar conversions (round-to-nearest-even, the rounding torch's .to(half/bfloat16) applies) --------------
+template <typename T> __device__ __forceinline__ float tof(T x) { return (float)x; }
+template <typename T> __device__ __forceinline__ T fromf(float x) { return (T)x; }
+// round a float through T and back: the "every torch op rounds its output to the model dtype" emulation
+template <typename T> __device__ __forceinline__ float rnd(float x) { return (float)((T)x); }
+
+template <typename T> struct Vec8;           // 8 x T in one 16-byte register quad
+template <> struct Vec8<f16> { typedef v8h type; };
+template <> struct Vec8<bf16> { typedef v8b type; };
+
+template <typename T> __device__ __forceinline__ typename Vec8<T>::type as_vec8(u4 v) {
+    return __builtin_bit_cast(typename Vec8<T>::type, v);
+}
+template <typename T> __device__ __forceinline__ u4 as_u4(typename Vec8<T>::type v) { return __builtin_bit_cast(u4, v); }
+
+__device__ __forceinline__ v4f mfma16(v8h a, v8h b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ v4f mfma16(v8b a, v8b b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// 16-byte loads. `ldg_nt` = streamed-once data (decode weights): non-temporal policy.
+__device__ __forceinline__ u4 ldg16(const void* p) { return *reinterpret_cast<const u4*>(p); }
+__device__ __forceinline__ u4 ldg16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u4*>(p)); }
+__device__ __forceinline__ void stg16(void* p, u4 v) { *reinterpret_cast<u4*>(p) = v; }
+
+// ---- wave (64 lanes) reductions ----------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block reductions through a small LDS scratch (>= 32 floats); all threads get the result.
+__device__ __forceinline__ float block_sum(float v, float* scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += scratch[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* scratch) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) scratch[w] = v;
+    __syncthreads();
+    float r = -INFINITY;
+    for (int i = 0; i < nw; ++i) r = fmaxf(r, scratch[i]);
+    return r;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+// packed GEMM weight geometry: [n_tile16][k_chunk32][64 lanes][8 elems]; lane = (g<<4)|r holds
+// W[n_tile*16 + r][k_chunk*32 + g*8 .. +8]  -- the MFMA 16x16x32 operand fragment, 1 KiB per block.
+__host__ __device__ __forceinline__ size_t packed_elems(int n, int k) { return (size_t)((n + 15) / 16) * 16 * (size_t)k; }
+
+}  // namespace rdx
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+#define RDX_DISPATCH_T(dt, T, ...)                         \
+    do {                                                   \
+        if ((dt) == rdx::DT_F16) { typedef rdx::f16 T; __VA_ARGS__; } \
+        else { typedef rdx::bf16 T; __VA_ARGS__; }         \
+    } while (0)

@@ -1,0 +1,93 @@
+// Host-visible launchers of librdx's HIP kernels (internal header; the public C ABI is include/rdx.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rdx {
+
+enum Epilogue {
+    EPI_NONE = 0,        // out = T(acc + bias)
+    EPI_RELU = 1,        // out = T(relu(acc + bias))
+    EPI_GELU = 2,        // out = T(gelu_erf(acc + bias))
+    EPI_RESID = 3,       // out = T(resid + T(acc + bias))
+    EPI_SILU_MUL = 4,    // gate/up interleaved tiles: out[:, N/2] = T(T(silu(T(g))) * T(u))
+    EPI_LOGITS = 5,      // skinny only: out = T(acc) for n < n_valid, plus per-tile argmax partials
+    EPI_RESID_RELU = 6,  // tiled only: out = T(relu(resid + T(acc + bias)))   (Bottleneck tail)
+};
+
+struct GemmArgs {
+    const void* X; int ldx;          // activations [M][K], row stride in elements
+    const void* W;                   // fragment-packed weights (see gemm.hip)
+    const float* bias;               // nullable [N]
+    const void* resid; int ldr;      // nullable [M][N]
+    void* out; int ldo;              // [M][N]  ([M][N/2] for EPI_SILU_MUL)
+    int M, N, K;
+    const void* norm_w; float eps;   // fused RMSNorm prologue (skinny): weight [K] or null
+    float* part_val; int* part_idx;  // EPI_LOGITS: [M][n_tiles]
+    int n_valid;                     // EPI_LOGITS: real vocab size (N is padded to 16)
+    const int* out_step; long out_step_stride;   // optional: out += (*out_step) * stride elements (per-step score rows)
+};
+
+struct ConvGeom {        // mode 0: plain row-major A.  mode 1: im2col gather from NHWC, K ordered (kh, kw, c)
+    int mode;
+    int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
+};
+
+struct AttnArgs {        // generic softmax(QK^T/sqrt(D)) V over strided tensors
+    const void* Q; const void* K; const void* V; void* O;
+    long q_bs, q_ts, q_hs;           // element strides: batch, token, head
+    long k_bs, k_ts, k_hs;
+    long v_bs, v_ts, v_hs;
+    long o_bs, o_ts, o_hs;
+    int B, H, Tq, Tk;
+    int causal;                      // query i attends keys j <= i + (Tk - Tq)
+    const uint8_t* key_mask; long km_bs;   // nullable [B][>=Tk], 1 = attend
+};
+
+// Decode-loop state lives in device memory, per batch row (slot_b[b] = KV slot the next token is written to,
+// step_b[b] = tokens generated so far, pos[b] = position id of the next token), so that one captured step graph can
+// be replayed with identical kernel arguments.
+
+struct LlamaDims {
+    int hidden, heads, head_dim, qkv_ld, lora_r;
+    float lora_scale;
+    int max_len;         // KV slots per (b, head)
+    int max_pos;
+};
+
+void launch_pack_weight(int dtype, const float* src, void* dst, int N, int K, int Npad, const int* rowmap, hipStream_t s);
+void launch_skinny_gemm(int dtype, const GemmArgs& a, int epi, hipStream_t s);
+void launch_tiled_gemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s);
+
+void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s);
+// prefill: LoRA add + RoPE + KV-cache write for T tokens of B rows; q -> qout [B*T][hidden]
+void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,
+                            const void* cos_t, const void* sin_t, const int* pos_ids, void* qout, void* kcache,
+                            void* vcache, int B, int T, hipStream_t s);
+// decode: LoRA + RoPE + KV append + attention over the cache for one new token per row
+void launch_decode_attention(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,
+                             const void* cos_t, const void* sin_t, const int* pos, const int* slot_b,
+                             const uint8_t* key_mask, void* kcache, void* vcache, void* out, int B, hipStream_t s);
+
+void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s);
+void launch_layernorm(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* out_f32,
+                      int rows, int H, float eps, hipStream_t s);
+void launch_scramble_layernorm(int dtype, const void* pp_nhwc, const float* gamma, const float* beta, void* out,
+                               float* out_f32, int B, int P, int C, float eps, hipStream_t s);
+void launch_img_prep(int dtype, const float* img, void* out, int B, int S, int pad, int Hp, int Wp, hipStream_t s);
+void launch_maxpool(int dtype, const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
+void launch_broadcast_rows(int dtype, const void* src, void* dst, int rows, int H, int B, hipStream_t s);
+void launch_to_f32(int dtype, const void* src, float* dst, size_t n, hipStream_t s);
+void launch_from_f32(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
+
+void launch_prep_prompt(const int* ids, const int* mask_in, int B, int T, int img_id, int pad_id, int* img_pos,
+                        int* pos_ids, uint8_t* key_mask, long km_bs, int* pos_next, int* slot_b, int* step_b,
+                        int* unfinished, hipStream_t s);
+void launch_embed_splice(int dtype, const int* ids, const int* img_pos, const void* embed, int vocab, const void* img_emb,
+                         int n_img, void* out, int B, int T, int H, int use_img, hipStream_t s);
+void launch_gather_last(int dtype, const void* x, void* out, int B, int T, int H, hipStream_t s);
+void launch_greedy_step(int dtype, const float* part_val, const int* part_idx, int n_tiles, int B, int eos_id, int pad_id,
+                        int max_new, int* out_tokens, int* unfinished, int* pos, int* slot_b, int* step_b,
+                        const void* embed, int vocab, void* x_next, int H, hipStream_t s);
+
+}  // namespace rdx

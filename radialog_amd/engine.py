@@ -1,0 +1,186 @@
+"""RdxEngine: the thin Python owner of one librdx context (one per process and GPU).
+
+PyTorch-ROCm is used only as the tensor container (device memory, dtype views) and for `torch.distributed`;
+all arithmetic of the hot path runs in librdx's HIP kernels. There is no eager/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import RdxConfig, check
+from .config import RaDialogCfg
+from . import weights as W
+
+_TORCH_DT = {"f16": torch.float16, "bf16": torch.bfloat16}
+_RDX_DT = {"f16": _lib.RDX_DTYPE_F16, "bf16": _lib.RDX_DTYPE_BF16}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class RdxEngine:
+    def __init__(self, cfg: RaDialogCfg, dtype: str = "bf16", device: int = 0, max_batch: int = 1, max_len: int = 512,
+                 lora: bool = True, vision: bool = True, llama: bool = True):
+        if dtype not in _RDX_DT:
+            raise ValueError(f"dtype must be 'f16' or 'bf16', got {dtype!r}")
+        self.lib = _lib.load()                       # raises RdxLibraryError when the HIP library is absent
+        if not torch.cuda.is_available():
+            raise _lib.RdxError("RdxEngine needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+        self.cfg, self.dtype, self.tdtype = cfg, dtype, _TORCH_DT[dtype]
+        self.device = torch.device("cuda", device)
+        self.lora = lora
+        l, q, v = cfg.llama, cfg.qformer, cfg.vision
+        rc = RdxConfig()
+        rc.dtype = _RDX_DT[dtype]
+        rc.vocab, rc.hidden, rc.inter, rc.layers, rc.heads, rc.max_pos = l.vocab, l.hidden, l.inter, l.layers, l.heads, l.max_pos
+        rc.rms_eps = l.rms_eps
+        rc.lora_r, rc.lora_scale = (l.lora_r if lora else 0), l.lora_scale
+        rc.qformer_dim = l.qformer_dim
+        rc.q_hidden, rc.q_layers, rc.q_heads, rc.q_inter = q.hidden, q.layers, q.heads, q.inter
+        rc.q_enc_width, rc.q_nquery, rc.q_cross_freq, rc.q_ln_eps = q.enc_width, q.n_query, q.cross_freq, q.ln_eps
+        rc.v_img, rc.v_stem, rc.v_b2v, rc.v_proj, rc.v_ln_eps = v.img, v.stem, v.b2v, v.proj, v.ln_eps
+        for i in range(4):
+            rc.v_planes[i] = v.planes[i]
+            rc.v_blocks[i] = v.blocks[i]
+        rc.max_batch, rc.max_len = max_batch, max_len
+        rc.enable_vision, rc.enable_llama = int(vision), int(llama)
+        self.max_batch, self.max_len = max_batch, max_len
+        self.ctx = C.c_void_p()
+        rcode = self.lib.rdx_create(C.byref(self.ctx), device, C.byref(rc))
+        if rcode != 0:
+            msg = self.lib.rdx_last_error(None)
+            raise _lib.RdxError(f"rdx_create failed ({rcode}): {msg.decode() if msg else '?'}")
+        self._finalized = False
+        self._keep = {}
+
+    # ------------------------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "ctx", None) is not None and self.ctx.value:
+            self.lib.rdx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.ctx, self.lib.rdx_sync(self.ctx), "rdx_sync")
+
+    # ------------------------------------------------------------------------------------------------------------
+    def _upload(self, items):
+        for name, t, kind in items:
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            if t.dim() == 1:
+                t = t.view(1, -1)
+            rows, cols = t.shape[0], t.numel() // t.shape[0]
+            torch.cuda.synchronize(self.device)
+            check(self.ctx, self.lib.rdx_set_weight(self.ctx, name.encode(), _ptr(t), rows, cols, kind), f"rdx_set_weight({name})")
+            del t
+
+    def load_weights(self, get: Callable[[str], torch.Tensor], vision: bool = True, llama: bool = True):
+        """`get(name)` returns the fp32 reference-named tensor (any device). Uploads and finalizes."""
+        with torch.no_grad():
+            if vision:
+                self._upload(W.vision_items(get, self.cfg.vision))
+                self._upload(W.qformer_items(get, self.cfg.qformer))
+            if llama:
+                self._upload(W.llama_items(get, self.cfg.llama, self.lora))
+        check(self.ctx, self.lib.rdx_finalize_weights(self.ctx), "rdx_finalize_weights")
+        self._finalized = True
+
+    # ------------------------------------------------------------------------------------------------------------
+    def encode_image(self, image: torch.Tensor, want_image_embeds: bool = True):
+        """image float32[B,3,S,S] on this device -> (qformer_out f32[B,nq,Hq], image_embeds f32[B,P,C] or None)."""
+        v, q = self.cfg.vision, self.cfg.qformer
+        if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != v.img or image.shape[3] != v.img:
+            raise ValueError(f"expected image [B,3,{v.img},{v.img}], got {tuple(image.shape)}")
+        image = image.to(device=self.device, dtype=torch.float32).contiguous()
+        B = image.shape[0]
+        out = torch.empty(B, q.n_query, q.hidden, dtype=torch.float32, device=self.device)
+        emb = torch.empty(B, v.n_patches, v.proj, dtype=torch.float32, device=self.device) if want_image_embeds else None
+        torch.cuda.synchronize(self.device)
+        check(self.ctx, self.lib.rdx_encode_image(self.ctx, _ptr(image), B, _ptr(out), _ptr(emb)), "rdx_encode_image")
+        self.sync()
+        return out, emb
+
+    def generate(self, ids: torch.Tensor, qformer_embs: Optional[torch.Tensor], max_new: int, eos_id: int = 2,
+                 pad_id: int = 0, mask: Optional[torch.Tensor] = None, output_scores: bool = False, use_graph: bool = True):
+        """Greedy generation. Returns (tokens int32[B,n_steps], scores [n_steps,B,V] model dtype or None, n_steps)."""
+        B, T = ids.shape
+        ids32 = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        m32 = None if mask is None else mask.to(device=self.device, dtype=torch.int32).contiguous()
+        qf = None if qformer_embs is None else qformer_embs.to(device=self.device, dtype=torch.float32).contiguous()
+        key = ("tok", B, max_new)
+        toks = self._keep.get(key)
+        if toks is None:
+            toks = torch.zeros(B, max_new, dtype=torch.int32, device=self.device)
+            self._keep[key] = toks
+        toks.fill_(pad_id)
+        scores = None
+        if output_scores:
+            skey = ("scores", B, max_new)
+            scores = self._keep.get(skey)
+            if scores is None:
+                scores = torch.zeros(max_new, B, self.cfg.llama.vocab, dtype=self.tdtype, device=self.device)
+                self._keep[skey] = scores
+        n = C.c_int(0)
+        torch.cuda.synchronize(self.device)
+        check(self.ctx, self.lib.rdx_generate(self.ctx, _ptr(ids32), _ptr(m32), B, T, _ptr(qf), max_new, eos_id, pad_id,
+                                              _ptr(toks), _ptr(scores), C.byref(n), int(use_graph)), "rdx_generate")
+        return toks, scores, n.value
+
+    def prefill(self, ids, qformer_embs, max_new, eos_id=2, pad_id=0, mask=None, want_logits=True):
+        B, T = ids.shape
+        ids32 = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        m32 = None if mask is None else mask.to(device=self.device, dtype=torch.int32).contiguous()
+        qf = None if qformer_embs is None else qformer_embs.to(device=self.device, dtype=torch.float32).contiguous()
+        toks = torch.full((B, max_new), pad_id, dtype=torch.int32, device=self.device)
+        logits = torch.empty(B, self.cfg.llama.vocab, dtype=self.tdtype, device=self.device) if want_logits else None
+        self._keep["prefill"] = (ids32, m32, qf, toks)
+        torch.cuda.synchronize(self.device)
+        check(self.ctx, self.lib.rdx_prefill(self.ctx, _ptr(ids32), _ptr(m32), B, T, _ptr(qf), max_new, eos_id, pad_id,
+                                             _ptr(toks), _ptr(logits)), "rdx_prefill")
+        self.sync()
+        return toks, logits
+
+    def decode_step(self, want_logits=True):
+        ids32, m32, qf, toks = self._keep["prefill"]
+        B = ids32.shape[0]
+        logits = torch.empty(B, self.cfg.llama.vocab, dtype=self.tdtype, device=self.device) if want_logits else None
+        check(self.ctx, self.lib.rdx_decode_step(self.ctx, _ptr(logits)), "rdx_decode_step")
+        self.sync()
+        return toks, logits
+
+    def kv_read(self, layer: int, which: int, batch: int) -> torch.Tensor:
+        l = self.cfg.llama
+        out = torch.empty(self.max_batch, l.heads, self.max_len, l.head_dim, dtype=self.tdtype, device=self.device)
+        check(self.ctx, self.lib.rdx_kv_read(self.ctx, layer, which, _ptr(out)), "rdx_kv_read")
+        self.sync()
+        return out[:batch]
+
+    def time_unit(self, what: int, iters: int) -> float:
+        ms = C.c_float(0)
+        check(self.ctx, self.lib.rdx_time(self.ctx, what, iters, C.byref(ms)), "rdx_time")
+        return ms.value
+
+
+def synth_getter(cfg: RaDialogCfg, device, lora: bool = True) -> Callable[[str], torch.Tensor]:
+    """Lazy deterministic random-init weights (radialog_amd.synth), generated on `device` one tensor at a time."""
+    from . import synth
+    specs: Dict[str, tuple] = {}
+    specs.update(synth.vision_specs(cfg.vision))
+    specs.update(synth.qformer_specs(cfg.qformer))
+    specs.update(synth.llama_specs(cfg.llama, lora=lora))
+
+    def get(name: str) -> torch.Tensor:
+        shape, gen = specs[name]
+        return gen(name, shape, device)
+
+    return get
