@@ -93,6 +93,12 @@ int rdx_hidden_read(rdx_ctx* ctx, void* dst /*model dtype [B][hidden]: decoder o
  *   what = 2: ... the QKV GEMV, 3: o_proj, 4: down_proj, 5: lm_head */
 int rdx_time(rdx_ctx* ctx, int what, int iters, float* ms_host);
 
+/* one bare GEMM through the production kernels: out = epilogue(X . W^T); X/resid/norm_w/out model dtype, W [N][K] and
+ * bias fp32. epi: 0 none, 1 relu, 2 gelu, 3 +resid, 4 swiglu(interleaved gate/up rows), 6 relu(+resid).
+ * force: 0 = production dispatch (M <= 32 -> skinny), 1 = skinny, 2 = tiled. Test / benchmark hook. */
+int rdx_gemm_test(rdx_ctx* ctx, const void* X, const float* W, const float* bias, const void* resid, void* out, int M, int N,
+                  int K, int epi, const void* norm_w, float eps, int force);
+
 #ifdef __cplusplus
 }
 #endif

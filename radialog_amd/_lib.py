@@ -8,6 +8,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must be imported BEFORE librdx.so is loaded so both share torch's HIP runtime
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librdx.so")
 
@@ -60,6 +62,7 @@ SYMBOLS = {
     "rdx_kv_read": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "rdx_hidden_read": (C.c_int, [_P, _P]),
     "rdx_time": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "rdx_gemm_test": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_int]),
 }
 
 _lib = None

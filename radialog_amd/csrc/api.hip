@@ -72,7 +72,7 @@ struct rdx_ctx {
     int *d_img_pos = nullptr, *d_pos_ids = nullptr, *d_pos = nullptr, *d_slot = nullptr, *d_step = nullptr, *d_unf = nullptr;
     float* part_val = nullptr; int* part_idx = nullptr; int n_vtiles = 0;
     // decode-step activations ([max_batch] rows) and prefill activations (grown on demand)
-    void *dx = nullptr, *dqkv = nullptr, *datt = nullptr, *dgu = nullptr;
+    void *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dgu = nullptr;
     void *px = nullptr, *pxn = nullptr, *pqkv = nullptr, *pq = nullptr, *patt = nullptr, *pgu = nullptr, *pqe = nullptr, *pimg = nullptr;
     size_t prefill_rows = 0;
     int cur_B = 0, cur_T = 0, cur_max_new = 0, cur_eos = -1, cur_pad = 0;
@@ -133,10 +133,20 @@ static GemmArgs gargs(const void* X, int ldx, const GemmW& W, const float* bias,
     return a;
 }
 
+// Skinny GEMM with an optional fused RMSNorm: fused when the activations fit the kernel's LDS staging path, otherwise
+// the rows are normalised once by rmsnorm_k into a scratch buffer (batch-32 decode).
+static void skinny(rdx_ctx* c, GemmArgs a, int epi) {
+    if (a.norm_w && !skinny_fits_lds(a.M, a.K)) {
+        launch_rmsnorm(c->cfg.dtype, a.X, a.norm_w, c->dxn, a.M, a.K, a.eps, c->stream);
+        a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr;
+    }
+    launch_skinny_gemm(c->cfg.dtype, a, epi, c->stream);
+}
+
 static void run_gemm(rdx_ctx* c, GemmArgs a, int epi) {
     ConvGeom cg;
     memset(&cg, 0, sizeof(cg));
-    if (a.M <= 32) launch_skinny_gemm(c->cfg.dtype, a, epi == EPI_RESID_RELU ? EPI_RESID : epi, c->stream);
+    if (a.M <= 32) skinny(c, a, epi == EPI_RESID_RELU ? EPI_RESID : epi);
     else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
 }
 
@@ -311,7 +321,7 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         c->n_vtiles = c->lm_head.Npad / 16;
         ALLOC(c, c->part_val, (size_t)B * c->n_vtiles * sizeof(float));
         ALLOC(c, c->part_idx, (size_t)B * c->n_vtiles * sizeof(int));
-        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
+        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)B * H * 2); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
         ALLOC(c, c->datt, (size_t)B * H * 2); ALLOC(c, c->dgu, (size_t)B * I * 2);
     }
     if (f.enable_vision) {
@@ -505,7 +515,7 @@ static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, c
     a.norm_w = c->final_norm; a.eps = f.rms_eps;
     a.part_val = c->part_val; a.part_idx = c->part_idx;
     a.out_step = out_step; a.out_step_stride = step_stride;
-    launch_skinny_gemm(f.dtype, a, EPI_LOGITS, c->stream);
+    skinny(c, a, EPI_LOGITS);
     launch_greedy_step(f.dtype, c->part_val, c->part_idx, c->n_vtiles, B, c->cur_eos, c->cur_pad, c->cur_max_new,
                        c->cur_tokens, c->d_unf, advance ? c->d_pos : nullptr, advance ? c->d_slot : nullptr, c->d_step,
                        c->embed, f.vocab, c->dx, f.hidden, c->stream);
@@ -570,13 +580,13 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
     for (int l = 0; l < f.layers; ++l) {
         const LlamaLayer& L = c->ll[l];
         { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps;
-          launch_skinny_gemm(dt, a, EPI_NONE, s); }
+          skinny(c, a, EPI_NONE); }
         launch_decode_attention(dt, c->ld, c->dqkv, L.lora_bq, L.lora_bv, c->rope_cos, c->rope_sin, c->d_pos, c->d_slot, c->key_mask,
                                 kv_ptr(c, c->kcache, l), kv_ptr(c, c->vcache, l), c->datt, B, s);
-        { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; launch_skinny_gemm(dt, a, EPI_RESID, s); }
+        { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; skinny(c, a, EPI_RESID); }
         { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps;
-          launch_skinny_gemm(dt, a, EPI_SILU_MUL, s); }
-        { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; launch_skinny_gemm(dt, a, EPI_RESID, s); }
+          skinny(c, a, EPI_SILU_MUL); }
+        { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; skinny(c, a, EPI_RESID); }
     }
     lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
 }
@@ -691,16 +701,16 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
                 GemmArgs a = gargs(c->dx, H, c->lm_head, nullptr, nullptr, f.vocab, B);
                 a.N = c->lm_head.Npad; a.n_valid = f.vocab; a.norm_w = c->final_norm; a.eps = f.rms_eps;
                 a.part_val = c->part_val; a.part_idx = c->part_idx;
-                launch_skinny_gemm(dt, a, EPI_LOGITS, c->stream);
+                skinny(c, a, EPI_LOGITS);
                 ++launches;
                 continue;
             }
             for (int l = 0; l < f.layers; ++l) {
                 const LlamaLayer& L = c->ll[l];
-                if (what == 1) { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; launch_skinny_gemm(dt, a, EPI_SILU_MUL, c->stream); }
-                else if (what == 2) { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps; launch_skinny_gemm(dt, a, EPI_NONE, c->stream); }
-                else if (what == 3) { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dqkv, H, B); launch_skinny_gemm(dt, a, EPI_NONE, c->stream); }
-                else if (what == 4) { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); launch_skinny_gemm(dt, a, EPI_NONE, c->stream); }
+                if (what == 1) { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; skinny(c, a, EPI_SILU_MUL); }
+                else if (what == 2) { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps; skinny(c, a, EPI_NONE); }
+                else if (what == 3) { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dqkv, H, B); skinny(c, a, EPI_NONE); }
+                else if (what == 4) { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); skinny(c, a, EPI_NONE); }
                 else return fail(c, -1, "rdx_time: unknown unit %d", what);
                 ++launches;
             }
@@ -712,5 +722,48 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
     HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
     hipEventDestroy(e0); hipEventDestroy(e1);
     *ms_host = ms / (float)launches;
+    return 0;
+}
+
+// One bare GEMM through the production kernels (unit tests / kernel benchmarks): out = epilogue(X . W^T).
+// X, resid, norm_w, out are model-dtype device tensors; W [N][K] and bias [N] are fp32 device tensors (W is packed here).
+extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const float* bias, const void* resid, void* out,
+                             int M, int N, int K, int epi, const void* norm_w, float eps, int force) {
+    if (!c || !X || !W || !out) return fail(c, -1, "rdx_gemm_test: null argument");
+    if (K % 32 || N % 16) return fail(c, -1, "rdx_gemm_test: need K %% 32 == 0 and N %% 16 == 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    GemmW w;
+    w.N = N; w.K = K; w.Npad = N;
+    void* wp = nullptr;
+    HIPCHK(c, hipMalloc(&wp, (size_t)N * K * 2));
+    w.w = wp;
+    launch_pack_weight(c->cfg.dtype, W, wp, N, K, N, nullptr, c->stream);
+    GemmArgs a = gargs(X, K, w, bias, out, epi == EPI_SILU_MUL ? N / 2 : N, M);
+    a.resid = resid; a.ldr = N;
+    a.norm_w = norm_w; a.eps = eps;
+    void* xn = nullptr;
+    const bool use_skinny = force == 1 || (force == 0 && M <= 32);
+    if (use_skinny) {
+        if (M > 32) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: skinny path needs M <= 32"); }
+        if (a.norm_w && !skinny_fits_lds(M, K)) {
+            HIPCHK(c, hipMalloc(&xn, (size_t)M * K * 2));
+            launch_rmsnorm(c->cfg.dtype, X, norm_w, xn, M, K, eps, c->stream);
+            a.X = xn; a.norm_w = nullptr;
+        }
+        launch_skinny_gemm(c->cfg.dtype, a, epi == EPI_RESID_RELU ? EPI_RESID : epi, c->stream);
+    } else {
+        if (a.norm_w) {
+            HIPCHK(c, hipMalloc(&xn, (size_t)M * K * 2));
+            launch_rmsnorm(c->cfg.dtype, X, norm_w, xn, M, K, eps, c->stream);
+            a.X = xn; a.norm_w = nullptr;
+        }
+        ConvGeom cg;
+        memset(&cg, 0, sizeof(cg));
+        launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    hipFree(wp);
+    if (xn) hipFree(xn);
     return 0;
 }

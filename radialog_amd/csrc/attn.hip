@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void attention_k(AttnArgs a, int TkP) {
     T* P = reinterpret_cast<T*>(smem + (size_t)16 * TkP * 4);        // [16][TkP]
 
     const int q0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // wave id made provably wave-uniform: MFMA must never sit under an EXEC-masked (per-lane) branch
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
     const T* Q = reinterpret_cast<const T*>(a.Q) + b * a.q_bs + h * a.q_hs;
     const T* K = reinterpret_cast<const T*>(a.K) + b * a.k_bs + h * a.k_hs;
@@ -218,7 +219,13 @@ void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, cons
 // ------------------------------------------------------------------------------------------------------------------
 // decode attention (head_dim 128; 16 lanes x 16 B cover one K/V cache row)
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int DA_WAVES = 4;
+// One workgroup of 16 waves per (head, batch row). The cache is small per head (L x 256 B for K and for V), so the
+// kernel is latency-bound: every lane issues ALL its K and V row loads up front (position j -> 16 lanes; up to
+// DA_PRE x 64 = 512 positions prefetched in registers, later positions by a second, plain loop), then scores,
+// two-pass fp32 softmax with the reference's rounding points, and PV from the already-resident V registers.
+constexpr int DA_WAVES = 16;
+constexpr int DA_PRE = 8;                     // prefetched (K,V) rows per lane
+constexpr int DA_SPAN = DA_WAVES * 4;         // positions covered by one block-wide load
 
 template <typename T>
 __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_k(LlamaDims d, const T* __restrict__ qkv,
@@ -238,7 +245,8 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_k(LlamaDims d,
     float* S = dsm + 3 * D + 32 + DA_WAVES * D;   // [max_len]
 
     const int h = blockIdx.x, b = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int jsub = lane >> 4, doct = lane & 15;
     const int H = d.hidden;
     const int slot = slot_b[b];
     const int nk = slot + 1;
@@ -246,6 +254,16 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_k(LlamaDims d,
     T* kc = kcache + ((size_t)b * d.heads + h) * d.max_len * D;
     T* vc = vcache + ((size_t)b * d.heads + h) * d.max_len * D;
     const uint8_t* km = key_mask + (size_t)b * d.max_len;
+
+    // ---- all cached K and V rows of this lane in flight first ----------------------------------------------------
+    u4 kr[DA_PRE], vr[DA_PRE];
+#pragma unroll
+    for (int u = 0; u < DA_PRE; ++u) {
+        const int j = u * DA_SPAN + w * 4 + jsub;
+        const int jc = j < slot ? j : 0;                       // clamped: unconditional loads, unused when j >= slot
+        kr[u] = ldg16(kc + (size_t)jc * D + doct * 8);
+        vr[u] = ldg16(vc + (size_t)jc * D + doct * 8);
+    }
 
     // ---- new token: LoRA add, RoPE, append to the cache -----------------------------------------------------------
     if (tid < D) {
@@ -278,39 +296,45 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_k(LlamaDims d,
     }
     __syncthreads();
 
-    // ---- scores over cached keys: one cache row per 16 lanes ------------------------------------------------------
-    const int jsub = lane >> 4, doct = lane & 15;
+    // ---- scores ---------------------------------------------------------------------------------------------------------
     float q8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) q8[e] = qf[doct * 8 + e];
     const float div = sqrtf((float)D);
-    constexpr int PER_IT = DA_WAVES * 4;
-    for (int j0 = 0; j0 < nk; j0 += PER_IT * 4) {
-        V8 kv[4];
-        int jj[4];
+    auto score_store = [&](int j, float acc) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            jj[u] = j0 + u * PER_IT + w * 4 + jsub;
-            if (jj[u] < slot) kv[u] = as_vec8<T>(ldg16(kc + (size_t)jj[u] * D + doct * 8));
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (doct == 0 && j < nk) {
+            const float sc = rnd<T>(rnd<T>(acc) / div);
+            S[j] = km[j] ? sc : -INFINITY;
         }
+    };
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = jj[u];
-            float acc = 0.f;
-            if (j < slot) {
+    for (int u = 0; u < DA_PRE; ++u) {
+        const int j = u * DA_SPAN + w * 4 + jsub;
+        float acc = 0.f;
+        if (j < slot) {
+            const V8 kv = as_vec8<T>(kr[u]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += q8[e] * tof<T>(kv[u][e]);
-            } else if (j == slot) {
+            for (int e = 0; e < 8; ++e) acc += q8[e] * tof<T>(kv[e]);
+        } else if (j == slot) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += q8[e] * kf[doct * 8 + e];
-            }
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-            if (doct == 0 && j < nk) {
-                const float sc = rnd<T>(rnd<T>(acc) / div);
-                S[j] = km[j] ? sc : -INFINITY;
-            }
+            for (int e = 0; e < 8; ++e) acc += q8[e] * kf[doct * 8 + e];
         }
+        score_store(j, acc);
+    }
+    for (int j0 = DA_PRE * DA_SPAN; j0 < nk; j0 += DA_SPAN) {          // contexts beyond the prefetch window
+        const int j = j0 + w * 4 + jsub;
+        float acc = 0.f;
+        if (j < slot) {
+            const V8 kv = as_vec8<T>(ldg16(kc + (size_t)j * D + doct * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += q8[e] * tof<T>(kv[e]);
+        } else if (j == slot) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += q8[e] * kf[doct * 8 + e];
+        }
+        score_store(j, acc);
     }
     __syncthreads();
 
@@ -332,26 +356,31 @@ __global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_k(LlamaDims d,
     float o8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o8[e] = 0.f;
-    for (int j0 = 0; j0 < nk; j0 += PER_IT * 4) {
-        V8 vv[4];
-        int jj[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            jj[u] = j0 + u * PER_IT + w * 4 + jsub;
-            if (jj[u] < slot) vv[u] = as_vec8<T>(ldg16(vc + (size_t)jj[u] * D + doct * 8));
+    for (int u = 0; u < DA_PRE; ++u) {
+        const int j = u * DA_SPAN + w * 4 + jsub;
+        if (j < slot) {
+            const float p = S[j];
+            const V8 vv = as_vec8<T>(vr[u]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] += p * tof<T>(vv[e]);
+        } else if (j == slot) {
+            const float p = S[j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] += p * vf[doct * 8 + e];
         }
+    }
+    for (int j0 = DA_PRE * DA_SPAN; j0 < nk; j0 += DA_SPAN) {
+        const int j = j0 + w * 4 + jsub;
+        if (j < slot) {
+            const float p = S[j];
+            const V8 vv = as_vec8<T>(ldg16(vc + (size_t)j * D + doct * 8));
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = jj[u];
-            if (j < slot) {
-                const float p = S[j];
+            for (int e = 0; e < 8; ++e) o8[e] += p * tof<T>(vv[e]);
+        } else if (j == slot) {
+            const float p = S[j];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o8[e] += p * tof<T>(vv[u][e]);
-            } else if (j == slot) {
-                const float p = S[j];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o8[e] += p * rnd<T>(vf[doct * 8 + e]);
-            }
+            for (int e = 0; e < 8; ++e) o8[e] += p * vf[doct * 8 + e];
         }
     }
 #pragma unroll

@@ -69,22 +69,86 @@ template <typename T> __device__ __forceinline__ float swiglu(float gate_acc, fl
 // ------------------------------------------------------------------------------------------------------------------
 // skinny GEMM
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int SK_WAVES = 8;
-constexpr int SK_UNROLL = 8;
-
-template <typename T, int MT, int EPI, bool NORM>
-__global__ __launch_bounds__(SK_WAVES * 64) void skinny_gemm_k(GemmArgs a) {
+// One workgroup = one 16-column output tile; its WAVES waves split K. Each wave streams its K slice of the packed tile
+// (1 KiB per wave-instruction, non-temporal) in register batches of U blocks, the next batch always in flight while
+// the current one is multiplied; the first batch is issued BEFORE the RMSNorm prologue so HBM latency overlaps it.
+// All weight loads are unconditional (addresses clamped inside the slice) so the compiler can hoist a whole batch.
+// XLDS = true : M*K activations fit in LDS -> the workgroup normalises (optional fused RMSNorm) and stages x-hat once,
+//               the main loop takes its MFMA B operand from LDS (no per-wave redundant norm math, few registers).
+// XLDS = false: activations streamed from global/L2 in fragment order (already normalised by rmsnorm_k if needed).
+template <typename T, int MT, int EPI, bool NORM, int WAVES, bool XLDS>
+__global__ __launch_bounds__(WAVES * 64) void skinny_gemm_k(GemmArgs a) {
     typedef typename Vec8<T>::type V8;
-    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][MT][256];   // [wave][mt][m_local*16 + n_local]
-    __shared__ float ssq[SK_WAVES][MT * 16];
-    __shared__ float rstd_s[MT * 16];
+    constexpr int U = XLDS ? 8 : 4;
+    constexpr int NTHR = WAVES * 64;
+    __shared__ __attribute__((aligned(16))) float red[WAVES][MT][256];   // [wave][mt][m_local*16 + n_local]
+    __shared__ float ssq[WAVES][16];
+    __shared__ float rstd_s[16];
+    extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
+    T* xs = reinterpret_cast<T*>(dyn_smem);                              // XLDS: [M][K] x-hat
 
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // wave id made provably wave-uniform (SGPR): K-slice bounds become scalar, and no MFMA ends up under an
+    // EXEC-masked per-lane branch (MFMA ignores EXEC -- a masked-off MFMA would still accumulate)
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int KC = a.K >> 5;
-    const int c0 = (KC * w) / SK_WAVES, c1 = (KC * (w + 1)) / SK_WAVES;
+    const int K = a.K, KC = K >> 5;
+    const int c0 = (KC * w) / WAVES, c1 = (KC * (w + 1)) / WAVES;
     const T* X = reinterpret_cast<const T*>(a.X);
-    const T* NW = reinterpret_cast<const T*>(a.norm_w);
+    const u4* wbase = reinterpret_cast<const u4*>(a.W) + (size_t)blockIdx.x * KC * 64 + lane;
+    const int clast = min(max(c1 - 1, c0), KC - 1);
+
+    // two weight batches in flight before anything else (HBM latency overlaps the prologue)
+    u4 wv[U], wn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) wv[u] = ldg16_nt(wbase + (size_t)min(c0 + u, clast) * 64);
+#pragma unroll
+    for (int u = 0; u < U; ++u) wn[u] = wv[u];
+    if (c0 + U < c1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) wn[u] = ldg16_nt(wbase + (size_t)min(c0 + U + u, clast) * 64);
+    }
+
+    if (XLDS) {
+        const int K8 = K >> 3;
+        if (NORM) {
+            // LlamaRMSNorm (:85-93): fp32 mean of squares per row
+            for (int m = 0; m < a.M; ++m) {
+                float ss = 0.f;
+                for (int k8 = threadIdx.x; k8 < K8; k8 += NTHR) {
+                    V8 xv = as_vec8<T>(ldg16(X + (size_t)m * a.ldx + (size_t)k8 * 8));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float f = tof<T>(xv[j]); ss += f * f; }
+                }
+                ss = wave_sum(ss);
+                if (lane == 0) ssq[w][m] = ss;
+            }
+            __syncthreads();
+            if (threadIdx.x < a.M) {
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < WAVES; ++i) t += ssq[i][threadIdx.x];
+                rstd_s[threadIdx.x] = rsqrtf(t / (float)K + a.eps);
+            }
+            __syncthreads();
+        }
+        const T* NW = reinterpret_cast<const T*>(a.norm_w);
+        const int total8 = a.M * K8;
+        for (int i = threadIdx.x; i < total8; i += NTHR) {
+            const int m = i / K8, k8 = i - m * K8;
+            V8 xv = as_vec8<T>(ldg16(X + (size_t)m * a.ldx + (size_t)k8 * 8));
+            if (NORM) {
+                const float rs = rstd_s[m];
+                V8 nw = as_vec8<T>(ldg16(NW + (size_t)k8 * 8));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float h = rnd<T>(tof<T>(xv[j]) * rs);      // (x * rsqrt(var+eps)).to(dtype)
+                    xv[j] = fromf<T>(tof<T>(nw[j]) * h);             // weight * hidden  (dtype mult)
+                }
+            }
+            *reinterpret_cast<u4*>(xs + (size_t)m * K + (size_t)k8 * 8) = as_u4<T>(xv);
+        }
+        __syncthreads();
+    }
 
     const T* xrow[MT];
     bool xok[MT];
@@ -92,82 +156,41 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_gemm_k(GemmArgs a) {
     for (int mt = 0; mt < MT; ++mt) {
         const int m = mt * 16 + r;
         xok[mt] = m < a.M;
-        xrow[mt] = X + (size_t)(xok[mt] ? m : 0) * a.ldx + g * 8;
-    }
-    const u4* wp = reinterpret_cast<const u4*>(a.W) + ((size_t)blockIdx.x * KC + c0) * 64 + lane;
-
-    float rs[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) rs[mt] = 1.f;
-    if (NORM) {
-        // LlamaRMSNorm statistics: mean of squares in fp32 over the whole row; each wave sums its own K slice.
-        float ss[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ss[mt] = 0.f;
-        for (int c = c0; c < c1; ++c) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                if (xok[mt]) {
-                    V8 xv = as_vec8<T>(ldg16(xrow[mt] + (size_t)c * 32));
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { const float f = tof<T>(xv[j]); ss[mt] += f * f; }
-                }
-            }
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            ss[mt] += __shfl_xor(ss[mt], 16, 64);
-            ss[mt] += __shfl_xor(ss[mt], 32, 64);
-            if (g == 0) ssq[w][mt * 16 + r] = ss[mt];
-        }
-        __syncthreads();
-        if (threadIdx.x < MT * 16) {
-            float t = 0.f;
-#pragma unroll
-            for (int i = 0; i < SK_WAVES; ++i) t += ssq[i][threadIdx.x];
-            rstd_s[threadIdx.x] = rsqrtf(t / (float)a.K + a.eps);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) rs[mt] = rstd_s[mt * 16 + r];
+        xrow[mt] = XLDS ? (xs + (size_t)(xok[mt] ? m : 0) * K + g * 8) : (X + (size_t)(xok[mt] ? m : 0) * a.ldx + g * 8);
     }
 
     v4f acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    for (int cb = c0; cb < c1; cb += SK_UNROLL) {
-        u4 wv[SK_UNROLL];
+    for (int cb = c0; cb < c1; cb += U) {
+        u4 xr[U][MT];
+        if (!XLDS) {
 #pragma unroll
-        for (int u = 0; u < SK_UNROLL; ++u)
-            if (cb + u < c1) wv[u] = ldg16_nt(wp + (size_t)u * 64);
-        wp += (size_t)SK_UNROLL * 64;
+            for (int u = 0; u < U; ++u) {
+                const int c = min(cb + u, clast);
 #pragma unroll
-        for (int u = 0; u < SK_UNROLL; ++u) {
-            const int c = cb + u;
-            if (c < c1) {
-                u4 nwv = (u4){0u, 0u, 0u, 0u};
-                if (NORM) nwv = ldg16(NW + (size_t)c * 32 + g * 8);
+                for (int mt = 0; mt < MT; ++mt)
+                    xr[u][mt] = xok[mt] ? ldg16(xrow[mt] + (size_t)c * 32) : (u4){0u, 0u, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (cb + u < c1) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    V8 xv;
-                    if (xok[mt]) {
-                        xv = as_vec8<T>(ldg16(xrow[mt] + (size_t)c * 32));
-                        if (NORM) {
-                            V8 nw = as_vec8<T>(nwv);
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const float h = rnd<T>(tof<T>(xv[j]) * rs[mt]);    // (x * rsqrt(var+eps)).to(dtype)
-                                xv[j] = fromf<T>(tof<T>(nw[j]) * h);               // weight * hidden  (dtype mult)
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) xv[j] = fromf<T>(0.f);
-                    }
-                    acc[mt] = mfma16(as_vec8<T>(wv[u]), xv, acc[mt]);
+                    u4 xv;
+                    if (XLDS) xv = xok[mt] ? *reinterpret_cast<const u4*>(xrow[mt] + (size_t)(cb + u) * 32) : (u4){0u, 0u, 0u, 0u};
+                    else xv = xr[u][mt];
+                    acc[mt] = mfma16(as_vec8<T>(wv[u]), as_vec8<T>(xv), acc[mt]);
                 }
             }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) wv[u] = wn[u];
+        if (cb + 2 * U < c1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) wn[u] = ldg16_nt(wbase + (size_t)min(cb + 2 * U + u, clast) * 64);
         }
     }
     // D[i = n_local = g*4+reg][j = m_local = r]  ->  red[w][mt][m_local*16 + n_local]
@@ -177,13 +200,14 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_gemm_k(GemmArgs a) {
     __syncthreads();
 
     const int t = threadIdx.x;
-    if (t >= MT * 256) return;
-    const int mt = t >> 8, idx = t & 255, m_local = idx >> 4, n_local = idx & 15;
+    constexpr int NOUT = MT * 256;
+    for (int o = t; o < NOUT; o += WAVES * 64) {
+    const int mt = o >> 8, idx = o & 255, m_local = idx >> 4, n_local = idx & 15;
     const int m = mt * 16 + m_local;
     const int n = blockIdx.x * 16 + n_local;
     float v = 0.f;
 #pragma unroll
-    for (int i = 0; i < SK_WAVES; ++i) v += red[i][mt][idx];
+    for (int i = 0; i < WAVES; ++i) v += red[i][mt][idx];
     if (a.bias && n < a.N) v += a.bias[n];
     T* out = reinterpret_cast<T*>(a.out);
     if (a.out_step && out) out += (size_t)(*a.out_step) * a.out_step_stride;
@@ -204,7 +228,7 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_gemm_k(GemmArgs a) {
         // rows of a tile: 0..7 = gate_proj rows 8t..8t+7, 8..15 = up_proj rows 8t..8t+7
         float u = 0.f;
 #pragma unroll
-        for (int i = 0; i < SK_WAVES; ++i) u += red[i][mt][(idx + 8) & 255];
+        for (int i = 0; i < WAVES; ++i) u += red[i][mt][(idx + 8) & 255];
         if (n_local < 8 && ok) out[(size_t)m * a.ldo + blockIdx.x * 8 + n_local] = fromf<T>(swiglu<T>(v, u));
     } else if (EPI == EPI_LOGITS) {
         float lv = rnd<T>(v);
@@ -214,9 +238,9 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_gemm_k(GemmArgs a) {
         if (!valid) { lv = -INFINITY; li = 0x7fffffff; }
         // argmax over the tile's 16 columns (16 consecutive lanes share m); ties -> lowest index (torch.argmax)
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(lv, o, 64);
-            const int oi = __shfl_xor(li, o, 64);
+        for (int sh = 8; sh > 0; sh >>= 1) {
+            const float ov = __shfl_xor(lv, sh, 64);
+            const int oi = __shfl_xor(li, sh, 64);
             if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
         }
         if (n_local == 0 && m < a.M) {
@@ -224,13 +248,15 @@ __global__ __launch_bounds__(SK_WAVES * 64) void skinny_gemm_k(GemmArgs a) {
             a.part_idx[(size_t)m * gridDim.x + blockIdx.x] = li;
         }
     }
+    }
 }
 
-template <typename T, int MT, bool NORM>
+template <typename T, int MT, bool NORM, int WAVES, bool XLDS>
 static void launch_skinny_epi(const GemmArgs& a, int epi, hipStream_t s) {
     const int nt = (a.N + 15) / 16;
-    dim3 grid(nt), block(SK_WAVES * 64);
-#define RDX_SK(E) hipLaunchKernelGGL((skinny_gemm_k<T, MT, E, NORM>), grid, block, 0, s, a)
+    dim3 grid(nt), block(WAVES * 64);
+    const size_t dyn = XLDS ? (size_t)a.M * a.K * 2 : 0;
+#define RDX_SK(E) hipLaunchKernelGGL((skinny_gemm_k<T, MT, E, NORM, WAVES, XLDS>), grid, block, dyn, s, a)
     switch (epi) {
         case EPI_NONE: RDX_SK(EPI_NONE); break;
         case EPI_RELU: RDX_SK(EPI_RELU); break;
@@ -243,15 +269,24 @@ static void launch_skinny_epi(const GemmArgs& a, int epi, hipStream_t s) {
 #undef RDX_SK
 }
 
-void launch_skinny_gemm(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
+// activations fit the LDS staging path when M*K*2 bytes <= 32 KiB (keeps >= 2 workgroups per CU resident)
+bool skinny_fits_lds(int M, int K) { return M <= 16 && (size_t)M * K * 2 <= 32 * 1024; }
+
+template <typename T>
+static void launch_skinny_T(const GemmArgs& a, int epi, hipStream_t s) {
     const bool norm = a.norm_w != nullptr;
-    RDX_DISPATCH_T(dtype, T, {
-        if (a.M <= 16) {
-            if (norm) launch_skinny_epi<T, 1, true>(a, epi, s); else launch_skinny_epi<T, 1, false>(a, epi, s);
-        } else {
-            if (norm) launch_skinny_epi<T, 2, true>(a, epi, s); else launch_skinny_epi<T, 2, false>(a, epi, s);
-        }
-    });
+    constexpr int WV = 8;
+    if (skinny_fits_lds(a.M, a.K)) {
+        if (norm) launch_skinny_epi<T, 1, true, WV, true>(a, epi, s); else launch_skinny_epi<T, 1, false, WV, true>(a, epi, s);
+    } else if (a.M <= 16) {
+        launch_skinny_epi<T, 1, false, WV, false>(a, epi, s);     // caller pre-normalises (rmsnorm_k) when needed
+    } else {
+        launch_skinny_epi<T, 2, false, WV, false>(a, epi, s);
+    }
+}
+
+void launch_skinny_gemm(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, launch_skinny_T<T>(a, epi, s));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -288,7 +323,7 @@ __global__ __launch_bounds__(256) void tiled_gemm_k(GemmArgs a, ConvGeom cg) {
     const int bn = tile / MB, bm = tile - bn * MB;
     const int M0 = bm * TG_BM, N0 = bn * TG_BN;
 
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
     const int KC = a.K >> 5;

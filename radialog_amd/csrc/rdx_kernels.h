@@ -56,6 +56,9 @@ struct LlamaDims {
 };
 
 void launch_pack_weight(int dtype, const float* src, void* dst, int N, int K, int Npad, const int* rowmap, hipStream_t s);
+// skinny GEMM. A fused RMSNorm (a.norm_w != null) is only honoured when skinny_fits_lds(M, K); otherwise the caller
+// must normalise first (launch_rmsnorm) and pass norm_w = null.
+bool skinny_fits_lds(int M, int K);
 void launch_skinny_gemm(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 void launch_tiled_gemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s);
 

@@ -165,6 +165,21 @@ class RdxEngine:
         self.sync()
         return out[:batch]
 
+    def gemm_test(self, x, w, bias=None, resid=None, epi=0, norm_w=None, eps=1e-6, force=0):
+        """out = epilogue(x @ w.T) through the production GEMM kernels. x [M,K] model dtype, w [N,K] fp32."""
+        M, K = x.shape
+        N = w.shape[0]
+        x = x.to(self.device, self.tdtype).contiguous()
+        w = w.to(self.device, torch.float32).contiguous()
+        b = None if bias is None else bias.to(self.device, torch.float32).contiguous()
+        r = None if resid is None else resid.to(self.device, self.tdtype).contiguous()
+        nw = None if norm_w is None else norm_w.to(self.device, self.tdtype).contiguous()
+        out = torch.empty(M, N // 2 if epi == 4 else N, dtype=self.tdtype, device=self.device)
+        torch.cuda.synchronize(self.device)
+        check(self.ctx, self.lib.rdx_gemm_test(self.ctx, _ptr(x), _ptr(w), _ptr(b), _ptr(r), _ptr(out), M, N, K, epi, _ptr(nw),
+                                               eps, force), "rdx_gemm_test")
+        return out
+
     def time_unit(self, what: int, iters: int) -> float:
         ms = C.c_float(0)
         check(self.ctx, self.lib.rdx_time(self.ctx, what, iters, C.byref(ms)), "rdx_time")

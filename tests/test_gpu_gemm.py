@@ -1,0 +1,68 @@
+"""GEMM kernels alone (through rdx_gemm_test) against torch fp32 matmul on the model-dtype-rounded operands."""
+import pytest
+import torch
+
+from radialog_amd import synth
+from radialog_amd.config import small_cfg
+
+pytestmark = pytest.mark.gpu
+DT = {"f16": torch.float16, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(scope="module", params=["f16", "bf16"])
+def eng(request):
+    from radialog_amd.engine import RdxEngine
+    e = RdxEngine(small_cfg(), dtype=request.param, device=0, max_batch=1, max_len=64, vision=False, llama=False)
+    yield e
+    e.close()
+
+
+def _ref(x, w, bias, resid, epi, norm_w, eps, dt):
+    xf = x.float()
+    if norm_w is not None:
+        var = xf.pow(2).mean(-1, keepdim=True)
+        xf = (norm_w.to(dt) * (xf * torch.rsqrt(var + eps)).to(dt)).float()
+    y = xf.double() @ w.to(dt).double().t()
+    if bias is not None:
+        y = y + bias.double()
+    if epi == 1:
+        y = y.relu()
+    elif epi == 2:
+        y = torch.nn.functional.gelu(y)
+    elif epi == 3:
+        y = y.to(dt).double() + resid.double()
+    elif epi == 6:
+        y = (y.to(dt).double() + resid.double()).relu()
+    elif epi == 4:
+        N = y.shape[1]
+        y4 = y.view(y.shape[0], N // 16, 2, 8)
+        g, u = y4[:, :, 0].to(dt), y4[:, :, 1].to(dt)
+        y = (torch.nn.functional.silu(g.float()).to(dt).double() * u.double()).reshape(y.shape[0], N // 2)
+    return y
+
+
+CASES = [
+    # M, N, K, epi, norm, force
+    (1, 256, 4096, 0, True, 0), (1, 64, 11008, 3, False, 0), (3, 128, 512, 4, True, 0), (8, 48, 352, 0, False, 0),
+    (16, 64, 704, 2, False, 0), (17, 64, 352, 0, False, 0), (32, 768, 352, 0, False, 0), (32, 128, 4096, 4, True, 0),
+    (20, 64, 1408, 3, False, 0), (12, 96, 4096, 3, True, 0),
+    (16, 64, 1408, 0, False, 0), (32, 64, 1024, 0, False, 0), (32, 64, 1280, 0, False, 0), (32, 64, 2048, 0, False, 0),
+    (32, 64, 3072, 0, False, 0), (32, 64, 256, 0, False, 0), (24, 64, 11008, 3, False, 0),
+    (33, 64, 64, 0, False, 0), (200, 352, 288, 1, False, 0), (257, 144, 1024, 6, False, 0), (130, 256, 512, 4, False, 0),
+    (64, 2304, 192, 0, False, 0), (196, 1408, 1408, 0, False, 2), (5, 64, 96, 3, False, 2),
+]
+
+
+@pytest.mark.parametrize("M,N,K,epi,norm,force", CASES)
+def test_gemm_matches_fp32(eng, M, N, K, epi, norm, force):
+    dt = DT[eng.dtype]
+    x = synth.synth(f"g.x{M}.{K}", (M, K), -1.0, 1.0).to(dt)
+    w = synth.synth(f"g.w{N}.{K}", (N, K), -0.05, 0.05)
+    bias = synth.synth(f"g.b{N}", (N,), -0.5, 0.5) if epi in (0, 1, 2) else None
+    resid = synth.synth(f"g.r{M}.{N}", (M, N), -1.0, 1.0).to(dt) if epi in (3, 6) else None
+    nw = synth.synth(f"g.n{K}", (K,), 0.8, 1.2).to(dt) if norm else None
+    out = eng.gemm_test(x, w, bias, resid, epi, nw, 1e-6, force).float().cpu()
+    ref = _ref(x, w, bias, resid, epi, nw, 1e-6, dt).float()
+    tol = {"f16": 2e-3, "bf16": 1.6e-2}[eng.dtype] * max(1.0, float(ref.abs().max()))
+    err = float((out - ref).abs().max())
+    assert err < tol, f"max abs err {err} (tol {tol})"
