@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""demo.py -- the reference's interactive entry point (demo.py:245-305 `get_response`) on the MI355X-native path.
+
+Same flow and flags (`--cfg-path`, `--options`): image -> vis_transforms (Resize 512 / CenterCrop 448 / ToTensor /
+ExpandChannels, demo.py:144) -> blip_model.forward_image -> report prompt with 32 x <IMG> -> lang_model.generate
+(greedy, max_new_tokens=300) -> text after "ASSISTANT:". The gradio widgets of the reference are UI only and are not
+reproduced; `--image` runs one request from the command line (a synthetic radiograph when no path is given, random-init
+weights when no checkpoints are reachable -- there is no network here)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from radialog_amd import synth                                              # noqa: E402
+from radialog_amd.blip2_qformer import Config, tasks                        # noqa: E402
+from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM             # noqa: E402
+from radialog_amd.prompter import new_conversation, report_prompt          # noqa: E402
+from radialog_amd.tokenizer import load_tokenizer                          # noqa: E402
+
+
+def parse_args():
+    p = argparse.ArgumentParser(description="RaDialog demo (MI355X-native hot path)")
+    p.add_argument("--cfg-path", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "blip2_pretrain_stage1_emb.yaml"))
+    p.add_argument("--options", nargs="+")
+    p.add_argument("--image", default=None, help=".png/.jpg chest X-ray; default: synthetic 448x448 image")
+    p.add_argument("--findings", default="no finding")
+    p.add_argument("--vicuna", default=None, help="local lmsys/vicuna-7b-v1.3 directory (weights + tokenizer)")
+    p.add_argument("--lora_model", default=None, help="adapter dir (adapter_model.bin incl. img_proj_layer)")
+    p.add_argument("--max_new_tokens", type=int, default=300)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    return p.parse_args()
+
+
+def load_image(path):
+    """demo.py:173-218 (remap_to_uint8 -> PIL 'L') + the inference transform (ReportDataset.py:96-106)."""
+    import numpy as np
+    from PIL import Image
+    arr = np.asarray(Image.open(path)).astype(float)
+    arr -= arr.min()
+    arr /= max(arr.max(), 1e-12)
+    img = Image.fromarray((arr * 255).astype(np.uint8)).convert("L")
+    w, h = img.size
+    s = 512 / min(w, h)                                                       # Resize(512): shorter side, bilinear
+    img = img.resize((max(512, round(w * s)), max(512, round(h * s))), Image.BILINEAR)
+    w, h = img.size
+    l, t = (w - 448) // 2, (h - 448) // 2                                     # CenterCrop(448)
+    img = img.crop((l, t, l + 448, t + 448))
+    x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0)[None]     # ToTensor
+    return torch.repeat_interleave(x, 3, dim=0)                               # ExpandChannels
+
+
+def init_blip(cfg):
+    task = tasks.setup_task(cfg)
+    return task.build_model(cfg).to(torch.device("cpu"))
+
+
+def init_vicuna(args):
+    tok = load_tokenizer(args.vicuna)
+    lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16,
+                                                  device_map="auto", max_batch=1, max_len=1024)
+    if args.lora_model:
+        lang_model.load_adapter(args.lora_model)
+    return lang_model.eval(), tok
+
+
+def get_response(blip_model, lang_model, tok, conv, image, findings, max_new_tokens=300):
+    blip_model = blip_model.to(torch.device("cuda"))
+    qformer_embs = blip_model.forward_image(image[None].to(torch.device("cuda")))[0].cpu().detach()
+    blip_model = blip_model.to(torch.device("cpu"))
+    torch.save(qformer_embs, "current_chat_img.pt")                           # the reference's hand-off file (demo.py:273)
+    conv.append_message(conv.roles[0], report_prompt(findings))
+    conv.append_message(conv.roles[1], None)
+    inputs = tok(conv.get_prompt(), return_tensors="pt")
+    out = lang_model.generate(input_ids=inputs["input_ids"], dicom=None, use_img=True, return_dict_in_generate=True,
+                              output_scores=True, max_new_tokens=max_new_tokens)
+    preds = tok.batch_decode(out.sequences, skip_special_tokens=True)
+    new_pred = preds[0].split("ASSISTANT:")[-1]
+    conv.messages.pop()
+    conv.append_message(conv.roles[1], new_pred)
+    return new_pred, out
+
+
+def main():
+    args = parse_args()
+    cfg = Config(args)
+    blip_model = init_blip(cfg).eval()
+    lang_model, tok = init_vicuna(args)
+    image = load_image(args.image) if args.image else synth.synth_images(1, 448)[0]
+    pred, out = get_response(blip_model, lang_model, tok, new_conversation(), image, args.findings, args.max_new_tokens)
+    print(f"generated {out.sequences.shape[1]} ids, {len(out.scores)} steps")
+    print("ASSISTANT:", pred[:400])
+
+
+if __name__ == "__main__":
+    main()

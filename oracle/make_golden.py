@@ -203,9 +203,35 @@ def make_projector():
     print("projector:", pp.shape, emb.shape)
 
 
+def make_prompter():
+    """utils/prompter.py Prompter('vicuna_v11') outputs (the reference resolves data/templates relative to the CWD)."""
+    import json
+    ref = _load("utils/prompter.py", "ref_prompter")
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        pr = ref.Prompter("vicuna_v11")
+    finally:
+        os.chdir(cwd)
+    cases = [("Write a report.", None, None), ("Instruction", "some input", None), ("Q?", None, " label text"),
+             ("A " + "<IMG>" * 32 + " B", "", None)]
+    gold = {"generate_prompt": [[list(c), pr.generate_prompt(*c)] for c in cases],
+            "get_response": [[s, pr.get_response(s)] for s in
+                             ["USER: hi ASSISTANT: hello there ", "x ASSISTANT: a ASSISTANT:  b  ", "no split here"]]}
+    with open(os.path.join(OUT, "prompter.json"), "w") as f:
+        json.dump(gold, f, indent=1)
+    print("prompter:", len(gold["generate_prompt"]), len(gold["get_response"]))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    make_llama()
-    make_qformer()
-    make_projector()
+    which = sys.argv[1:] or ["llama", "qformer", "projector", "prompter"]
+    if "llama" in which:
+        make_llama()
+    if "qformer" in which:
+        make_qformer()
+    if "projector" in which:
+        make_projector()
+    if "prompter" in which:
+        make_prompter()

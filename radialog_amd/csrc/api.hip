@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -78,6 +79,7 @@ struct rdx_ctx {
     int cur_B = 0, cur_T = 0, cur_max_new = 0, cur_eos = -1, cur_pad = 0;
     int32_t* cur_tokens = nullptr;
     hipGraphExec_t graph = nullptr;
+    bool prefetch_weights = true;    // RDX_PREFETCH=0 disables the cache-warming workgroups of decode attention
     GraphKey gkey;
 
     // ---- q-former ----
@@ -178,6 +180,7 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
     rdx_ctx* c = new rdx_ctx();
     c->cfg = *cfg;
     c->device = device_id;
+    if (const char* e = getenv("RDX_PREFETCH")) c->prefetch_weights = atoi(e) != 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail(nullptr, -2, "rdx_create: cannot create stream on device %d", device_id);
@@ -582,7 +585,8 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps;
           skinny(c, a, EPI_NONE); }
         launch_decode_attention(dt, c->ld, c->dqkv, L.lora_bq, L.lora_bv, c->rope_cos, c->rope_sin, c->d_pos, c->d_slot, c->key_mask,
-                                kv_ptr(c, c->kcache, l), kv_ptr(c, c->vcache, l), c->datt, B, s);
+                                kv_ptr(c, c->kcache, l), kv_ptr(c, c->vcache, l), c->datt, B,
+                                c->prefetch_weights ? L.wo.w : nullptr, (size_t)L.wo.Npad * L.wo.K * 2, s);
         { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; skinny(c, a, EPI_RESID); }
         { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps;
           skinny(c, a, EPI_SILU_MUL); }

@@ -77,9 +77,9 @@ template <typename T> __device__ __forceinline__ float swiglu(float gate_acc, fl
 //               the main loop takes its MFMA B operand from LDS (no per-wave redundant norm math, few registers).
 // XLDS = false: activations streamed from global/L2 in fragment order (already normalised by rmsnorm_k if needed).
 template <typename T, int MT, int EPI, bool NORM, int WAVES, bool XLDS>
-__global__ __launch_bounds__(WAVES * 64) void skinny_gemm_k(GemmArgs a) {
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void skinny_gemm_k(GemmArgs a) {
     typedef typename Vec8<T>::type V8;
-    constexpr int U = XLDS ? 8 : 4;
+    constexpr int U = (XLDS && WAVES >= 8) ? 8 : 4;    // 4-wave workgroups stay <= 64 VGPRs: 8 workgroups per CU
     constexpr int NTHR = WAVES * 64;
     __shared__ __attribute__((aligned(16))) float red[WAVES][MT][256];   // [wave][mt][m_local*16 + n_local]
     __shared__ float ssq[WAVES][16];
@@ -276,6 +276,20 @@ template <typename T>
 static void launch_skinny_T(const GemmArgs& a, int epi, hipStream_t s) {
     const bool norm = a.norm_w != nullptr;
     constexpr int WV = 8;
+    // few output tiles (N <= 4096 -> at most one workgroup per CU): 16 waves per workgroup put twice as many
+    // weight loads in flight per CU
+    static const int wide = getenv("RDX_SK_WIDE") ? atoi(getenv("RDX_SK_WIDE")) : 1;
+    if (wide && skinny_fits_lds(a.M, a.K) && (a.N + 15) / 16 <= 256 && a.K >= 4096) {
+        if (norm) launch_skinny_epi<T, 1, true, 16, true>(a, epi, s); else launch_skinny_epi<T, 1, false, 16, true>(a, epi, s);
+        return;
+    }
+    // many output tiles: 4-wave workgroups at <= 64 VGPRs keep up to 2048 tiles resident at once (8 per CU), so the
+    // whole GEMV runs as ONE round of workgroups sharing HBM evenly instead of 2-4 quantised rounds
+    static const int smallwg = getenv("RDX_SK_SMALLWG") ? atoi(getenv("RDX_SK_SMALLWG")) : 1;
+    if (smallwg && skinny_fits_lds(a.M, a.K) && (a.N + 15) / 16 > 512 && (size_t)a.M * a.K * 2 <= 16 * 1024) {
+        if (norm) launch_skinny_epi<T, 1, true, 4, true>(a, epi, s); else launch_skinny_epi<T, 1, false, 4, true>(a, epi, s);
+        return;
+    }
     if (skinny_fits_lds(a.M, a.K)) {
         if (norm) launch_skinny_epi<T, 1, true, WV, true>(a, epi, s); else launch_skinny_epi<T, 1, false, WV, true>(a, epi, s);
     } else if (a.M <= 16) {

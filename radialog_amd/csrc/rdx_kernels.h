@@ -70,7 +70,8 @@ void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, cons
 // decode: LoRA + RoPE + KV append + attention over the cache for one new token per row
 void launch_decode_attention(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,
                              const void* cos_t, const void* sin_t, const int* pos, const int* slot_b,
-                             const uint8_t* key_mask, void* kcache, void* vcache, void* out, int B, hipStream_t s);
+                             const uint8_t* key_mask, void* kcache, void* vcache, void* out, int B, const void* prefetch,
+                             size_t prefetch_bytes, hipStream_t s);
 
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s);
 void launch_layernorm(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* out_f32,

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""test.py -- the reference's batched report-generation loop (test.py:277-373) on the MI355X-native path.
+
+Same flags (`--prompt`, `--lora_model`, `--num_workers`, `--use_embs`, `--num_beams`); batches of 12 left-padded
+prompts, `lang_model.generate(input_ids=..., dicom=dicom_id if use_embs else None, max_new_tokens=300,
+return_dict_in_generate=True, output_scores=True)`, predictions = text after "ASSISTANT:". MIMIC-CXR is credentialed
+data and the NLG/CheXbert metrics need Java and a second conda env, so the dataset is replaced by synthetic studies
+(`--num_samples`) whose image embeddings are produced by the encoder half first (the reference's
+pretraining/train.py evaluate branch) and handed over through the same {dicom: float32[32,768]} mapping.
+With WORLD_SIZE > 1 (torch.distributed.run) the studies are sharded across ranks and predictions all-gathered."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from radialog_amd import synth                                              # noqa: E402
+from radialog_amd.embed_dump import dump_embeddings                         # noqa: E402
+from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM             # noqa: E402
+from radialog_amd.prompter import new_conversation, report_prompt          # noqa: E402
+from radialog_amd.shard import allgather_ragged, shard_range               # noqa: E402
+from radialog_amd.tokenizer import load_tokenizer                          # noqa: E402
+
+
+def main():
+    p = argparse.ArgumentParser()
+    p.add_argument("--prompt", type=str, default="img_matching_examples_ig2_noexamples_IMG_findings")
+    p.add_argument("--lora_model", type=str, default=None)
+    p.add_argument("--num_workers", type=int, default=8)
+    p.add_argument("--use_embs", action="store_true", default=False)
+    p.add_argument("--num_beams", type=int, default=1)
+    p.add_argument("--vicuna", default=None)
+    p.add_argument("--num_samples", type=int, default=24)
+    p.add_argument("--batch_size", type=int, default=12)
+    p.add_argument("--max_new_tokens", type=int, default=300)
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    args = p.parse_args()
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    lo, hi = shard_range(args.num_samples, world, rank)
+    dicoms = [f"synthetic-{i:05d}" for i in range(lo, hi)]
+    tok = load_tokenizer(args.vicuna)
+    lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16,
+                                                  device_map="auto", max_batch=args.batch_size, max_len=1024, device=local)
+    if args.lora_model:
+        lang_model.load_adapter(args.lora_model)
+    lang_model.eval()
+    if args.use_embs:
+        images = synth.synth_images(len(dicoms), 448, seed=1000 + lo)
+        lang_model.model.blip_embeddings.update(dump_embeddings(images, dicoms, dtype=args.dtype, device=local))
+
+    all_preds, all_ids = [], []
+    for s in range(0, len(dicoms), args.batch_size):
+        batch = dicoms[s: s + args.batch_size]
+        texts = []
+        for d in batch:
+            conv = new_conversation()
+            conv.append_message(conv.roles[0], report_prompt("no finding"))
+            conv.append_message(conv.roles[1], None)
+            texts.append(conv.get_prompt())
+        input_ids = tok.batch_encode_plus(texts, return_tensors="pt", padding=True)["input_ids"]
+        out = lang_model.generate(input_ids=input_ids, dicom=batch if args.use_embs else None, return_dict_in_generate=True,
+                                  output_scores=True, max_new_tokens=args.max_new_tokens, num_beams=args.num_beams)
+        preds = tok.batch_decode(out.sequences, skip_special_tokens=True)
+        all_preds.extend([q.split("ASSISTANT:")[1] if "ASSISTANT:" in q else q for q in preds])
+        gen = out.sequences[:, input_ids.shape[1]:]
+        pad = torch.zeros(gen.shape[0], args.max_new_tokens, dtype=torch.int32, device=gen.device)
+        pad[:, : gen.shape[1]] = gen.to(torch.int32)
+        all_ids.append(pad)
+    ids = torch.cat(all_ids, 0)
+    if world > 1:
+        counts = [shard_range(args.num_samples, world, r)[1] - shard_range(args.num_samples, world, r)[0] for r in range(world)]
+        ids = allgather_ragged(ids, counts, world)
+    if rank == 0:
+        print(f"generated {ids.shape[0]} reports x {ids.shape[1]} token slots on {world} GPU(s); first: {all_preds[0][:120]!r}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,49 @@
+"""The reference-shaped Python surface end to end on the GPU (small shapes): Blip2Qformer.forward_image ->
+{dicom: emb} / current_chat_img.pt hand-off -> LlamaForCausalLM.generate -> .sequences / .scores, checked against the
+oracle driven the same way."""
+import os
+
+import pytest
+import torch
+
+from radialog_amd import synth
+from radialog_amd.config import small_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def test_forward_image_then_generate_like_demo_and_test_py(tmp_path, monkeypatch):
+    from oracle import ref_cpu
+    from radialog_amd.blip2_qformer import Blip2Qformer
+    from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM
+    monkeypatch.chdir(tmp_path)
+    cfg = small_cfg()
+    blip = Blip2Qformer(img_size=cfg.vision.img, dtype="f16", cfg=cfg).to(torch.device("cuda")).eval()
+    img = synth.synth_images(2, cfg.vision.img)
+    q, emb = blip.forward_image(img.cuda())
+    assert q.shape == (2, 32, cfg.qformer.hidden) and emb.shape == (2, cfg.vision.n_patches, cfg.vision.proj)
+    assert q.dtype == torch.float32 and q.is_cuda
+
+    lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.float16, cfg=cfg.llama, max_batch=2, max_len=128).eval()
+    # test.py path: embeddings by dicom id
+    lm.model.blip_embeddings.update({"a": q[0].cpu().numpy(), "b": q[1].cpu().numpy()})
+    ids = synth.synth_prompt_ids(2, 48, vocab=cfg.llama.vocab, img_offset=4)
+    ids[1] = torch.cat([torch.zeros(3, dtype=torch.long), ids[1, :45]])
+    out = lm.generate(input_ids=ids, dicom=["a", "b"], return_dict_in_generate=True, output_scores=True, max_new_tokens=6,
+                      eos_token_id=-1)
+    assert out.sequences.shape == (2, 54) and out.sequences.dtype == torch.int64
+    assert torch.equal(out.sequences[:, :48].cpu(), ids)
+    assert len(out.scores) == 6 and out.scores[0].shape == (2, cfg.llama.vocab)
+    # demo.py path: current_chat_img.pt + use_img
+    torch.save(q[:1].cpu(), "current_chat_img.pt")
+    out1 = lm.generate(input_ids=ids[:1], dicom=None, use_img=True, return_dict_in_generate=True, output_scores=True,
+                       max_new_tokens=6, eos_token_id=-1)
+    assert torch.equal(out1.sequences[0], out.sequences[0])
+    # oracle, same weights and the same embeddings
+    W = synth.make_weights(synth.llama_specs(cfg.llama))
+    ref = ref_cpu.LlamaOracle(W, cfg.llama, torch.float16).generate_greedy(ids, q.cpu(), max_new=6, eos_id=-1)
+    same = out.sequences[:, 48:].cpu() == ref["tokens"]
+    assert bool(same.all()) or float(ref["margins"].min()) < 4e-2
+    # plain ids without return_dict
+    seq = lm.generate(input_ids=ids, dicom=["a", "b"], max_new_tokens=2, eos_token_id=-1)
+    assert torch.is_tensor(seq) and seq.shape == (2, 50)

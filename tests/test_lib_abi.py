@@ -1,0 +1,61 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/rdx.h declares; compute entry
+points are not called here (no GPU), but the error path of rdx_create is."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from radialog_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "rdx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rdx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_table_agree():
+    assert _declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in _declared_symbols():
+        assert hasattr(lib, name), f"librdx.so does not export {name}"
+
+
+def test_config_struct_matches_header_field_count():
+    text = open(os.path.join(REPO, "include", "rdx.h")).read()
+    body = text[text.index("typedef struct rdx_config {"): text.index("} rdx_config;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    n_fields = 0
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if decl:
+            n_fields += decl.count(",") + 1
+    assert n_fields == len(_lib.RdxConfig._fields_)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="error path of a GPU-less host")
+def test_create_fails_loudly_without_gpu():
+    lib = _lib.load()
+    ctx = C.c_void_p()
+    cfg = _lib.RdxConfig()
+    rc = lib.rdx_create(C.byref(ctx), 0, C.byref(cfg))
+    assert rc != 0 and not ctx.value
+    assert b"rdx_create" in lib.rdx_last_error(None)
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="error path of a GPU-less host")
+def test_engine_has_no_cpu_fallback():
+    from radialog_amd.config import small_cfg
+    from radialog_amd.engine import RdxEngine
+    with pytest.raises(_lib.RdxError):
+        RdxEngine(small_cfg(), dtype="f16")
+    from radialog_amd.blip2_qformer import Blip2Qformer
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        Blip2Qformer().forward_image(torch.zeros(1, 3, 448, 448))
