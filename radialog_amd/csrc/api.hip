@@ -79,7 +79,8 @@ struct rdx_ctx {
     int cur_B = 0, cur_T = 0, cur_max_new = 0, cur_eos = -1, cur_pad = 0;
     int32_t* cur_tokens = nullptr;
     hipGraphExec_t graph = nullptr;
-    bool prefetch_weights = true;    // RDX_PREFETCH=0 disables the cache-warming workgroups of decode attention
+    bool fuse_attn_oproj = false;    // RDX_FUSE_AO=1: attention + o_proj in one launch with a flag hand-off (measured: no gain at B=1)
+    int *d_ctr = nullptr, *d_err = nullptr;   // per-layer hand-off counters of the fused launch, sticky error flag
     GraphKey gkey;
 
     // ---- q-former ----
@@ -180,7 +181,7 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
     rdx_ctx* c = new rdx_ctx();
     c->cfg = *cfg;
     c->device = device_id;
-    if (const char* e = getenv("RDX_PREFETCH")) c->prefetch_weights = atoi(e) != 0;
+    if (const char* e = getenv("RDX_FUSE_AO")) c->fuse_attn_oproj = atoi(e) != 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail(nullptr, -2, "rdx_create: cannot create stream on device %d", device_id);
@@ -320,6 +321,9 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         ALLOC(c, c->key_mask, (size_t)B * f.max_len);
         ALLOC(c, c->d_img_pos, B * sizeof(int)); ALLOC(c, c->d_pos, B * sizeof(int)); ALLOC(c, c->d_slot, B * sizeof(int));
         ALLOC(c, c->d_step, B * sizeof(int)); ALLOC(c, c->d_unf, B * sizeof(int));
+        ALLOC(c, c->d_ctr, f.layers * sizeof(int)); ALLOC(c, c->d_err, sizeof(int));
+        HIPCHK(c, hipMemset(c->d_ctr, 0, f.layers * sizeof(int)));
+        HIPCHK(c, hipMemset(c->d_err, 0, sizeof(int)));
         ALLOC(c, c->d_pos_ids, (size_t)B * f.max_len * sizeof(int));
         c->n_vtiles = c->lm_head.Npad / 16;
         ALLOC(c, c->part_val, (size_t)B * c->n_vtiles * sizeof(float));
@@ -580,14 +584,23 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
     const rdx_config& f = c->cfg;
     const int dt = f.dtype, H = f.hidden, B = c->cur_B;
     hipStream_t s = c->stream;
+    if (c->fuse_attn_oproj) hipMemsetAsync(c->d_ctr, 0, (size_t)f.layers * sizeof(int), s);   // hand-off counters, once per step
     for (int l = 0; l < f.layers; ++l) {
         const LlamaLayer& L = c->ll[l];
         { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps;
           skinny(c, a, EPI_NONE); }
-        launch_decode_attention(dt, c->ld, c->dqkv, L.lora_bq, L.lora_bv, c->rope_cos, c->rope_sin, c->d_pos, c->d_slot, c->key_mask,
-                                kv_ptr(c, c->kcache, l), kv_ptr(c, c->vcache, l), c->datt, B,
-                                c->prefetch_weights ? L.wo.w : nullptr, (size_t)L.wo.Npad * L.wo.K * 2, s);
-        { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; skinny(c, a, EPI_RESID); }
+        DecAttnArgs at;
+        at.d = c->ld; at.qkv = c->dqkv; at.lbq = L.lora_bq; at.lbv = L.lora_bv; at.cos_t = c->rope_cos; at.sin_t = c->rope_sin;
+        at.pos = c->d_pos; at.slot_b = c->d_slot; at.key_mask = c->key_mask;
+        at.kcache = kv_ptr(c, c->kcache, l); at.vcache = kv_ptr(c, c->vcache, l); at.out = c->datt;
+        GemmArgs ao = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B);
+        ao.resid = c->dx; ao.ldr = H;
+        if (c->fuse_attn_oproj && (L.wo.N + 15) / 16 <= 256) {
+            launch_attn_oproj(dt, at, ao, B, c->d_ctr + l, c->d_err, s);
+        } else {
+            launch_decode_attention(dt, at, B, s);
+            skinny(c, ao, EPI_RESID);
+        }
         { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps;
           skinny(c, a, EPI_SILU_MUL); }
         { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; skinny(c, a, EPI_RESID); }
@@ -657,6 +670,12 @@ extern "C" int rdx_generate(rdx_ctx* c, const int32_t* ids, const int32_t* mask,
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     if (n_steps_host) *n_steps_host = done;
+    int herr = 0;
+    HIPCHK(c, hipMemcpy(&herr, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (herr) {
+        hipMemset(c->d_err, 0, sizeof(int));
+        return fail(c, -5, "rdx_generate: attention->o_proj hand-off timed out inside the fused launch (results invalid)");
+    }
     return 0;
 }
 
@@ -682,6 +701,8 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
     HIPCHK(c, hipSetDevice(c->device));
     const rdx_config& f = c->cfg;
     const int dt = f.dtype, H = f.hidden, B = c->cur_B;
+    const bool same_layer = what >= 10;   // what = 10 + k: unit k on layer 0 only (weights stay cache resident)
+    if (same_layer) what -= 10;
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
@@ -710,7 +731,7 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
                 continue;
             }
             for (int l = 0; l < f.layers; ++l) {
-                const LlamaLayer& L = c->ll[l];
+                const LlamaLayer& L = c->ll[same_layer ? 0 : l];
                 if (what == 1) { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; skinny(c, a, EPI_SILU_MUL); }
                 else if (what == 2) { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps; skinny(c, a, EPI_NONE); }
                 else if (what == 3) { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dqkv, H, B); skinny(c, a, EPI_NONE); }

@@ -12,6 +12,7 @@
 //                        wavefront-shuffle reductions for the dot products and the softmax.
 #include "rdx_common.h"
 #include "rdx_kernels.h"
+#include "attn_body.h"
 
 namespace rdx {
 
@@ -160,12 +161,6 @@ __device__ __forceinline__ float lora_delta(const T* Bm, int n, const T* avec, i
 }
 
 template <typename T>
-__device__ __forceinline__ float rope_one(float x, float partner_signed, float c, float s) {
-    // (x * cos) + (rotate_half(x) * sin), every op rounded to the model dtype
-    return rnd<T>(rnd<T>(x * c) + rnd<T>(partner_signed * s));
-}
-
-template <typename T>
 __global__ __launch_bounds__(256) void rope_kv_prefill_k(LlamaDims d, const T* __restrict__ qkv, const T* __restrict__ lbq,
                                                          const T* __restrict__ lbv, const T* __restrict__ cos_t,
                                                          const T* __restrict__ sin_t, const int* __restrict__ pos_ids,
@@ -217,231 +212,20 @@ void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, cons
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// decode attention (head_dim 128; 16 lanes x 16 B cover one K/V cache row)
+// decode attention (body in attn_body.h)
 // ------------------------------------------------------------------------------------------------------------------
-// One workgroup of 16 waves per (head, batch row). The cache is small per head (L x 256 B for K and for V), so the
-// kernel is latency-bound and is organised to have only two workgroup barriers:
-//   * every lane issues ALL its K and V row loads up front (position j -> 16 lanes; DA_PRE x 64 = 512 positions are
-//     prefetched in registers, later positions by a second, plain loop);
-//   * the new token's LoRA add + RoPE is done redundantly by every wave in registers (lane (jsub, doct) owns dims
-//     doct*8..+8; the rotate-half partner d+-64 lives in lane^8), so no LDS hand-off is needed for q / k_new / v_new;
-//   * scores go to LDS once; each wave then recomputes the softmax statistics itself (wave shuffles, no block
-//     reduction) and applies the rounded probabilities to its V registers.
-// Workgroups with blockIdx.x >= heads (optional) only touch the NEXT GEMV's weights so that they are cache resident
-// (the 224 CUs that attention leaves idle at batch 1 pull the o_proj panel towards L2 / Infinity Cache) -- a pure
-// performance hint with no data dependence.
 constexpr int DA_WAVES = 16;
-constexpr int DA_PRE = 8;                     // prefetched (K,V) rows per lane
-constexpr int DA_SPAN = DA_WAVES * 4;         // positions covered by one block-wide load
 
 template <typename T>
-__global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_k(LlamaDims d, const T* __restrict__ qkv,
-                                                                   const T* __restrict__ lbq, const T* __restrict__ lbv,
-                                                                   const T* __restrict__ cos_t, const T* __restrict__ sin_t,
-                                                                   const int* __restrict__ pos, const int* __restrict__ slot_b,
-                                                                   const uint8_t* __restrict__ key_mask, T* __restrict__ kcache,
-                                                                   T* __restrict__ vcache, T* __restrict__ out,
-                                                                   const u4* __restrict__ pf_ptr, size_t pf_vec16) {
-    typedef typename Vec8<T>::type V8;
-    constexpr int D = 128;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if ((int)blockIdx.x >= d.heads) {
-        // cache-warming role
-        if (blockIdx.y != 0 || pf_ptr == nullptr) return;
-        const size_t nb = gridDim.x - d.heads, me = blockIdx.x - d.heads;
-        unsigned keep = 0;
-        for (size_t i = me * blockDim.x + tid; i < pf_vec16; i += nb * blockDim.x) {
-            const u4 v = ldg16(pf_ptr + i);
-            keep ^= v[0];
-        }
-        asm volatile("" ::"v"(keep));
-        return;
-    }
+__global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_k(DecAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
-    float* part = dsm;                    // [DA_WAVES][D]
-    float* qf = dsm + DA_WAVES * D;       // [D] rotated query
-    float* S = dsm + DA_WAVES * D + D;    // [max_len]
-
-    const int h = blockIdx.x, b = blockIdx.y;
-    const int jsub = lane >> 4, doct = lane & 15;
-    const int H = d.hidden;
-    const int slot = slot_b[b];
-    const int nk = slot + 1;
-    const T* x = qkv + (size_t)b * d.qkv_ld;
-    T* kc = kcache + ((size_t)b * d.heads + h) * d.max_len * D;
-    T* vc = vcache + ((size_t)b * d.heads + h) * d.max_len * D;
-    const uint8_t* km = key_mask + (size_t)b * d.max_len;
-
-    // ---- all cached K and V rows of this lane in flight first ----------------------------------------------------
-    u4 kr[DA_PRE], vr[DA_PRE];
-#pragma unroll
-    for (int u = 0; u < DA_PRE; ++u) {
-        const int j = u * DA_SPAN + w * 4 + jsub;
-        const int jc = j < slot ? j : 0;                       // clamped: unconditional loads, unused when j >= slot
-        kr[u] = ldg16(kc + (size_t)jc * D + doct * 8);
-    }
-
-    // ---- new token (wave 0 only, in registers): LoRA add + RoPE for dims doct*8 .. +8 of this head -------------------
-    // lane (jsub, doct) owns 8 dims; the rotate-half partner d+-64 lives in lane^8. q goes to LDS for everybody,
-    // k_new / v_new stay in wave 0's registers (it also handles the score / PV term of the new position itself).
-    float k8[8], v8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { k8[e] = 0.f; v8[e] = 0.f; }
-    if (w == 0) {
-        const int n0 = h * D + doct * 8;
-        float q8n[8];
-        const V8 qv = as_vec8<T>(ldg16(x + n0)), kv = as_vec8<T>(ldg16(x + H + n0)), vv = as_vec8<T>(ldg16(x + 2 * H + n0));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { q8n[e] = tof<T>(qv[e]); k8[e] = tof<T>(kv[e]); v8[e] = tof<T>(vv[e]); }
-        if (d.lora_r == 8) {
-            const V8 aq = as_vec8<T>(ldg16(x + 3 * H)), av = as_vec8<T>(ldg16(x + 3 * H + 8));
-#pragma unroll 2
-            for (int e = 0; e < 8; ++e) {                        // partial unroll: stays inside the 128-VGPR budget
-                const V8 bq = as_vec8<T>(ldg16(lbq + (size_t)(n0 + e) * 8)), bv = as_vec8<T>(ldg16(lbv + (size_t)(n0 + e) * 8));
-                float sq = 0.f, sv = 0.f;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) { sq += tof<T>(bq[i]) * tof<T>(aq[i]); sv += tof<T>(bv[i]) * tof<T>(av[i]); }
-                q8n[e] = rnd<T>(q8n[e] + rnd<T>(rnd<T>(sq) * d.lora_scale));   // result += lora_B(lora_A(x)) * scaling
-                v8[e] = rnd<T>(v8[e] + rnd<T>(rnd<T>(sv) * d.lora_scale));
-            }
-        }
-        const int p = pos[b];
-        const V8 cv = as_vec8<T>(ldg16(cos_t + (size_t)p * D + doct * 8)), sv_ = as_vec8<T>(ldg16(sin_t + (size_t)p * D + doct * 8));
-        const bool lo = doct < 8;                                               // dims < 64: rotate_half gives -x[d+64]
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float qo = __shfl_xor(q8n[e], 8, 64), ko = __shfl_xor(k8[e], 8, 64);
-            const float c = tof<T>(cv[e]), sn = tof<T>(sv_[e]);
-            q8n[e] = rope_one<T>(q8n[e], lo ? -qo : qo, c, sn);
-            k8[e] = rope_one<T>(k8[e], lo ? -ko : ko, c, sn);
-        }
-        if (jsub == 0) {                                                        // publish q, append k / v to the cache
-            V8 ko, vo;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { qf[doct * 8 + e] = q8n[e]; ko[e] = fromf<T>(k8[e]); vo[e] = fromf<T>(v8[e]); }
-            stg16(kc + (size_t)slot * D + doct * 8, as_u4<T>(ko));
-            stg16(vc + (size_t)slot * D + doct * 8, as_u4<T>(vo));
-        }
-    }
-
-    // V rows go in flight now (their latency hides under the scores and the softmax)
-#pragma unroll
-    for (int u = 0; u < DA_PRE; ++u) {
-        const int j = u * DA_SPAN + w * 4 + jsub;
-        const int jc = j < slot ? j : 0;
-        vr[u] = ldg16(vc + (size_t)jc * D + doct * 8);
-    }
-
-    __syncthreads();
-    float q8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) q8[e] = qf[doct * 8 + e];
-
-    // ---- scores ---------------------------------------------------------------------------------------------------------
-    const float div = sqrtf((float)D);
-    auto score_store = [&](int j, float acc) {
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (doct == 0 && j < nk) {
-            const float sc = rnd<T>(rnd<T>(acc) / div);
-            S[j] = km[j] ? sc : -INFINITY;
-        }
-    };
-#pragma unroll
-    for (int u = 0; u < DA_PRE; ++u) {
-        const int j = u * DA_SPAN + w * 4 + jsub;
-        float acc = 0.f;
-        if (j < slot) {
-            const V8 kv = as_vec8<T>(kr[u]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += q8[e] * tof<T>(kv[e]);
-        }
-        score_store(j < slot ? j : nk, acc);                                    // one wave-wide call (shuffles inside)
-    }
-    if (w == 0) {                                                               // the new position itself
-        float acc = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc += q8[e] * k8[e];
-        score_store(jsub == 0 ? slot : nk, acc);
-    }
-    for (int j0 = DA_PRE * DA_SPAN; j0 < slot; j0 += DA_SPAN) {        // contexts beyond the prefetch window
-        const int j = j0 + w * 4 + jsub;
-        float acc = 0.f;
-        if (j < slot) {
-            const V8 kv = as_vec8<T>(ldg16(kc + (size_t)j * D + doct * 8));
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += q8[e] * tof<T>(kv[e]);
-        }
-        score_store(j < slot ? j : nk, acc);
-    }
-    __syncthreads();
-
-    // ---- softmax statistics (fp32), recomputed by every wave -------------------------------------------------------
-    float mx = -INFINITY;
-    for (int j = lane; j < nk; j += 64) mx = fmaxf(mx, S[j]);
-    mx = wave_max(mx);
-    float sum = 0.f;
-    for (int j = lane; j < nk; j += 64) sum += expf(S[j] - mx);
-    sum = wave_sum(sum);
-
-    // ---- O = P V with P rounded to T ---------------------------------------------------------------------------------
-    float o8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o8[e] = 0.f;
-#pragma unroll
-    for (int u = 0; u < DA_PRE; ++u) {
-        const int j = u * DA_SPAN + w * 4 + jsub;
-        if (j < slot) {
-            const float p = rnd<T>(expf(S[j] - mx) / sum);
-            const V8 vv = as_vec8<T>(vr[u]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] += p * tof<T>(vv[e]);
-        }
-    }
-    if (w == 0 && jsub == 0) {
-        const float p = rnd<T>(expf(S[slot] - mx) / sum);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o8[e] += p * v8[e];
-    }
-    for (int j0 = DA_PRE * DA_SPAN; j0 < slot; j0 += DA_SPAN) {
-        const int j = j0 + w * 4 + jsub;
-        if (j < slot) {
-            const float p = rnd<T>(expf(S[j] - mx) / sum);
-            const V8 vv = as_vec8<T>(ldg16(vc + (size_t)j * D + doct * 8));
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] += p * tof<T>(vv[e]);
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        o8[e] += __shfl_xor(o8[e], 16, 64);
-        o8[e] += __shfl_xor(o8[e], 32, 64);
-    }
-    if (jsub == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) part[w * D + doct * 8 + e] = o8[e];
-    }
-    __syncthreads();
-    if (tid < D) {
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < DA_WAVES; ++i) v += part[i * D + tid];
-        out[(size_t)b * H + h * D + tid] = fromf<T>(v);
-    }
+    decode_attention_body<T, DA_WAVES>(a, blockIdx.x, blockIdx.y, dsm);
 }
 
-void launch_decode_attention(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,
-                             const void* cos_t, const void* sin_t, const int* pos, const int* slot_b,
-                             const uint8_t* key_mask, void* kcache, void* vcache, void* out, int B, const void* prefetch,
-                             size_t prefetch_bytes, hipStream_t s) {
-    // at small batch the attention grid leaves most CUs idle: give them the cache-warming role
-    const int extra = (prefetch && B * d.heads < 256) ? (256 - B * d.heads > 224 ? 224 : 256 - B * d.heads) : 0;
-    dim3 grid(d.heads + extra, B), block(DA_WAVES * 64);
-    const size_t smem = (size_t)(DA_WAVES * 128 + 128 + d.max_len) * sizeof(float);
-    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T>), grid, block, smem, s, d, (const T*)qkv,
-                                                (const T*)lora_bq, (const T*)lora_bv, (const T*)cos_t, (const T*)sin_t, pos,
-                                                slot_b, key_mask, (T*)kcache, (T*)vcache, (T*)out, (const u4*)prefetch,
-                                                prefetch_bytes / 16));
+void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s) {
+    dim3 grid(a.d.heads, B), block(DA_WAVES * 64);
+    const size_t smem = decode_attention_smem_floats(DA_WAVES, a.d.max_len) * sizeof(float);
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T>), grid, block, smem, s, a));
 }
 
 }  // namespace rdx

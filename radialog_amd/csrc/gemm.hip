@@ -18,6 +18,7 @@
 //                 on the fly from an NHWC tensor (torchvision Bottleneck convs behind biovil_t/resnet.py:34-42).
 #include "rdx_common.h"
 #include "rdx_kernels.h"
+#include "skinny_body.h"
 
 namespace rdx {
 
@@ -58,197 +59,12 @@ void launch_pack_weight(int dtype, const float* src, void* dst, int N, int K, in
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// shared epilogue math (rounding points follow the reference's fp16/bf16 op sequence, see oracle/ref_cpu.py)
+// skinny GEMM (body in skinny_body.h)
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ float swiglu(float gate_acc, float up_acc) {
-    const float gt = rnd<T>(gate_acc), up = rnd<T>(up_acc);   // gate_proj(x), up_proj(x) as model-dtype tensors
-    const float s = rnd<T>(silu(gt));                          // act_fn output rounded
-    return s * up;                                             // product rounded by the caller's store
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// skinny GEMM
-// ------------------------------------------------------------------------------------------------------------------
-// One workgroup = one 16-column output tile; its WAVES waves split K. Each wave streams its K slice of the packed tile
-// (1 KiB per wave-instruction, non-temporal) in register batches of U blocks, the next batch always in flight while
-// the current one is multiplied; the first batch is issued BEFORE the RMSNorm prologue so HBM latency overlaps it.
-// All weight loads are unconditional (addresses clamped inside the slice) so the compiler can hoist a whole batch.
-// XLDS = true : M*K activations fit in LDS -> the workgroup normalises (optional fused RMSNorm) and stages x-hat once,
-//               the main loop takes its MFMA B operand from LDS (no per-wave redundant norm math, few registers).
-// XLDS = false: activations streamed from global/L2 in fragment order (already normalised by rmsnorm_k if needed).
 template <typename T, int MT, int EPI, bool NORM, int WAVES, bool XLDS>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void skinny_gemm_k(GemmArgs a) {
-    typedef typename Vec8<T>::type V8;
-    constexpr int U = (XLDS && WAVES >= 8) ? 8 : 4;    // 4-wave workgroups stay <= 64 VGPRs: 8 workgroups per CU
-    constexpr int NTHR = WAVES * 64;
-    __shared__ __attribute__((aligned(16))) float red[WAVES][MT][256];   // [wave][mt][m_local*16 + n_local]
-    __shared__ float ssq[WAVES][16];
-    __shared__ float rstd_s[16];
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-    T* xs = reinterpret_cast<T*>(dyn_smem);                              // XLDS: [M][K] x-hat
-
-    // wave id made provably wave-uniform (SGPR): K-slice bounds become scalar, and no MFMA ends up under an
-    // EXEC-masked per-lane branch (MFMA ignores EXEC -- a masked-off MFMA would still accumulate)
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 15, g = lane >> 4;
-    const int K = a.K, KC = K >> 5;
-    const int c0 = (KC * w) / WAVES, c1 = (KC * (w + 1)) / WAVES;
-    const T* X = reinterpret_cast<const T*>(a.X);
-    const u4* wbase = reinterpret_cast<const u4*>(a.W) + (size_t)blockIdx.x * KC * 64 + lane;
-    const int clast = min(max(c1 - 1, c0), KC - 1);
-
-    // two weight batches in flight before anything else (HBM latency overlaps the prologue)
-    u4 wv[U], wn[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) wv[u] = ldg16_nt(wbase + (size_t)min(c0 + u, clast) * 64);
-#pragma unroll
-    for (int u = 0; u < U; ++u) wn[u] = wv[u];
-    if (c0 + U < c1) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) wn[u] = ldg16_nt(wbase + (size_t)min(c0 + U + u, clast) * 64);
-    }
-
-    if (XLDS) {
-        const int K8 = K >> 3;
-        if (NORM) {
-            // LlamaRMSNorm (:85-93): fp32 mean of squares per row
-            for (int m = 0; m < a.M; ++m) {
-                float ss = 0.f;
-                for (int k8 = threadIdx.x; k8 < K8; k8 += NTHR) {
-                    V8 xv = as_vec8<T>(ldg16(X + (size_t)m * a.ldx + (size_t)k8 * 8));
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { const float f = tof<T>(xv[j]); ss += f * f; }
-                }
-                ss = wave_sum(ss);
-                if (lane == 0) ssq[w][m] = ss;
-            }
-            __syncthreads();
-            if (threadIdx.x < a.M) {
-                float t = 0.f;
-#pragma unroll
-                for (int i = 0; i < WAVES; ++i) t += ssq[i][threadIdx.x];
-                rstd_s[threadIdx.x] = rsqrtf(t / (float)K + a.eps);
-            }
-            __syncthreads();
-        }
-        const T* NW = reinterpret_cast<const T*>(a.norm_w);
-        const int total8 = a.M * K8;
-        for (int i = threadIdx.x; i < total8; i += NTHR) {
-            const int m = i / K8, k8 = i - m * K8;
-            V8 xv = as_vec8<T>(ldg16(X + (size_t)m * a.ldx + (size_t)k8 * 8));
-            if (NORM) {
-                const float rs = rstd_s[m];
-                V8 nw = as_vec8<T>(ldg16(NW + (size_t)k8 * 8));
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float h = rnd<T>(tof<T>(xv[j]) * rs);      // (x * rsqrt(var+eps)).to(dtype)
-                    xv[j] = fromf<T>(tof<T>(nw[j]) * h);             // weight * hidden  (dtype mult)
-                }
-            }
-            *reinterpret_cast<u4*>(xs + (size_t)m * K + (size_t)k8 * 8) = as_u4<T>(xv);
-        }
-        __syncthreads();
-    }
-
-    const T* xrow[MT];
-    bool xok[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = mt * 16 + r;
-        xok[mt] = m < a.M;
-        xrow[mt] = XLDS ? (xs + (size_t)(xok[mt] ? m : 0) * K + g * 8) : (X + (size_t)(xok[mt] ? m : 0) * a.ldx + g * 8);
-    }
-
-    v4f acc[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-    for (int cb = c0; cb < c1; cb += U) {
-        u4 xr[U][MT];
-        if (!XLDS) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = min(cb + u, clast);
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    xr[u][mt] = xok[mt] ? ldg16(xrow[mt] + (size_t)c * 32) : (u4){0u, 0u, 0u, 0u};
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (cb + u < c1) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    u4 xv;
-                    if (XLDS) xv = xok[mt] ? *reinterpret_cast<const u4*>(xrow[mt] + (size_t)(cb + u) * 32) : (u4){0u, 0u, 0u, 0u};
-                    else xv = xr[u][mt];
-                    acc[mt] = mfma16(as_vec8<T>(wv[u]), as_vec8<T>(xv), acc[mt]);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) wv[u] = wn[u];
-        if (cb + 2 * U < c1) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) wn[u] = ldg16_nt(wbase + (size_t)min(cb + 2 * U + u, clast) * 64);
-        }
-    }
-    // D[i = n_local = g*4+reg][j = m_local = r]  ->  red[w][mt][m_local*16 + n_local]
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-        *reinterpret_cast<float4*>(&red[w][mt][r * 16 + g * 4]) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
-    __syncthreads();
-
-    const int t = threadIdx.x;
-    constexpr int NOUT = MT * 256;
-    for (int o = t; o < NOUT; o += WAVES * 64) {
-    const int mt = o >> 8, idx = o & 255, m_local = idx >> 4, n_local = idx & 15;
-    const int m = mt * 16 + m_local;
-    const int n = blockIdx.x * 16 + n_local;
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < WAVES; ++i) v += red[i][mt][idx];
-    if (a.bias && n < a.N) v += a.bias[n];
-    T* out = reinterpret_cast<T*>(a.out);
-    if (a.out_step && out) out += (size_t)(*a.out_step) * a.out_step_stride;
-    const bool ok = (m < a.M) && (n < a.N);
-
-    if (EPI == EPI_NONE) {
-        if (ok) out[(size_t)m * a.ldo + n] = fromf<T>(v);
-    } else if (EPI == EPI_RELU) {
-        if (ok) out[(size_t)m * a.ldo + n] = fromf<T>(fmaxf(v, 0.f));
-    } else if (EPI == EPI_GELU) {
-        if (ok) out[(size_t)m * a.ldo + n] = fromf<T>(gelu_erf(v));
-    } else if (EPI == EPI_RESID) {
-        if (ok) {
-            const float rsd = tof<T>(reinterpret_cast<const T*>(a.resid)[(size_t)m * a.ldr + n]);
-            out[(size_t)m * a.ldo + n] = fromf<T>(rsd + rnd<T>(v));
-        }
-    } else if (EPI == EPI_SILU_MUL) {
-        // rows of a tile: 0..7 = gate_proj rows 8t..8t+7, 8..15 = up_proj rows 8t..8t+7
-        float u = 0.f;
-#pragma unroll
-        for (int i = 0; i < WAVES; ++i) u += red[i][mt][(idx + 8) & 255];
-        if (n_local < 8 && ok) out[(size_t)m * a.ldo + blockIdx.x * 8 + n_local] = fromf<T>(swiglu<T>(v, u));
-    } else if (EPI == EPI_LOGITS) {
-        float lv = rnd<T>(v);
-        int li = n;
-        const bool valid = n < a.n_valid;
-        if (valid && m < a.M && out) out[(size_t)m * a.ldo + n] = fromf<T>(lv);
-        if (!valid) { lv = -INFINITY; li = 0x7fffffff; }
-        // argmax over the tile's 16 columns (16 consecutive lanes share m); ties -> lowest index (torch.argmax)
-#pragma unroll
-        for (int sh = 8; sh > 0; sh >>= 1) {
-            const float ov = __shfl_xor(lv, sh, 64);
-            const int oi = __shfl_xor(li, sh, 64);
-            if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
-        }
-        if (n_local == 0 && m < a.M) {
-            a.part_val[(size_t)m * gridDim.x + blockIdx.x] = lv;
-            a.part_idx[(size_t)m * gridDim.x + blockIdx.x] = li;
-        }
-    }
-    }
+    skinny_tile<T, MT, EPI, NORM, WAVES, XLDS>(a, blockIdx.x, gridDim.x, dyn_smem, NoWait());
 }
 
 template <typename T, int MT, bool NORM, int WAVES, bool XLDS>

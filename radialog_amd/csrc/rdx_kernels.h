@@ -68,10 +68,18 @@ void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, cons
                             const void* cos_t, const void* sin_t, const int* pos_ids, void* qout, void* kcache,
                             void* vcache, int B, int T, hipStream_t s);
 // decode: LoRA + RoPE + KV append + attention over the cache for one new token per row
-void launch_decode_attention(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,
-                             const void* cos_t, const void* sin_t, const int* pos, const int* slot_b,
-                             const uint8_t* key_mask, void* kcache, void* vcache, void* out, int B, const void* prefetch,
-                             size_t prefetch_bytes, hipStream_t s);
+struct DecAttnArgs {
+    LlamaDims d;
+    const void *qkv, *lbq, *lbv, *cos_t, *sin_t;
+    const int *pos, *slot_b;
+    const uint8_t* key_mask;
+    void *kcache, *vcache, *out;
+};
+void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s);
+// decode attention + o_proj(+residual) in ONE launch: the o_proj tile workgroups put their weights in flight
+// immediately and wait on `counter` (agent-scope release/acquire hand-off) for the heads*B attention workgroups.
+// `counter` must be zero at launch; `err` is set to 1 if a wait ever times out (never hangs).
+void launch_attn_oproj(int dtype, const DecAttnArgs& a, const GemmArgs& g, int B, int* counter, int* err, hipStream_t s);
 
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s);
 void launch_layernorm(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* out_f32,

@@ -143,3 +143,23 @@ def test_eos_and_padding_rule(engine, cfg, cpu_w):
     if float(ref["margins"].min()) > 4 * LOGIT_TOL[engine.dtype]:
         assert torch.equal(toks[:, :nref], ref["tokens"])
         assert int(toks[0, 3:].abs().sum()) == 0      # row 0 finished at step 2 -> pads afterwards
+
+
+def test_fused_attention_oproj_launch_matches_oracle(cfg, cpu_w, monkeypatch):
+    """RDX_FUSE_AO=1: decode attention and o_proj in ONE launch with an agent-scope release/acquire hand-off
+    (csrc/fused.hip). Off by default (no speed-up at batch 1); must still be exact."""
+    from oracle import ref_cpu
+    from radialog_amd.engine import RdxEngine, synth_getter
+    monkeypatch.setenv("RDX_FUSE_AO", "1")
+    eng = RdxEngine(cfg, dtype="f16", device=0, max_batch=4, max_len=256, lora=True, vision=False)
+    eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+    B, T, N = 3, 72, 24
+    ids = _prompt(cfg, B, T, seed=33)
+    qf = synth.synth("t.qf2", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    with torch.no_grad():
+        ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, torch.float16, lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1)
+    for use_graph in (False, True):
+        toks, _, n = eng.generate(ids, qf, max_new=N, eos_id=-1, use_graph=use_graph)
+        same = toks.cpu().long() == ref["tokens"]
+        assert bool(same.all()) or float(ref["margins"].min()) < 4e-2
+    eng.close()
