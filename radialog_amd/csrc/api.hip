@@ -81,6 +81,8 @@ struct rdx_ctx {
     hipGraphExec_t graph = nullptr;
     bool fuse_attn_oproj = false;    // RDX_FUSE_AO=1: attention + o_proj in one launch with a flag hand-off (measured: no gain at B=1)
     int *d_ctr = nullptr, *d_err = nullptr;   // per-layer hand-off counters of the fused launch, sticky error flag
+    bool use_dma_gemm = true;        // RDX_DMA=0: route every large-M GEMM through tiled_gemm_k
+    float* gemm_ws = nullptr; size_t gemm_ws_floats = 0;      // split-K slabs of gemm_dma_k
     GraphKey gkey;
 
     // ---- q-former ----
@@ -150,6 +152,7 @@ static void run_gemm(rdx_ctx* c, GemmArgs a, int epi) {
     ConvGeom cg;
     memset(&cg, 0, sizeof(cg));
     if (a.M <= 32) skinny(c, a, epi == EPI_RESID_RELU ? EPI_RESID : epi);
+    else if (c->use_dma_gemm && gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
     else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
 }
 
@@ -182,10 +185,14 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
     c->cfg = *cfg;
     c->device = device_id;
     if (const char* e = getenv("RDX_FUSE_AO")) c->fuse_attn_oproj = atoi(e) != 0;
+    if (const char* e = getenv("RDX_DMA")) c->use_dma_gemm = atoi(e) != 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail(nullptr, -2, "rdx_create: cannot create stream on device %d", device_id);
     }
+    c->gemm_ws_floats = (size_t)16 << 20;          // 64 MiB of fp32 split-K slabs
+    if (hipMalloc((void**)&c->gemm_ws, c->gemm_ws_floats * sizeof(float)) != hipSuccess) { c->gemm_ws = nullptr; c->gemm_ws_floats = 0; }
+    else c->allocs.push_back(c->gemm_ws);
     *out = c;
     return 0;
 }
@@ -417,8 +424,9 @@ static void conv_gemm(rdx_ctx* c, const void* X, const GemmW& W, const float* bi
     cg.mode = 1; cg.Hin = Hin; cg.Win = Win; cg.Cin = Cin; cg.Hout = Hout; cg.Wout = Wout;
     cg.KH = KH; cg.KW = KW; cg.stride = stride; cg.pad = pad;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) cg.mode = 0;
-    // conv GEMMs always have M >= 16 rows of real work; route everything through the tiled kernel (gather support)
-    launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
+    // 1x1 stride-1 convolutions are plain GEMMs; everything else needs the gather path of the tiled kernel
+    if (cg.mode == 0 && c->use_dma_gemm && gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
+    else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
 }
 
 extern "C" int rdx_encode_image(rdx_ctx* c, const float* image, int B, float* qformer_out, float* image_embeds) {
@@ -784,7 +792,12 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
         }
         ConvGeom cg;
         memset(&cg, 0, sizeof(cg));
-        launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
+        if (force == 3 || (force == 0 && c->use_dma_gemm && gemm_dma_supported(a))) {
+            if (!gemm_dma_supported(a)) { hipFree(wp); if (xn) hipFree(xn); return fail(c, -1, "rdx_gemm_test: shape not supported by gemm_dma_k"); }
+            launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
+        } else {
+            launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
+        }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());

@@ -1,0 +1,244 @@
+// Large-M MFMA GEMM with LDS-DMA staging (gfx950):  out[M,N] = epilogue(X[M,K] . W[N,K]^T),  K % 64 == 0.
+//
+// Used for the Llama prefill GEMMs, the 1x1 convolutions of the ResNet trunk / projector and the Q-Former at batch > 1
+// (everything `tiled_gemm_k` does except the im2col-gather convolutions). Structure:
+//   * 128 x 128 block tile, 4 waves as 2 (M) x 2 (N), each wave 4 x 4 MFMA 16x16x32 tiles, BK = 64 per step;
+//   * both operands go global -> LDS by `global_load_lds_dwordx4` (no VGPR round trip), 1 KiB per wave-instruction.
+//     Weights are already stored in MFMA-fragment order, so a packed block lands in LDS exactly as ds_read_b128 wants
+//     it (lane-linear, conflict-free). For the activations the per-lane SOURCE address follows the fragment order
+//     (lane (r,g) fetches row r, k-octet g of a 16 x 32 sub-tile), so their LDS image is fragment-linear as well;
+//   * two LDS buffers (2 x 32 KiB); the loads of step s+1 are in flight across the barrier while step s is multiplied:
+//     counted `s_waitcnt vmcnt(8)` + raw `s_barrier` (a __syncthreads() would drain the DMA queue);
+//   * split-K over blockIdx.z for small grids (prefill at M = 160 has only 64-350 output tiles for 256 CUs): fp32
+//     partial slabs + a fixed-order reduce kernel that applies the epilogue (deterministic, no atomics).
+#include <algorithm>
+
+#include "rdx_common.h"
+#include "rdx_kernels.h"
+#include "skinny_body.h"
+
+namespace rdx {
+
+constexpr int DG_BM = 128, DG_BN = 128, DG_BK = 64;
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// epilogue on 4 consecutive columns n..n+3 of row m (shared by the main kernel and the split-K reducer)
+template <typename T, int EPI>
+__device__ __forceinline__ void store4(const GemmArgs& a, int m, int n, float v[4]) {
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    T* out = reinterpret_cast<T*>(a.out);
+    if (a.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(a.bias + n);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    }
+    if (EPI == EPI_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (EPI == EPI_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    } else if (EPI == EPI_RESID || EPI == EPI_RESID_RELU) {
+        const T4 rv = *reinterpret_cast<const T4*>(reinterpret_cast<const T*>(a.resid) + (size_t)m * a.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = tof<T>(rv[e]) + rnd<T>(v[e]);
+            if (EPI == EPI_RESID_RELU) v[e] = fmaxf(v[e], 0.f);
+        }
+    }
+    T4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = fromf<T>(v[e]);
+    *reinterpret_cast<T4*>(out + (size_t)m * a.ldo + n) = o;
+}
+
+template <typename T, int EPI, bool SPLIT>
+__global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict__ partial, int steps_per_split) {
+    typedef typename Vec8<T>::type V8;
+    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [buf 2][operand 2][block 16][lane 64]
+    const int MB = (a.M + DG_BM - 1) / DG_BM, NB = (a.N + DG_BN - 1) / DG_BN;
+    const int nwg = MB * NB;
+    int tile;
+    {   // XCD-aware order: ids that land on one XCD walk consecutive m-blocks of one n-block (weight panel stays in its L2)
+        const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, rr = nwg & 7;
+        tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+    }
+    const int bn = tile / MB, bm = tile - bn * MB;
+    const int M0 = bm * DG_BM, N0 = bn * DG_BN;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int wm = w >> 1, wn = w & 1;
+    const int KC = a.K >> 5, NT16 = (a.N + 15) >> 4;
+    const int nsteps_total = a.K / DG_BK;
+    const int s0 = blockIdx.z * steps_per_split;
+    const int s1 = min(nsteps_total, s0 + steps_per_split);
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const u4* Wp = reinterpret_cast<const u4*>(a.W);
+
+    // this wave stages blocks i = w*4 .. w*4+3 of each operand per step; block i = (sub-tile i>>1, k-chunk i&1)
+    const u4* wsrc[4];
+    const T* xsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = w * 4 + j, st = i >> 1, kc = i & 1;
+        const int t16 = min((N0 >> 4) + st, NT16 - 1);
+        wsrc[j] = Wp + ((size_t)t16 * KC + kc) * 64 + lane;
+        const int row = min(M0 + st * 16 + r, a.M - 1);
+        xsrc[j] = X + (size_t)row * a.ldx + kc * 32 + g * 8;
+    }
+    auto stage = [&](int s, int buf) {
+        u4* base = lds + (size_t)buf * 2 * 16 * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = w * 4 + j;
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + (size_t)s * 2 * 64), (lptr_t)(base + i * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[j] + (size_t)s * DG_BK), (lptr_t)(base + (16 + i) * 64), 16, 0, 0);
+        }
+    };
+
+    v4f acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    if (s0 < s1) stage(s0, 0);
+    for (int s = s0; s < s1; ++s) {
+        const int buf = (s - s0) & 1;
+        if (s + 1 < s1) {
+            stage(s + 1, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // the 8 loads of step s have landed, step s+1 stays in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const u4* base = lds + (size_t)buf * 2 * 16 * 64;
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            V8 wf[4], xf[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf[nt] = as_vec8<T>(base[((wn * 4 + nt) * 2 + kc) * 64 + lane]);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) xf[mt] = as_vec8<T>(base[(16 + (wm * 4 + mt) * 2 + kc) * 64 + lane]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(wf[nt], xf[mt], acc[nt][mt]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                               // everyone is done reading buf before it is re-staged
+    }
+
+    // epilogue: lane (r = m_local, g) holds out[m][n0 + g*4 + 0..3]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = N0 + (wn * 4 + nt) * 16 + g * 4;
+        if (n >= a.N) continue;                                     // whole 16-column tile at once (N % 16 == 0)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = M0 + (wm * 4 + mt) * 16 + r;
+            float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+            if (SPLIT) {
+                if (m < a.M)
+                    *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.z * a.M + m) * a.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+                continue;
+            }
+            if (EPI == EPI_SILU_MUL) {
+                // gate rows live at n_local 0..7 (g = 0,1), up rows at 8..15 (g = 2,3): partner lane = lane ^ 32
+                float u[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] = __shfl_xor(v[e], 32, 64);
+                if (g < 2 && m < a.M) {
+                    typedef T T4 __attribute__((ext_vector_type(4)));
+                    T4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fromf<T>(swiglu<T>(v[e], u[e]));
+                    const int oc = (N0 >> 1) + (wn * 4 + nt) * 8 + g * 4;
+                    *reinterpret_cast<T4*>(reinterpret_cast<T*>(a.out) + (size_t)m * a.ldo + oc) = o;
+                }
+                continue;
+            }
+            if (m < a.M) store4<T, EPI>(a, m, n, v);
+        }
+    }
+}
+
+// split-K reducer: sums the fp32 slabs in split order and applies the epilogue. One thread = 4 consecutive columns.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_k(GemmArgs a, const float* __restrict__ partial, int splits) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int N4 = a.N >> 2;
+    if (idx >= (size_t)a.M * N4) return;
+    const int m = (int)(idx / N4), n = (int)(idx % N4) * 4;
+    auto sum4 = [&](int col, float v[4]) {
+        v[0] = v[1] = v[2] = v[3] = 0.f;
+        for (int s = 0; s < splits; ++s) {
+            const float4 p = *reinterpret_cast<const float4*>(partial + ((size_t)s * a.M + m) * a.N + col);
+            v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+        }
+    };
+    float v[4];
+    if (EPI == EPI_SILU_MUL) {
+        const int n_local = n & 15;
+        if (n_local >= 8) return;                                    // gate half drives; up half is read at +8
+        float u[4];
+        sum4(n, v);
+        sum4(n + 8, u);
+        typedef T T4 __attribute__((ext_vector_type(4)));
+        T4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fromf<T>(swiglu<T>(v[e], u[e]));
+        *reinterpret_cast<T4*>(reinterpret_cast<T*>(a.out) + (size_t)m * a.ldo + (n >> 4) * 8 + n_local) = o;
+        return;
+    }
+    sum4(n, v);
+    store4<T, EPI>(a, m, n, v);
+}
+
+template <typename T, int EPI>
+static void launch_dma_epi(const GemmArgs& a, float* ws, size_t ws_floats, hipStream_t s) {
+    const int MB = (a.M + DG_BM - 1) / DG_BM, NB = (a.N + DG_BN - 1) / DG_BN, blocks = MB * NB;
+    const int nsteps = a.K / DG_BK;
+    int splits = 1;
+    if (blocks < 192 && nsteps >= 16 && ws) {
+        splits = std::min(std::min((256 + blocks - 1) / blocks, nsteps / 8), 8);
+        while (splits > 1 && (size_t)splits * a.M * a.N > ws_floats) --splits;
+    }
+    const int per = (nsteps + splits - 1) / splits;
+    splits = (nsteps + per - 1) / per;
+    const size_t smem = (size_t)2 * 2 * 16 * 64 * sizeof(u4);       // 64 KiB
+    dim3 grid(blocks, 1, splits), block(256);
+    if (splits > 1) {
+        static bool attr = false;
+        if (!attr) { hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+        hipLaunchKernelGGL((gemm_dma_k<T, EPI, true>), grid, block, smem, s, a, ws, per);
+        const size_t total = (size_t)a.M * (a.N >> 2);
+        hipLaunchKernelGGL((splitk_reduce_k<T, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, ws, splits);
+    } else {
+        static bool attr = false;
+        if (!attr) { hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+        hipLaunchKernelGGL((gemm_dma_k<T, EPI, false>), grid, block, smem, s, a, nullptr, nsteps);
+    }
+}
+
+template <typename T>
+static void launch_dma_T(const GemmArgs& a, int epi, float* ws, size_t ws_floats, hipStream_t s) {
+    switch (epi) {
+        case EPI_NONE: launch_dma_epi<T, EPI_NONE>(a, ws, ws_floats, s); break;
+        case EPI_RELU: launch_dma_epi<T, EPI_RELU>(a, ws, ws_floats, s); break;
+        case EPI_GELU: launch_dma_epi<T, EPI_GELU>(a, ws, ws_floats, s); break;
+        case EPI_RESID: launch_dma_epi<T, EPI_RESID>(a, ws, ws_floats, s); break;
+        case EPI_RESID_RELU: launch_dma_epi<T, EPI_RESID_RELU>(a, ws, ws_floats, s); break;
+        case EPI_SILU_MUL: launch_dma_epi<T, EPI_SILU_MUL>(a, ws, ws_floats, s); break;
+        default: break;
+    }
+}
+
+bool gemm_dma_supported(const GemmArgs& a) { return a.K % DG_BK == 0 && a.N % 16 == 0 && a.ldx % 8 == 0 && a.M > 32; }
+
+void launch_gemm_dma(int dtype, const GemmArgs& a, int epi, float* ws, size_t ws_floats, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, launch_dma_T<T>(a, epi, ws, ws_floats, s));
+}
+
+}  // namespace rdx

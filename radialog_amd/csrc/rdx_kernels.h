@@ -61,6 +61,9 @@ void launch_pack_weight(int dtype, const float* src, void* dst, int N, int K, in
 bool skinny_fits_lds(int M, int K);
 void launch_skinny_gemm(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 void launch_tiled_gemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s);
+// LDS-DMA GEMM for plain row-major activations (M > 32, K % 64 == 0); `ws` = fp32 split-K workspace (nullable)
+bool gemm_dma_supported(const GemmArgs& a);
+void launch_gemm_dma(int dtype, const GemmArgs& a, int epi, float* ws, size_t ws_floats, hipStream_t s);
 
 void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s);
 // prefill: LoRA add + RoPE + KV-cache write for T tokens of B rows; q -> qout [B*T][hidden]

@@ -50,6 +50,10 @@ CASES = [
     (32, 64, 3072, 0, False, 0), (32, 64, 256, 0, False, 0), (24, 64, 11008, 3, False, 0),
     (33, 64, 64, 0, False, 0), (200, 352, 288, 1, False, 0), (257, 144, 1024, 6, False, 0), (130, 256, 512, 4, False, 0),
     (64, 2304, 192, 0, False, 0), (196, 1408, 1408, 0, False, 2), (5, 64, 96, 3, False, 2),
+    # LDS-DMA kernel (force=3): plain, split-K (few tiles, long K), every epilogue, ragged M / N
+    (196, 1408, 1408, 0, False, 3), (160, 4096, 4096, 3, False, 3), (160, 512, 11008, 3, False, 3), (160, 256, 4096, 4, False, 3),
+    (300, 144, 512, 1, False, 3), (33, 64, 64, 2, False, 3), (1000, 272, 2048, 6, False, 3), (129, 4096, 128, 0, True, 3),
+    (160, 2048, 4096, 4, True, 0),
 ]
 
 
