@@ -214,18 +214,24 @@ void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, cons
 // ------------------------------------------------------------------------------------------------------------------
 // decode attention (body in attn_body.h)
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int DA_WAVES = 16;
+constexpr int DA_WAVES = 16;       // latency variant: few (head, row) pairs, each gets a whole CU
+constexpr int DA_WAVES_TP = 4;     // throughput variant: >= 256 pairs, 4 workgroups per CU share the KV stream
 
-template <typename T>
-__global__ __launch_bounds__(DA_WAVES * 64) void decode_attention_k(DecAttnArgs a) {
+template <typename T, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void decode_attention_k(DecAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
-    decode_attention_body<T, DA_WAVES>(a, blockIdx.x, blockIdx.y, dsm);
+    decode_attention_body<T, WAVES, false>(a, blockIdx.x, blockIdx.y, dsm);
 }
 
 void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s) {
-    dim3 grid(a.d.heads, B), block(DA_WAVES * 64);
-    const size_t smem = decode_attention_smem_floats(DA_WAVES, a.d.max_len) * sizeof(float);
-    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T>), grid, block, smem, s, a));
+    dim3 grid(a.d.heads, B);
+    if (a.d.heads * B <= 256) {
+        const size_t smem = decode_attention_smem_floats(DA_WAVES, a.d.max_len) * sizeof(float);
+        RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T, DA_WAVES>), grid, dim3(DA_WAVES * 64), smem, s, a));
+    } else {
+        const size_t smem = decode_attention_smem_floats(DA_WAVES_TP, a.d.max_len) * sizeof(float);
+        RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T, DA_WAVES_TP>), grid, dim3(DA_WAVES_TP * 64), smem, s, a));
+    }
 }
 
 }  // namespace rdx

@@ -26,16 +26,16 @@ __device__ __forceinline__ float rope_one(float x, float partner_signed, float c
 
 __host__ __device__ inline size_t decode_attention_smem_floats(int waves, int max_len) { return (size_t)waves * 128 + 128 + max_len; }
 
-template <typename T, int WAVES>
+template <typename T, int WAVES, bool DED = (WAVES == 8)>
 __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, const int h, const int b, float* dsm) {
     typedef typename Vec8<T>::type V8;
     constexpr int D = 128;
     // 8-wave variant (fused launch, 128-VGPR cap): wave 0 is dedicated to the new token and holds no cache rows, so its
     // register-hungry LoRA/RoPE block never overlaps a live K window; waves 1..7 own the cache rows.
-    constexpr bool DED = WAVES < 16;
     constexpr int CW = DED ? WAVES - 1 : WAVES;  // waves that own cache rows
     constexpr int SPAN = CW * 4;                 // positions covered by one block-wide load
-    constexpr int PRE = DED ? 14 : 8;            // register-resident rows per lane: 512 positions at 16 waves, 392 at 8
+    constexpr int PRE = DED ? 14 : 8;            // register-resident rows per lane: 512 positions at 16 waves, 392 at 8,
+                                                 // 128 at 4 waves (throughput variant for large batches; the rest streams)
     constexpr bool V_EARLY = !DED;               // enough registers to have K and V in flight together
     const LlamaDims& d = a.d;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
@@ -161,6 +161,7 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
         for (int e = 0; e < 8; ++e) acc += q8[e] * k8[e];
         score_store(jsub == 0 ? slot : nk, acc);
     }
+#pragma unroll 4
     for (int j0 = PRE * SPAN; owns_rows && j0 < slot; j0 += SPAN) {             // contexts beyond the register window
         const int j = j0 + cw * 4 + jsub;
         float acc = 0.f;

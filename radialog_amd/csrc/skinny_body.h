@@ -113,17 +113,21 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-    for (int cb = c0; cb < c1; cb += U) {
-        u4 xr[U][MT];
-        if (!XLDS) {
+    // activations of the non-LDS path are software-pipelined one batch ahead as well (L2 latency, 2x the weight bytes at M = 32)
+    u4 xr[U][MT], xn[U][MT];
+    auto load_x = [&](u4 (&dst)[U][MT], int cb) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = min(cb + u, clast);
+        for (int u = 0; u < U; ++u) {
+            const int c = min(cb + u, clast);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    xr[u][mt] = xok[mt] ? ldg16(xrow[mt] + (size_t)c * 32) : (u4){0u, 0u, 0u, 0u};
-            }
+            for (int mt = 0; mt < MT; ++mt)
+                dst[u][mt] = xok[mt] ? ldg16(xrow[mt] + (size_t)c * 32) : (u4){0u, 0u, 0u, 0u};
         }
+    };
+    if (!XLDS) load_x(xr, c0);
+
+    for (int cb = c0; cb < c1; cb += U) {
+        if (!XLDS && cb + U < c1) load_x(xn, cb + U);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (cb + u < c1) {
@@ -138,6 +142,12 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) wv[u] = wn[u];
+        if (!XLDS && cb + U < c1) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xr[u][mt] = xn[u][mt];
+        }
         if (cb + 2 * U < c1) {
 #pragma unroll
             for (int u = 0; u < U; ++u) wn[u] = ldg16_nt(wbase + (size_t)min(cb + 2 * U + u, clast) * 64);
