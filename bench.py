@@ -43,6 +43,20 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(batch, dtype):
+    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
+    passes, gfx950 read-side doubling): measured offline because counters cannot be read from inside the timed process;
+    the summary lives in profiles/r01_pmc_hbm_traffic.md and its machine-readable twin profiles/r01_pmc.json.
+    Only valid for the configuration it was measured on (batch 1, bf16) -> null otherwise."""
+    if batch != 1 or dtype != "bf16":
+        return None
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_pmc.json")) as f:
+            return next(iter(json.load(f).values()))["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def _pick_threads():
     """torch's intra-op pool at os.cpu_count() threads can be far slower than a smaller pool on many-core hosts
     (sync overhead on decode-sized ops); calibrate on a decode-shaped matmul and use the fastest setting."""
@@ -198,7 +212,7 @@ def main():
             "bound": "hbm", "kernel": "skinny_gemm_k<bf16,MT,EPI_SILU_MUL,NORM> (gate/up SwiGLU GEMV)" if args.dtype == "bf16"
             else "skinny_gemm_k<f16,MT,EPI_SILU_MUL,NORM> (gate/up SwiGLU GEMV)",
             "achieved": gu_bytes / (gu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "frac": gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(B, args.dtype),
             "bytes_per_launch": gu_bytes, "us_per_launch": gu_ms * 1e3,
             "decode_step_ms": step_ms, "decode_step_weight_GBs": step_bytes / (step_ms * 1e-3) / 1e9,
             "decode_step_frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

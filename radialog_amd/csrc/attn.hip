@@ -160,52 +160,74 @@ __device__ __forceinline__ float lora_delta(const T* Bm, int n, const T* avec, i
     return rnd<T>(rnd<T>(acc) * scale);
 }
 
+// one thread = 8 contiguous dims of one (token, head): 16-byte loads/stores throughout; the rotate-half partner of q
+// (which needs the LoRA-updated value) is exchanged through LDS, the partner of k is read straight from the GEMM output.
 template <typename T>
-__global__ __launch_bounds__(256) void rope_kv_prefill_k(LlamaDims d, const T* __restrict__ qkv, const T* __restrict__ lbq,
-                                                         const T* __restrict__ lbv, const T* __restrict__ cos_t,
-                                                         const T* __restrict__ sin_t, const int* __restrict__ pos_ids,
-                                                         T* __restrict__ qout, T* __restrict__ kcache,
-                                                         T* __restrict__ vcache, int B, int Tn) {
-    extern __shared__ float sm[];            // q[hidden], k[hidden]
-    float* qs = sm;
-    float* ks = sm + d.hidden;
+__global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* __restrict__ qkv, const T* __restrict__ lbq,
+                                                          const T* __restrict__ lbv, const T* __restrict__ cos_t,
+                                                          const T* __restrict__ sin_t, const int* __restrict__ pos_ids,
+                                                          T* __restrict__ qout, T* __restrict__ kcache,
+                                                          T* __restrict__ vcache, int B, int Tn) {
+    typedef typename Vec8<T>::type V8;
+    extern __shared__ float qs[];            // [hidden] q after the LoRA add
+    constexpr int D = 128;
     const int t = blockIdx.x, b = blockIdx.y;
     const size_t row = (size_t)b * Tn + t;
     const T* x = qkv + row * d.qkv_ld;
-    const int H = d.hidden, D = d.head_dim;
-    const T* aq = x + 3 * H;
-    const T* av = x + 3 * H + d.lora_r;
-    for (int n = threadIdx.x; n < H; n += blockDim.x) {
-        float q = tof<T>(x[n]);
-        const float k = tof<T>(x[H + n]);
-        float v = tof<T>(x[2 * H + n]);
-        if (d.lora_r > 0) {
-            q = rnd<T>(q + lora_delta<T>(lbq, n, aq, d.lora_r, d.lora_scale));
-            v = rnd<T>(v + lora_delta<T>(lbv, n, av, d.lora_r, d.lora_scale));
+    const int H = d.hidden;
+    const int n0 = threadIdx.x * 8;
+    const bool act = n0 < H;
+    const int hh = n0 / D, dd = n0 - hh * D;
+    const bool lo = dd < D / 2;
+    float q8[8], k8[8], kp8[8];
+    if (act) {
+        const V8 qv = as_vec8<T>(ldg16(x + n0)), kv = as_vec8<T>(ldg16(x + H + n0)), vv = as_vec8<T>(ldg16(x + 2 * H + n0));
+        const V8 kpv = as_vec8<T>(ldg16(x + H + (lo ? n0 + D / 2 : n0 - D / 2)));
+        float v8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { q8[e] = tof<T>(qv[e]); k8[e] = tof<T>(kv[e]); v8[e] = tof<T>(vv[e]); kp8[e] = tof<T>(kpv[e]); }
+        if (d.lora_r == 8) {
+            const V8 aq = as_vec8<T>(ldg16(x + 3 * H)), av = as_vec8<T>(ldg16(x + 3 * H + 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const V8 bq = as_vec8<T>(ldg16(lbq + (size_t)(n0 + e) * 8)), bv = as_vec8<T>(ldg16(lbv + (size_t)(n0 + e) * 8));
+                float sq = 0.f, sv = 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { sq += tof<T>(bq[i]) * tof<T>(aq[i]); sv += tof<T>(bv[i]) * tof<T>(av[i]); }
+                q8[e] = rnd<T>(q8[e] + rnd<T>(rnd<T>(sq) * d.lora_scale));     // result += lora_B(lora_A(x)) * scaling
+                v8[e] = rnd<T>(v8[e] + rnd<T>(rnd<T>(sv) * d.lora_scale));
+            }
         }
-        qs[n] = q;
-        ks[n] = k;
-        const int hh = n / D, dd = n - hh * D;
-        vcache[(((size_t)b * d.heads + hh) * d.max_len + t) * D + dd] = fromf<T>(v);
+        V8 vo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qs[n0 + e] = q8[e]; vo[e] = fromf<T>(v8[e]); }
+        stg16(vcache + (((size_t)b * d.heads + hh) * d.max_len + t) * D + dd, as_u4<T>(vo));
     }
     __syncthreads();
-    const int pos = pos_ids[row];
-    for (int n = threadIdx.x; n < H; n += blockDim.x) {
-        const int hh = n / D, dd = n - hh * D;
-        const float c = tof<T>(cos_t[(size_t)pos * D + dd]), s = tof<T>(sin_t[(size_t)pos * D + dd]);
-        const bool lo = dd < D / 2;
-        const float qp = lo ? -qs[n + D / 2] : qs[n - D / 2];
-        const float kp = lo ? -ks[n + D / 2] : ks[n - D / 2];
-        qout[row * H + n] = fromf<T>(rope_one<T>(qs[n], qp, c, s));
-        kcache[(((size_t)b * d.heads + hh) * d.max_len + t) * D + dd] = fromf<T>(rope_one<T>(ks[n], kp, c, s));
+    if (act) {
+        const int pos = pos_ids[row];
+        const V8 cv = as_vec8<T>(ldg16(cos_t + (size_t)pos * D + dd)), sv = as_vec8<T>(ldg16(sin_t + (size_t)pos * D + dd));
+        const int pn = lo ? n0 + D / 2 : n0 - D / 2;
+        V8 qo, ko;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float c = tof<T>(cv[e]), sn = tof<T>(sv[e]);
+            const float qp = lo ? -qs[pn + e] : qs[pn + e];
+            const float kp = lo ? -kp8[e] : kp8[e];
+            qo[e] = fromf<T>(rope_one<T>(q8[e], qp, c, sn));
+            ko[e] = fromf<T>(rope_one<T>(k8[e], kp, c, sn));
+        }
+        stg16(qout + row * H + n0, as_u4<T>(qo));
+        stg16(kcache + (((size_t)b * d.heads + hh) * d.max_len + t) * D + dd, as_u4<T>(ko));
     }
 }
 
 void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,
                             const void* cos_t, const void* sin_t, const int* pos_ids, void* qout, void* kcache,
                             void* vcache, int B, int T_, hipStream_t s) {
-    dim3 grid(T_, B), block(256);
-    const size_t smem = (size_t)2 * d.hidden * sizeof(float);
+    const int threads = ((d.hidden / 8 + 63) / 64) * 64;          // hidden <= 8192
+    dim3 grid(T_, B), block(threads);
+    const size_t smem = (size_t)d.hidden * sizeof(float);
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rope_kv_prefill_k<T>), grid, block, smem, s, d, (const T*)qkv,
                                                 (const T*)lora_bq, (const T*)lora_bv, (const T*)cos_t, (const T*)sin_t,
                                                 pos_ids, (T*)qout, (T*)kcache, (T*)vcache, B, T_));
