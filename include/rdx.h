@@ -61,6 +61,11 @@ int rdx_finalize_weights(rdx_ctx* ctx);            /* resolves names, checks com
 /* Blip2Qformer.forward_image (blip2_qformer.py:467-484): image float32[B,3,S,S] ->
  *   qformer_out float32[B,n_query,q_hidden] (last_hidden_state), image_embeds float32[B,P,v_proj] (nullable). */
 int rdx_encode_image(rdx_ctx* ctx, const float* image, int batch, float* qformer_out, float* image_embeds);
+/* Same with a prior study: MultiImageEncoder.forward(current_image, previous_image) (biovil_t/encoder.py:117-123) runs
+ * both images through the trunk and takes the difference features from the VisionTransformerPooler
+ * (biovil_t/transformer.py:73-224). No RaDialog caller passes a previous image; optional mode of the encoder. */
+int rdx_encode_image2(rdx_ctx* ctx, const float* image, const float* previous_image, int batch, float* qformer_out,
+                      float* image_embeds);
 
 /* LlamaForCausalLM.generate(..., num_beams=1) as the reference calls it (demo.py:290-297, test.py:339-348):
  * greedy search (transformers 4.28.1 GenerationMixin.greedy_search) over LlamaForCausalLM.forward with the image

@@ -70,15 +70,52 @@ def resnet50_trunk(x: torch.Tensor, W: Dict[str, torch.Tensor], vcfg) -> torch.T
     return x
 
 
-def patch_fused(images: torch.Tensor, W, vcfg) -> torch.Tensor:
-    """MultiImageEncoder.forward, single-image branch (biovil_t/encoder.py:124-130): trunk -> 1x1 conv
-    -> concat with the learned constant `missing_previous_emb`."""
+def patch_fused(images: torch.Tensor, W, vcfg, previous: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MultiImageEncoder.forward (biovil_t/encoder.py:110-136). Single-image branch (:124-130): trunk -> 1x1 conv ->
+    concat with the learned constant `missing_previous_emb`. Two-image branch (:117-123): both images through the
+    trunk and the 1x1 conv, difference features from the ViT pooler."""
     E = "visual_encoder.encoder."
-    x = resnet50_trunk(images, W, vcfg)
-    patch_x = F.conv2d(x, W[E + "backbone_to_vit.weight"])
-    B, _, h, w = patch_x.shape
-    diff_x = W[E + "missing_previous_emb"].repeat(B, 1, h, w)
+    B = images.shape[0]
+    if previous is not None:
+        x = resnet50_trunk(torch.cat([images, previous], dim=0), W, vcfg)
+        x = F.conv2d(x, W[E + "backbone_to_vit.weight"])
+        patch_x, patch_prev = x[:B], x[B:]
+        diff_x = vit_pooler(patch_x, patch_prev, W, vcfg)
+    else:
+        x = resnet50_trunk(images, W, vcfg)
+        patch_x = F.conv2d(x, W[E + "backbone_to_vit.weight"])
+        _, _, h, w = patch_x.shape
+        diff_x = W[E + "missing_previous_emb"].repeat(B, 1, h, w)
     return torch.cat([patch_x, diff_x], dim=1)
+
+
+def vit_pooler(cur: torch.Tensor, prev: torch.Tensor, W, vcfg) -> torch.Tensor:
+    """VisionTransformerPooler.forward with a previous image (biovil_t/transformer.py:73-119) -- PARITY UNPINNED
+    (timm Mlp / DropPath absent; eval mode makes every dropout the identity). cur, prev: [B, C, g, g] -> [B, C, g, g].
+    Block (:219-224): q = k = v = norm1(x) + (pos + type) embedding (the embedding reaches V too), MHA without qkv bias,
+    proj with bias, residual; timm Mlp(C -> C -> C, GELU), residual; norm_post; the current image's tokens are returned."""
+    P = "visual_encoder.encoder.vit_pooler."
+    B, C, g, _ = cur.shape
+    L, heads, eps = g * g, vcfg.pool_heads, vcfg.pool_ln_eps
+    x = torch.cat([cur.view(B, C, L).transpose(1, 2), prev.view(B, C, L).transpose(1, 2)], dim=1)      # [B, 2L, C]
+    pos = sine_pos_embed(g, C)                                                                          # [1, L, C]
+    te = W[P + "type_embed"]                                                                            # [2, 1, C]
+    pte = torch.cat([pos + te[0][None], pos + te[1][None]], dim=1)                                      # [1, 2L, C]
+    d = C // heads
+    for i in range(vcfg.pool_blocks):
+        Bk = f"{P}blocks.{i}."
+        xe = F.layer_norm(x, (C,), W[Bk + "norm1.weight"], W[Bk + "norm1.bias"], eps) + pte
+        q = F.linear(xe, W[Bk + "attn.proj_q.weight"]).reshape(B, 2 * L, heads, d).permute(0, 2, 1, 3)
+        k = F.linear(xe, W[Bk + "attn.proj_k.weight"]).reshape(B, 2 * L, heads, d).permute(0, 2, 1, 3)
+        v = F.linear(xe, W[Bk + "attn.proj_v.weight"]).reshape(B, 2 * L, heads, d).permute(0, 2, 1, 3)
+        a = ((q @ k.transpose(-2, -1)) * d ** -0.5).softmax(dim=-1)
+        o = (a @ v).transpose(1, 2).reshape(B, 2 * L, C)
+        x = x + F.linear(o, W[Bk + "attn.proj.weight"], W[Bk + "attn.proj.bias"])
+        h = F.layer_norm(x, (C,), W[Bk + "norm2.weight"], W[Bk + "norm2.bias"], eps)
+        h = F.linear(F.gelu(F.linear(h, W[Bk + "mlp.fc1.weight"], W[Bk + "mlp.fc1.bias"])), W[Bk + "mlp.fc2.weight"], W[Bk + "mlp.fc2.bias"])
+        x = x + h
+    x = F.layer_norm(x, (C,), W[P + "norm_post.weight"], W[P + "norm_post.bias"], eps)
+    return x[:, :L].transpose(1, 2).reshape(B, C, g, g)
 
 
 def projector(patch: torch.Tensor, W, vcfg) -> torch.Tensor:
@@ -89,10 +126,10 @@ def projector(patch: torch.Tensor, W, vcfg) -> torch.Tensor:
     return F.conv2d(x, W[J + "3.weight"], W[J + "3.bias"])
 
 
-def image_embeds(images: torch.Tensor, W, vcfg) -> torch.Tensor:
+def image_embeds(images: torch.Tensor, W, vcfg, previous: Optional[torch.Tensor] = None) -> torch.Tensor:
     """ln_vision(projected_patch_embeddings.reshape(B,-1,1408)) -- the raw NCHW reshape WITHOUT a permute
     (blip2_qformer.py:469) and the fp32 LayerNorm (blip2.py:199-205)."""
-    pp = projector(patch_fused(images, W, vcfg), W, vcfg)                 # [B, C, g, g] NCHW
+    pp = projector(patch_fused(images, W, vcfg, previous), W, vcfg)       # [B, C, g, g] NCHW
     B, C = pp.shape[0], pp.shape[1]
     tok = pp.reshape(B, -1, C)                                           # flat re-chunking (finding 4)
     return F.layer_norm(tok.float(), (C,), W["ln_vision.weight"], W["ln_vision.bias"], vcfg.ln_eps)
@@ -139,9 +176,10 @@ def qformer(img_emb: torch.Tensor, W, qcfg) -> torch.Tensor:
     return x
 
 
-def forward_image(images: torch.Tensor, W, cfg) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Blip2Qformer.forward_image (blip2_qformer.py:467-484): (last_hidden_state, image_embeds)."""
-    emb = image_embeds(images, W, cfg.vision)
+def forward_image(images: torch.Tensor, W, cfg, previous: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Blip2Qformer.forward_image (blip2_qformer.py:467-484): (last_hidden_state, image_embeds). `previous` switches the
+    BioViL-T encoder to its two-image branch (never passed by a RaDialog caller; an optional mode of the encoder)."""
+    emb = image_embeds(images, W, cfg.vision, previous)
     return qformer(emb, W, cfg.qformer), emb
 
 

@@ -176,9 +176,11 @@ class Blip2Qformer:
 
     # -- the hot-path method ------------------------------------------------------------------------------------------------
     @torch.no_grad()
-    def forward_image(self, image: torch.Tensor):
-        """image float32[B,3,S,S] on the model device -> (last_hidden_state f32[B,32,768], image_embeds f32[B,196,1408])."""
+    def forward_image(self, image: torch.Tensor, previous_image: Optional[torch.Tensor] = None):
+        """image float32[B,3,S,S] on the model device -> (last_hidden_state f32[B,32,768], image_embeds f32[B,196,1408]).
+        `previous_image` is an extension: the reference's forward_image never passes one, but its BioViL-T encoder has the
+        two-image branch (MultiImageEncoder.forward, biovil_t/encoder.py:117-123) and ships the pooler weights."""
         if self._engine is None:
             raise RuntimeError("Blip2Qformer.forward_image needs the model on a GPU: call .to('cuda') first "
                                "(there is no CPU implementation of the hot path)")
-        return self._engine.encode_image(image)
+        return self._engine.encode_image(image, previous_image=previous_image)

@@ -68,6 +68,9 @@ class VisionCfg:
     proj: int = 1408                                # projector hidden = output
     bn_eps: float = 1e-5
     ln_eps: float = 1e-5                            # ln_vision (nn.LayerNorm default)
+    pool_blocks: int = 3                            # VisionTransformerPooler (biovil_t/transformer.py:42-52): two-image mode
+    pool_heads: int = 8
+    pool_ln_eps: float = 1e-6
 
     @property
     def grid(self) -> int:
@@ -100,5 +103,6 @@ def small_cfg() -> RaDialogCfg:
     return RaDialogCfg(
         llama=LlamaCfg(vocab=32001, hidden=512, inter=1408, layers=2, heads=4, qformer_dim=192),
         qformer=QFormerCfg(hidden=192, layers=4, heads=3, inter=768, enc_width=352, n_query=32),
-        vision=VisionCfg(img=128, stem=32, planes=(32, 64, 128, 256), blocks=(1, 2, 2, 1), b2v=64, proj=352),
+        vision=VisionCfg(img=128, stem=32, planes=(32, 64, 128, 256), blocks=(1, 2, 2, 1), b2v=64, proj=352,
+                         pool_blocks=2, pool_heads=2),
     )

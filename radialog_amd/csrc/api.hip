@@ -39,6 +39,11 @@ struct VBlock {
     int planes, stride;
 };
 
+struct PoolBlock {          // one VisionTransformerPooler block (two-image mode)
+    const float *n1_g, *n1_b, *n2_g, *n2_b, *bo, *b1, *b2;
+    GemmW wqkv, wo, w1, w2;
+};
+
 struct GraphKey {
     int B = -1, max_new = 0, eos = 0, pad = 0;
     const void* tokens = nullptr; const void* scores = nullptr;
@@ -93,6 +98,11 @@ struct rdx_ctx {
     GemmW v_conv1, v_b2v, v_p1, v_p2;
     const float *v_conv1_b = nullptr, *v_p1_b = nullptr, *v_p2_b = nullptr, *v_ln_g = nullptr, *v_ln_b = nullptr;
     std::vector<VBlock> vb;
+    std::vector<PoolBlock> pool;                    // optional: present when the pooler weights were uploaded
+    const void* pool_emb = nullptr;                 // [2*P][b2v] pos + type embedding (model dtype)
+    const float *pool_ng = nullptr, *pool_nb = nullptr, *v_p1f_b = nullptr;
+    GemmW v_p1f;                                    // projector conv-1 over the full 2*b2v channels (two-image mode)
+    float pool_eps = 1e-6f;
     int enc_batch = 0;
     void *vin = nullptr, *vbuf[4] = {nullptr, nullptr, nullptr, nullptr}, *v_imgemb = nullptr;
     void *qx = nullptr, *qt = nullptr, *qqkv = nullptr, *qctx = nullptr, *qh = nullptr, *qkvx = nullptr;
@@ -385,6 +395,23 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         c->v_p2 = R.g("v.proj2.w", f.v_proj, f.v_proj); c->v_p2_b = R.f("v.proj2.b", f.v_proj);
         c->v_ln_g = R.f("v.ln.g", f.v_proj); c->v_ln_b = R.f("v.ln.b", f.v_proj);
         if (f.q_enc_width != f.v_proj) return fail(c, -1, "q_enc_width %d != v_proj %d", f.q_enc_width, f.v_proj);
+        if (c->tens.count("v.pool.emb")) {          // two-image mode is optional: resolve it only when its weights are there
+            const int Cv = f.v_b2v, Pn = (f.v_img / 32) * (f.v_img / 32);
+            if (Cv % 32) return fail(c, -1, "ViT pooler needs b2v %% 32 == 0");
+            c->pool_emb = R.t("v.pool.emb", (int64_t)2 * Pn * Cv);
+            c->pool_ng = R.f("v.pool.norm_g", Cv); c->pool_nb = R.f("v.pool.norm_b", Cv);
+            c->v_p1f = R.g("v.proj1f.w", f.v_proj, 2 * Cv); c->v_p1f_b = R.f("v.proj1f.b", f.v_proj);
+            for (int i = 0; c->gemm.count(S("v.pool.%d.wqkv", i)); ++i) {
+                PoolBlock pb;
+                const std::string p = S("v.pool.%d.", i);
+                pb.n1_g = R.f(p + "n1_g", Cv); pb.n1_b = R.f(p + "n1_b", Cv); pb.n2_g = R.f(p + "n2_g", Cv); pb.n2_b = R.f(p + "n2_b", Cv);
+                pb.wqkv = R.g(p + "wqkv", 3 * Cv, Cv);
+                pb.wo = R.g(p + "wo", Cv, Cv); pb.bo = R.f(p + "bo", Cv);
+                pb.w1 = R.g(p + "w1", Cv, Cv); pb.b1 = R.f(p + "b1", Cv);
+                pb.w2 = R.g(p + "w2", Cv, Cv); pb.b2 = R.f(p + "b2", Cv);
+                c->pool.push_back(pb);
+            }
+        }
     }
     if (R.rc) return R.rc;
     c->finalized = true;
@@ -429,11 +456,13 @@ static void conv_gemm(rdx_ctx* c, const void* X, const GemmW& W, const float* bi
     else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
 }
 
-extern "C" int rdx_encode_image(rdx_ctx* c, const float* image, int B, float* qformer_out, float* image_embeds) {
+static int encode_impl(rdx_ctx* c, const float* image, const float* previous, int Bimg, float* qformer_out, float* image_embeds) {
     if (!c) return -1;
     if (!c->finalized || !c->cfg.enable_vision) return fail(c, -1, "rdx_encode_image: vision weights not finalized");
-    if (!image || !qformer_out || B <= 0) return fail(c, -1, "rdx_encode_image: bad arguments");
+    if (!image || !qformer_out || Bimg <= 0) return fail(c, -1, "rdx_encode_image: bad arguments");
+    if (previous && !c->pool_emb) return fail(c, -1, "rdx_encode_image2: the ViT-pooler weights (two-image mode) were not loaded");
     HIPCHK(c, hipSetDevice(c->device));
+    int B = previous ? 2 * Bimg : Bimg;            // trunk batch: [current ; previous] like torch.cat (encoder.py:119)
     int rc = ensure_enc_ws(c, B);
     if (rc) return rc;
     const rdx_config& f = c->cfg;
@@ -441,7 +470,8 @@ extern "C" int rdx_encode_image(rdx_ctx* c, const float* image, int B, float* qf
     hipStream_t s = c->stream;
 
     // a1/a2: stem. 7x7/2 conv as implicit GEMM over a zero-padded NHWC4 image: K = 7 x 8(kw, last is zero) x 4(c, last is zero)
-    launch_img_prep(dt, image, c->vin, B, S_, 3, Hp, Hp, s);
+    launch_img_prep(dt, image, c->vin, Bimg, S_, 3, Hp, Hp, s);
+    if (previous) launch_img_prep(dt, previous, (char*)c->vin + (size_t)Bimg * Hp * Hp * 4 * 2, Bimg, S_, 3, Hp, Hp, s);
     int Hc = S_ / 2;
     conv_gemm(c, c->vin, c->v_conv1, c->v_conv1_b, nullptr, c->vbuf[0], B, Hp, Hp, 4, 7, 8, 2, 0, Hc, Hc, EPI_RELU);
     launch_maxpool(dt, c->vbuf[0], c->vbuf[1], B, Hc, Hc, f.v_stem, s);
@@ -462,12 +492,40 @@ extern "C" int rdx_encode_image(rdx_ctx* c, const float* image, int B, float* qf
         Hc = Ho; C = 4 * vb.planes;
     }
     // a3/a4: backbone_to_vit, projector (missing_previous_emb + BN folded into proj1's bias), NHWC output
-    const int P = Hc * Hc, MP = B * P;
-    { GemmArgs a = gargs(cur, C, c->v_b2v, nullptr, t1, f.v_b2v, MP); launch_tiled_gemm(dt, a, ConvGeom{0}, EPI_NONE, s); }
-    { GemmArgs a = gargs(t1, f.v_b2v, c->v_p1, c->v_p1_b, t2, f.v_proj, MP); launch_tiled_gemm(dt, a, ConvGeom{0}, EPI_RELU, s); }
-    { GemmArgs a = gargs(t2, f.v_proj, c->v_p2, c->v_p2_b, t3, f.v_proj, MP); launch_tiled_gemm(dt, a, ConvGeom{0}, EPI_NONE, s); }
+    const int P = Hc * Hc;
+    { GemmArgs a = gargs(cur, C, c->v_b2v, nullptr, t1, f.v_b2v, B * P); run_gemm(c, a, EPI_NONE); }      // [B*P][b2v], NHWC = token order
+    const int MP = Bimg * P;
+    if (!previous) {
+        { GemmArgs a = gargs(t1, f.v_b2v, c->v_p1, c->v_p1_b, t2, f.v_proj, MP); run_gemm(c, a, EPI_RELU); }
+    } else {
+        // a3': VisionTransformerPooler over [current ; previous] tokens (biovil_t/transformer.py:73-224), then the projector's
+        // first conv over the real 2*b2v channels [patch_x | diff_x] (no constant fold in this mode)
+        const int Cv = f.v_b2v, L2 = 2 * P, MT = Bimg * L2;
+        void *tok = cur, *xe = t2, *qkv = t3;          // the trunk output is dead after backbone_to_vit
+        launch_pool_gather(dt, t1, tok, Bimg, P, Cv, s);
+        for (const PoolBlock& pb : c->pool) {
+            launch_layernorm_ex(dt, tok, Cv, pb.n1_g, pb.n1_b, c->pool_emb, L2, xe, Cv, MT, Cv, c->pool_eps, s);
+            { GemmArgs a = gargs(xe, Cv, pb.wqkv, nullptr, qkv, 3 * Cv, MT); run_gemm(c, a, EPI_NONE); }
+            AttnArgs at;
+            memset(&at, 0, sizeof(at));
+            at.Q = qkv; at.K = (const char*)qkv + (size_t)Cv * 2; at.V = (const char*)qkv + (size_t)2 * Cv * 2; at.O = xe;
+            at.q_bs = at.k_bs = at.v_bs = (long)L2 * 3 * Cv; at.q_ts = at.k_ts = at.v_ts = 3 * Cv; at.q_hs = at.k_hs = at.v_hs = 32;
+            at.o_bs = (long)L2 * Cv; at.o_ts = Cv; at.o_hs = 32;
+            at.B = Bimg; at.H = Cv / 32; at.Tq = L2; at.Tk = L2;
+            launch_attention(dt, 32, at, s);
+            { GemmArgs a = gargs(xe, Cv, pb.wo, pb.bo, tok, Cv, MT); a.resid = tok; a.ldr = Cv; run_gemm(c, a, EPI_RESID); }
+            launch_layernorm_ex(dt, tok, Cv, pb.n2_g, pb.n2_b, nullptr, 1, xe, Cv, MT, Cv, c->pool_eps, s);
+            { GemmArgs a = gargs(xe, Cv, pb.w1, pb.b1, qkv, Cv, MT); run_gemm(c, a, EPI_GELU); }
+            { GemmArgs a = gargs(qkv, Cv, pb.w2, pb.b2, tok, Cv, MT); a.resid = tok; a.ldr = Cv; run_gemm(c, a, EPI_RESID); }
+        }
+        launch_layernorm_ex(dt, tok, Cv, c->pool_ng, c->pool_nb, nullptr, 1, xe, Cv, MT, Cv, c->pool_eps, s);
+        launch_pool_concat(dt, t1, xe, qkv, Bimg, P, Cv, s);                      // [Bimg*P][2*b2v]
+        { GemmArgs a = gargs(qkv, 2 * Cv, c->v_p1f, c->v_p1f_b, t2, f.v_proj, MP); run_gemm(c, a, EPI_RELU); }
+    }
+    { GemmArgs a = gargs(t2, f.v_proj, c->v_p2, c->v_p2_b, t3, f.v_proj, MP); run_gemm(c, a, EPI_NONE); }
     // a5: NCHW reshape scramble + ln_vision
-    launch_scramble_layernorm(dt, t3, c->v_ln_g, c->v_ln_b, c->v_imgemb, image_embeds, B, P, f.v_proj, f.v_ln_eps, s);
+    launch_scramble_layernorm(dt, t3, c->v_ln_g, c->v_ln_b, c->v_imgemb, image_embeds, Bimg, P, f.v_proj, f.v_ln_eps, s);
+    B = Bimg;
 
     // a6: Q-Former, query-only path
     const int H = f.q_hidden, NQ = f.q_nquery, M = B * NQ, KVW = c->n_cross * 2 * H;
@@ -503,6 +561,16 @@ extern "C" int rdx_encode_image(rdx_ctx* c, const float* image, int B, float* qf
     }
     HIPCHK(c, hipGetLastError());
     return 0;
+}
+
+extern "C" int rdx_encode_image(rdx_ctx* c, const float* image, int B, float* qformer_out, float* image_embeds) {
+    return encode_impl(c, image, nullptr, B, qformer_out, image_embeds);
+}
+
+extern "C" int rdx_encode_image2(rdx_ctx* c, const float* image, const float* previous_image, int B, float* qformer_out,
+                                 float* image_embeds) {
+    if (!previous_image) return fail(c, -1, "rdx_encode_image2: previous_image is null (use rdx_encode_image)");
+    return encode_impl(c, image, previous_image, B, qformer_out, image_embeds);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -141,6 +141,10 @@ void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s)
             static bool attr128 = false;
             if (!attr128) { hipFuncSetAttribute((const void*)attention_k<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr128 = true; }
             hipLaunchKernelGGL((attention_k<T, 128>), grid, block, smem, s, a, TkP);
+        } else if (head_dim == 32) {
+            static bool attr32 = false;
+            if (!attr32) { hipFuncSetAttribute((const void*)attention_k<T, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr32 = true; }
+            hipLaunchKernelGGL((attention_k<T, 32>), grid, block, smem, s, a, TkP);
         } else {
             static bool attr64 = false;
             if (!attr64) { hipFuncSetAttribute((const void*)attention_k<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr64 = true; }

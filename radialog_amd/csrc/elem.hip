@@ -62,6 +62,67 @@ void launch_layernorm(int dtype, const void* x, const float* gamma, const float*
                                                 (T*)out, out_f32, H, eps));
 }
 
+// ---- LayerNorm with row strides and an optional additive per-token embedding (ViT pooler: norm1(x) + pos/type emb) ---
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_ex_k(const T* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, const T* __restrict__ emb, int emb_rows,
+                                                      T* __restrict__ out, long ldo, int H, float eps) {
+    __shared__ float red[32];
+    const size_t row = blockIdx.x;
+    const T* xr = x + row * ldx;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) s += tof<T>(xr[i]);
+    const float mean = block_sum(s, red) / (float)H;
+    float v = 0.f;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) { const float d = tof<T>(xr[i]) - mean; v += d * d; }
+    const float rstd = rsqrtf(block_sum(v, red) / (float)H + eps);
+    const T* er = emb ? emb + (size_t)(row % emb_rows) * H : nullptr;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) {
+        float y = (tof<T>(xr[i]) - mean) * rstd * gamma[i] + beta[i];
+        if (er) y += tof<T>(er[i]);
+        out[row * ldo + i] = fromf<T>(y);
+    }
+}
+void launch_layernorm_ex(int dtype, const void* x, long ldx, const float* gamma, const float* beta, const void* emb, int emb_rows,
+                         void* out, long ldo, int rows, int H, float eps, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((layernorm_ex_k<T>), dim3(rows), dim3(256), 0, s, (const T*)x, ldx, gamma, beta,
+                                                (const T*)emb, emb_rows, (T*)out, ldo, H, eps));
+}
+
+// ---- ViT pooler token plumbing: tokens[b][j] = (j < L ? current : previous) image's patch j % L; final concat ----------
+template <typename T>
+__global__ void pool_gather_k(const T* __restrict__ src, T* __restrict__ dst, int B, int L, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // one thread = 8 channels
+    const int C8 = C >> 3;
+    if (i >= (size_t)B * 2 * L * C8) return;
+    const int c8 = (int)(i % C8);
+    const size_t tok = i / C8;
+    const int j = (int)(tok % (2 * L)), b = (int)(tok / (2 * L));
+    const size_t srow = (size_t)(j < L ? b : B + b) * L + (j % L);
+    stg16(dst + tok * C + c8 * 8, ldg16(src + srow * C + c8 * 8));
+}
+void launch_pool_gather(int dtype, const void* src, void* dst, int B, int L, int C, hipStream_t s) {
+    const size_t n = (size_t)B * 2 * L * (C >> 3);
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((pool_gather_k<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)src,
+                                                (T*)dst, B, L, C));
+}
+template <typename T>
+__global__ void pool_concat_k(const T* __restrict__ patch, const T* __restrict__ tokens, T* __restrict__ dst, int B, int L, int C) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;        // dst [B*L][2C]: [patch_x | diff_x]
+    const int C8 = C >> 3;
+    if (i >= (size_t)B * L * 2 * C8) return;
+    const int c8 = (int)(i % (2 * C8));
+    const size_t row = i / (2 * C8);
+    const int b = (int)(row / L), j = (int)(row % L);
+    const T* srcp = c8 < C8 ? patch + row * C + c8 * 8 : tokens + ((size_t)b * 2 * L + j) * C + (c8 - C8) * 8;
+    stg16(dst + row * 2 * C + c8 * 8, ldg16(srcp));
+}
+void launch_pool_concat(int dtype, const void* patch, const void* tokens, void* dst, int B, int L, int C, hipStream_t s) {
+    const size_t n = (size_t)B * L * 2 * (C >> 3);
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((pool_concat_k<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const T*)patch,
+                                                (const T*)tokens, (T*)dst, B, L, C));
+}
+
 // ---- the NCHW reshape scramble + ln_vision (blip2_qformer.py:469, blip2.py:199-205) ----------------------------------
 // The projector output is produced NHWC ([B][P][C]); the reference reshapes its NCHW tensor [B][C][P] to [B][P][C] without a
 // permute, so token row r, column c is flat element f = r*C + c of the [C][P] matrix: channel f / P, position f % P.

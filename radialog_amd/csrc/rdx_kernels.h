@@ -87,6 +87,10 @@ void launch_attn_oproj(int dtype, const DecAttnArgs& a, const GemmArgs& g, int B
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s);
 void launch_layernorm(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* out_f32,
                       int rows, int H, float eps, hipStream_t s);
+void launch_layernorm_ex(int dtype, const void* x, long ldx, const float* gamma, const float* beta, const void* emb, int emb_rows,
+                         void* out, long ldo, int rows, int H, float eps, hipStream_t s);
+void launch_pool_gather(int dtype, const void* src, void* dst, int B, int L, int C, hipStream_t s);
+void launch_pool_concat(int dtype, const void* patch, const void* tokens, void* dst, int B, int L, int C, hipStream_t s);
 void launch_scramble_layernorm(int dtype, const void* pp_nhwc, const float* gamma, const float* beta, void* out,
                                float* out_f32, int B, int P, int C, float eps, hipStream_t s);
 void launch_img_prep(int dtype, const float* img, void* out, int B, int S, int pad, int Hp, int Wp, hipStream_t s);

@@ -96,8 +96,9 @@ class RdxEngine:
         self._finalized = True
 
     # ------------------------------------------------------------------------------------------------------------
-    def encode_image(self, image: torch.Tensor, want_image_embeds: bool = True):
-        """image float32[B,3,S,S] on this device -> (qformer_out f32[B,nq,Hq], image_embeds f32[B,P,C] or None)."""
+    def encode_image(self, image: torch.Tensor, want_image_embeds: bool = True, previous_image: Optional[torch.Tensor] = None):
+        """image float32[B,3,S,S] on this device -> (qformer_out f32[B,nq,Hq], image_embeds f32[B,P,C] or None).
+        `previous_image` (same shape) selects the BioViL-T two-image branch (ViT pooler difference features)."""
         v, q = self.cfg.vision, self.cfg.qformer
         if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != v.img or image.shape[3] != v.img:
             raise ValueError(f"expected image [B,3,{v.img},{v.img}], got {tuple(image.shape)}")
@@ -105,8 +106,16 @@ class RdxEngine:
         B = image.shape[0]
         out = torch.empty(B, q.n_query, q.hidden, dtype=torch.float32, device=self.device)
         emb = torch.empty(B, v.n_patches, v.proj, dtype=torch.float32, device=self.device) if want_image_embeds else None
+        prev = None
+        if previous_image is not None:
+            if previous_image.shape != image.shape:
+                raise AssertionError("current_image and previous_image shapes do not match")     # biovil_t/encoder.py:118
+            prev = previous_image.to(device=self.device, dtype=torch.float32).contiguous()
         torch.cuda.synchronize(self.device)
-        check(self.ctx, self.lib.rdx_encode_image(self.ctx, _ptr(image), B, _ptr(out), _ptr(emb)), "rdx_encode_image")
+        if prev is None:
+            check(self.ctx, self.lib.rdx_encode_image(self.ctx, _ptr(image), B, _ptr(out), _ptr(emb)), "rdx_encode_image")
+        else:
+            check(self.ctx, self.lib.rdx_encode_image2(self.ctx, _ptr(image), _ptr(prev), B, _ptr(out), _ptr(emb)), "rdx_encode_image2")
         self.sync()
         return out, emb
 

@@ -116,6 +116,23 @@ def vision_specs(v: VisionCfg) -> Dict[str, Spec]:
     E = "visual_encoder.encoder."
     sp[E + "backbone_to_vit.weight"] = ((v.b2v, v.trunk_out, 1, 1), _w(math.sqrt(1.0 / v.trunk_out)))
     sp[E + "missing_previous_emb"] = ((1, v.b2v, 1, 1), _w(0.5))
+    Pp = E + "vit_pooler."                                   # two-image mode (biovil_t/transformer.py:28-65,:137-224)
+    C = v.b2v
+    for i in range(v.pool_blocks):
+        Bk = f"{Pp}blocks.{i}."
+        for nm in ("norm1", "norm2"):
+            sp[Bk + nm + ".weight"] = ((C,), _u(0.8, 1.2))
+            sp[Bk + nm + ".bias"] = ((C,), _u(-0.1, 0.1))
+        for nm in ("proj_q", "proj_k", "proj_v"):
+            sp[Bk + f"attn.{nm}.weight"] = ((C, C), _w(math.sqrt(1.0 / C)))
+        sp[Bk + "attn.proj.weight"] = ((C, C), _w(math.sqrt(1.0 / C)))
+        sp[Bk + "attn.proj.bias"] = ((C,), _u(-0.05, 0.05))
+        for nm in ("fc1", "fc2"):
+            sp[Bk + f"mlp.{nm}.weight"] = ((C, C), _w(math.sqrt(1.0 / C)))
+            sp[Bk + f"mlp.{nm}.bias"] = ((C,), _u(-0.05, 0.05))
+    sp[Pp + "norm_post.weight"] = ((C,), _u(0.8, 1.2))
+    sp[Pp + "norm_post.bias"] = ((C,), _u(-0.1, 0.1))
+    sp[Pp + "type_embed"] = ((2, 1, C), _w(0.2))
     J = "visual_encoder.projector.model."
     sp[J + "0.weight"] = ((v.proj, 2 * v.b2v, 1, 1), _w(math.sqrt(2.0 / (2 * v.b2v))))
     bn(J + "1", v.proj)

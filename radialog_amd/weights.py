@@ -69,10 +69,57 @@ def vision_items(get: Getter, v: VisionCfg) -> Iterator[Item]:
     bias = (const - get(J + "1.running_mean")) * scale + get(J + "1.bias")
     yield "v.proj1.w", (w0[:, : v.b2v] * scale[:, None]).contiguous(), RDX_W_GEMM
     yield "v.proj1.b", bias.view(1, -1), RDX_W_F32
+    # optional two-image mode (VisionTransformerPooler, biovil_t/transformer.py:28-224): only when its weights are present
+    Pp = E + "vit_pooler."
+    try:
+        te = get(Pp + "type_embed")
+    except KeyError:
+        te = None
+    if te is not None:
+        Cv, g = v.b2v, v.grid
+        pos = sine_pos_embed(g, Cv)[0].to(te.device)                      # [P, C]; pos_embed is a non-persistent buffer
+        yield "v.pool.emb", torch.cat([pos + te[0], pos + te[1]], 0).contiguous(), RDX_W_TENSOR
+        for i in range(v.pool_blocks):
+            Bk, o = f"{Pp}blocks.{i}.", f"v.pool.{i}."
+            yield o + "n1_g", get(Bk + "norm1.weight").view(1, -1), RDX_W_F32
+            yield o + "n1_b", get(Bk + "norm1.bias").view(1, -1), RDX_W_F32
+            yield o + "n2_g", get(Bk + "norm2.weight").view(1, -1), RDX_W_F32
+            yield o + "n2_b", get(Bk + "norm2.bias").view(1, -1), RDX_W_F32
+            yield o + "wqkv", torch.cat([get(Bk + f"attn.proj_{n}.weight") for n in "qkv"], 0).contiguous(), RDX_W_GEMM
+            yield o + "wo", get(Bk + "attn.proj.weight"), RDX_W_GEMM
+            yield o + "bo", get(Bk + "attn.proj.bias").view(1, -1), RDX_W_F32
+            yield o + "w1", get(Bk + "mlp.fc1.weight"), RDX_W_GEMM
+            yield o + "b1", get(Bk + "mlp.fc1.bias").view(1, -1), RDX_W_F32
+            yield o + "w2", get(Bk + "mlp.fc2.weight"), RDX_W_GEMM
+            yield o + "b2", get(Bk + "mlp.fc2.bias").view(1, -1), RDX_W_F32
+        yield "v.pool.norm_g", get(Pp + "norm_post.weight").view(1, -1), RDX_W_F32
+        yield "v.pool.norm_b", get(Pp + "norm_post.bias").view(1, -1), RDX_W_F32
+        # projector conv-1 over the real [patch_x | diff_x] channels: BN folded, nothing constant to fold
+        yield "v.proj1f.w", (w0 * scale[:, None]).contiguous(), RDX_W_GEMM
+        yield "v.proj1f.b", (get(J + "1.bias") - get(J + "1.running_mean") * scale).view(1, -1), RDX_W_F32
     yield "v.proj2.w", get(J + "3.weight").reshape(v.proj, v.proj).contiguous(), RDX_W_GEMM
     yield "v.proj2.b", get(J + "3.bias").view(1, -1), RDX_W_F32
     yield "v.ln.g", get("ln_vision.weight").view(1, -1), RDX_W_F32
     yield "v.ln.b", get("ln_vision.bias").view(1, -1), RDX_W_F32
+
+
+def sine_pos_embed(grid: int, dim: int, temperature: float = 10000.0) -> torch.Tensor:
+    """SinePositionEmbedding(embedding_dim=dim//2, normalize=True) over an all-ones grid mask
+    (biovil_t/transformer.py:63-65,:248-266) -> [1, grid*grid, dim], built with the same torch ops."""
+    import math
+    npf = dim // 2
+    ones = torch.ones(1, grid, grid)
+    y = ones.cumsum(1, dtype=torch.float32)
+    x = ones.cumsum(2, dtype=torch.float32)
+    y = y / (y[:, -1:, :] + 1e-6) * (2 * math.pi)
+    x = x / (x[:, :, -1:] + 1e-6) * (2 * math.pi)
+    dim_t = torch.arange(npf, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / npf)
+    px = x[:, :, :, None] / dim_t
+    py = y[:, :, :, None] / dim_t
+    px = torch.stack((px[:, :, :, 0::2].sin(), px[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    py = torch.stack((py[:, :, :, 0::2].sin(), py[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    return torch.cat((py, px), dim=3).view(1, grid * grid, dim)
 
 
 def qformer_items(get: Getter, q: QFormerCfg) -> Iterator[Item]:

@@ -65,6 +65,20 @@ def test_encode_image_matches_oracle(engine, cfg, cpu_w):
     assert _rel_l2(q.cpu(), ref_q) < tol, "Q-Former last_hidden_state"
 
 
+def test_two_image_mode_vit_pooler_matches_oracle(engine, cfg, cpu_w):
+    """Optional BioViL-T two-image branch: both images through the trunk, ViT pooler difference features, full projector."""
+    from oracle import ref_cpu
+    img = synth.synth_images(2, cfg.vision.img)
+    prev = synth.synth_images(2, cfg.vision.img, seed=77)
+    with torch.no_grad():
+        ref_q, ref_emb = ref_cpu.forward_image(img, cpu_w, cfg, previous=prev)
+        single_q, _ = ref_cpu.forward_image(img, cpu_w, cfg)
+    q, emb = engine.encode_image(img.to(engine.device), previous_image=prev.to(engine.device))
+    tol = ENC_TOL[engine.dtype]
+    assert _rel_l2(emb.cpu(), ref_emb) < tol and _rel_l2(q.cpu(), ref_q) < tol
+    assert _rel_l2(q.cpu(), single_q) > 0.1                 # and it really is a different function of the inputs
+
+
 def _prompt(cfg, B, T, seed):
     ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, pad_rows=False, seed=seed)
     if B > 1:                                  # left-pad row 1 by 5 (pad id 0), keep 32 <IMG> inside

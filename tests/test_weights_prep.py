@@ -28,6 +28,7 @@ def test_vision_and_qformer_engine_tensors_reproduce_oracle():
     Wt = synth.make_weights({**synth.vision_specs(v), **synth.qformer_specs(q)})
     get = Wt.__getitem__
     E = _items(W.vision_items(get, v))
+    assert torch.equal(W.sine_pos_embed(v.grid, v.b2v), ref_cpu.sine_pos_embed(v.grid, v.b2v))
     E.update(_items(W.qformer_items(get, q)))
     B = 2
     img = synth.synth_images(B, v.img)
