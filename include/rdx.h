@@ -95,8 +95,14 @@ int rdx_hidden_read(rdx_ctx* ctx, void* dst /*model dtype [B][hidden]: decoder o
 /* average duration (ms) of one hot-path unit, measured with HIP events on the context's stream:
  *   what = 0: one decode step (whole graph) at the current state, `iters` replays
  *   what = 1: the gate/up SwiGLU weight-streaming GEMV of every layer in turn, `iters` sweeps -> ms per launch
- *   what = 2: ... the QKV GEMV, 3: o_proj, 4: down_proj, 5: lm_head */
+ *   what = 2: ... the QKV GEMV, 3: o_proj, 4: down_proj, 5: lm_head, 6: decode attention (re-appends the current KV row);
+ *   what + 10: the same unit on layer 0 only (weights stay cache resident) */
 int rdx_time(rdx_ctx* ctx, int what, int iters, float* ms_host);
+/* debug (RDX_MEGA only): one eager decode step of the chained decode-layer kernel with per-workgroup timestamps,
+ * host[wg*4 + 0..3] = {start, inputs ready, end (100 MHz ticks), role}; the caller sizes `host` for max_wgs entries */
+int rdx_mega_trace(rdx_ctx* ctx, long long* host, int max_wgs);
+/* debug: 8 timestamps (100 MHz ticks) of workgroup (0,0) of the stand-alone decode-attention kernel of `layer` */
+int rdx_attn_trace(rdx_ctx* ctx, int layer, long long* host);
 
 /* one bare GEMM through the production kernels: out = epilogue(X . W^T); X/resid/norm_w/out model dtype, W [N][K] and
  * bias fp32. epi: 0 none, 1 relu, 2 gelu, 3 +resid, 4 swiglu(interleaved gate/up rows), 6 relu(+resid).

@@ -63,6 +63,8 @@ SYMBOLS = {
     "rdx_kv_read": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "rdx_hidden_read": (C.c_int, [_P, _P]),
     "rdx_time": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "rdx_mega_trace": (C.c_int, [_P, _P, C.c_int]),
+    "rdx_attn_trace": (C.c_int, [_P, C.c_int, _P]),
     "rdx_gemm_test": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_int]),
 }
 

@@ -85,6 +85,12 @@ struct rdx_ctx {
     int32_t* cur_tokens = nullptr;
     hipGraphExec_t graph = nullptr;
     bool fuse_attn_oproj = false;    // RDX_FUSE_AO=1: attention + o_proj in one launch with a flag hand-off (measured: no gain at B=1)
+    int use_mega = 0;                // RDX_MEGA=n: chained decode-layer kernel (mega.hip), n layers per launch (0 = off, -1 = all)
+    int mega_naps = 1;               // RDX_MEGA_NAPS: poll back-off
+    int mega_occ = 8;                // RDX_MEGA_OCC: 8 = two workgroups per CU, 4 = one
+    void* d_cur_rope = nullptr;      // [B][2][128] cos | sin row of each row's current position (written by greedy_step_k)
+    MegaLayer* d_mlayers = nullptr; int* d_mctr = nullptr;
+    long long* d_mtrace = nullptr;   // set only during rdx_mega_trace
     int *d_ctr = nullptr, *d_err = nullptr;   // per-layer hand-off counters of the fused launch, sticky error flag
     bool use_dma_gemm = true;        // RDX_DMA=0: route every large-M GEMM through tiled_gemm_k
     float* gemm_ws = nullptr; size_t gemm_ws_floats = 0;      // split-K slabs of gemm_dma_k
@@ -195,6 +201,9 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
     c->cfg = *cfg;
     c->device = device_id;
     if (const char* e = getenv("RDX_FUSE_AO")) c->fuse_attn_oproj = atoi(e) != 0;
+    if (const char* e = getenv("RDX_MEGA")) c->use_mega = atoi(e);
+    if (const char* e = getenv("RDX_MEGA_NAPS")) c->mega_naps = atoi(e);
+    if (const char* e = getenv("RDX_MEGA_OCC")) c->mega_occ = atoi(e) == 4 ? 4 : 8;
     if (const char* e = getenv("RDX_DMA")) c->use_dma_gemm = atoi(e) != 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
@@ -335,12 +344,28 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         c->kv_layer_elems = (size_t)B * f.heads * f.max_len * 128;
         ALLOC(c, c->kcache, c->kv_layer_elems * f.layers * 2);
         ALLOC(c, c->vcache, c->kv_layer_elems * f.layers * 2);
+        // zero-initialised: decode attention multiplies never-written rows by P = 0 (any finite value is fine, NaN bits are not)
+        HIPCHK(c, hipMemset(c->kcache, 0, c->kv_layer_elems * f.layers * 2));
+        HIPCHK(c, hipMemset(c->vcache, 0, c->kv_layer_elems * f.layers * 2));
         ALLOC(c, c->key_mask, (size_t)B * f.max_len);
+        HIPCHK(c, hipMemset(c->key_mask, 0, (size_t)B * f.max_len));
         ALLOC(c, c->d_img_pos, B * sizeof(int)); ALLOC(c, c->d_pos, B * sizeof(int)); ALLOC(c, c->d_slot, B * sizeof(int));
         ALLOC(c, c->d_step, B * sizeof(int)); ALLOC(c, c->d_unf, B * sizeof(int));
-        ALLOC(c, c->d_ctr, f.layers * sizeof(int)); ALLOC(c, c->d_err, sizeof(int));
-        HIPCHK(c, hipMemset(c->d_ctr, 0, f.layers * sizeof(int)));
+        ALLOC(c, c->d_ctr, (size_t)f.layers * 128 * sizeof(int)); ALLOC(c, c->d_err, sizeof(int));   // 8 shards x 64 B per layer
+        HIPCHK(c, hipMemset(c->d_ctr, 0, (size_t)f.layers * 128 * sizeof(int)));
         HIPCHK(c, hipMemset(c->d_err, 0, sizeof(int)));
+        {
+            std::vector<MegaLayer> ml(f.layers);
+            for (int l = 0; l < f.layers; ++l) {
+                const LlamaLayer& L = c->ll[l];
+                ml[l] = MegaLayer{L.wqkv.w, L.wo.w, L.wgu.w, L.wdown.w, L.attn_norm, L.mlp_norm, L.lora_bq, L.lora_bv,
+                                  (char*)c->kcache + (size_t)l * c->kv_layer_elems * 2, (char*)c->vcache + (size_t)l * c->kv_layer_elems * 2};
+            }
+            ALLOC(c, c->d_mlayers, ml.size() * sizeof(MegaLayer));
+            HIPCHK(c, hipMemcpy(c->d_mlayers, ml.data(), ml.size() * sizeof(MegaLayer), hipMemcpyHostToDevice));
+            ALLOC(c, c->d_mctr, mega_ctr_ints(f.layers) * sizeof(int));
+        }
+        ALLOC(c, c->d_cur_rope, (size_t)B * 256 * 2);
         ALLOC(c, c->d_pos_ids, (size_t)B * f.max_len * sizeof(int));
         c->n_vtiles = c->lm_head.Npad / 16;
         ALLOC(c, c->part_val, (size_t)B * c->n_vtiles * sizeof(float));
@@ -601,7 +626,7 @@ static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, c
     skinny(c, a, EPI_LOGITS);
     launch_greedy_step(f.dtype, c->part_val, c->part_idx, c->n_vtiles, B, c->cur_eos, c->cur_pad, c->cur_max_new,
                        c->cur_tokens, c->d_unf, advance ? c->d_pos : nullptr, advance ? c->d_slot : nullptr, c->d_step,
-                       c->embed, f.vocab, c->dx, f.hidden, c->stream);
+                       c->embed, f.vocab, c->dx, f.hidden, c->d_pos, c->rope_cos, c->rope_sin, c->d_cur_rope, c->stream);
 }
 
 extern "C" int rdx_prefill(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int T, const float* qformer_embs,
@@ -660,19 +685,34 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
     const rdx_config& f = c->cfg;
     const int dt = f.dtype, H = f.hidden, B = c->cur_B;
     hipStream_t s = c->stream;
-    if (c->fuse_attn_oproj) hipMemsetAsync(c->d_ctr, 0, (size_t)f.layers * sizeof(int), s);   // hand-off counters, once per step
+    if (c->use_mega && mega_supported(c->ld, f.inter, B)) {
+        hipMemsetAsync(c->d_mctr, 0, mega_ctr_ints(f.layers) * sizeof(int), s);   // hand-off counters, once per step
+        MegaArgs ma;
+        memset(&ma, 0, sizeof(ma));
+        ma.layers = c->d_mlayers; ma.d = c->ld; ma.inter = f.inter; ma.qkv_n = c->ll[0].wqkv.Npad; ma.B = B; ma.eps = f.rms_eps;
+        ma.dx = c->dx; ma.dqkv = c->dqkv; ma.datt = c->datt; ma.dgu = c->dgu; ma.cos_t = c->rope_cos; ma.sin_t = c->rope_sin;
+        ma.cur_rope = c->d_cur_rope; ma.pos = c->d_pos; ma.slot_b = c->d_slot; ma.key_mask = c->key_mask; ma.ctr = c->d_mctr; ma.err = c->d_err; ma.naps = c->mega_naps; ma.trace = c->d_mtrace;
+        const int per = c->use_mega < 0 ? f.layers : c->use_mega;
+        for (int l0 = 0; l0 < f.layers; l0 += per) {
+            ma.layer0 = l0;
+            launch_decode_layers(dt, ma, std::min(per, f.layers - l0), c->mega_occ, s);
+        }
+        lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
+        return;
+    }
+    if (c->fuse_attn_oproj) hipMemsetAsync(c->d_ctr, 0, (size_t)f.layers * 128 * sizeof(int), s);   // hand-off counter shards, once per step
     for (int l = 0; l < f.layers; ++l) {
         const LlamaLayer& L = c->ll[l];
         { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps;
           skinny(c, a, EPI_NONE); }
         DecAttnArgs at;
         at.d = c->ld; at.qkv = c->dqkv; at.lbq = L.lora_bq; at.lbv = L.lora_bv; at.cos_t = c->rope_cos; at.sin_t = c->rope_sin;
-        at.pos = c->d_pos; at.slot_b = c->d_slot; at.key_mask = c->key_mask;
+        at.pos = c->d_pos; at.slot_b = c->d_slot; at.key_mask = c->key_mask; at.cur_rope = c->d_cur_rope;
         at.kcache = kv_ptr(c, c->kcache, l); at.vcache = kv_ptr(c, c->vcache, l); at.out = c->datt;
         GemmArgs ao = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B);
         ao.resid = c->dx; ao.ldr = H;
         if (c->fuse_attn_oproj && (L.wo.N + 15) / 16 <= 256) {
-            launch_attn_oproj(dt, at, ao, B, c->d_ctr + l, c->d_err, s);
+            launch_attn_oproj(dt, at, ao, B, c->d_ctr + (size_t)l * 128, c->d_err, s);
         } else {
             launch_decode_attention(dt, at, B, s);
             skinny(c, ao, EPI_RESID);
@@ -682,6 +722,46 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; skinny(c, a, EPI_RESID); }
     }
     lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
+}
+
+// Debug: run ONE eager decode step through the chained decode-layer kernel with per-workgroup timestamps and copy
+// them out: host[wg*4 + {0,1,2,3}] = {start, inputs ready, end (100 MHz ticks), role}. 
+extern "C" int rdx_mega_trace(rdx_ctx* c, long long* host, int max_wgs) {
+    if (!c || !c->finalized || c->cur_B <= 0 || !host) return fail(c, -1, "rdx_mega_trace: run a prefill first");
+    if (!c->use_mega || !mega_supported(c->ld, c->cfg.inter, c->cur_B)) return fail(c, -1, "rdx_mega_trace: chained kernel not enabled (RDX_MEGA) or unsupported shape");
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)max_wgs * 4 * sizeof(long long);
+    HIPCHK(c, hipMalloc(&c->d_mtrace, bytes));
+    HIPCHK(c, hipMemsetAsync(c->d_mtrace, 0, bytes, c->stream));
+    decode_step_launch(c, nullptr, nullptr, 0);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(host, c->d_mtrace, bytes, hipMemcpyDeviceToHost);
+    hipFree(c->d_mtrace);
+    c->d_mtrace = nullptr;
+    HIPCHK(c, e);
+    return 0;
+}
+
+// Debug: the stand-alone decode-attention kernel of layer `layer` at the current state, 8 timestamps of workgroup (0,0):
+// host[0..6] = after slot load, inputs ready, new token done, barrier 1, scores + barrier, softmax, PV + barrier; [7] = entry.
+extern "C" int rdx_attn_trace(rdx_ctx* c, int layer, long long* host) {
+    if (!c || !c->finalized || c->cur_B <= 0 || !host) return fail(c, -1, "rdx_attn_trace: run a prefill first");
+    HIPCHK(c, hipSetDevice(c->device));
+    long long* dtr = nullptr;
+    HIPCHK(c, hipMalloc(&dtr, 8 * sizeof(long long)));
+    HIPCHK(c, hipMemsetAsync(dtr, 0, 8 * sizeof(long long), c->stream));
+    const LlamaLayer& L = c->ll[layer];
+    DecAttnArgs at;
+    at.d = c->ld; at.qkv = c->dqkv; at.lbq = L.lora_bq; at.lbv = L.lora_bv; at.cos_t = c->rope_cos; at.sin_t = c->rope_sin;
+    at.pos = c->d_pos; at.slot_b = c->d_slot; at.key_mask = c->key_mask; at.cur_rope = c->d_cur_rope;
+    at.kcache = kv_ptr(c, c->kcache, layer); at.vcache = kv_ptr(c, c->vcache, layer); at.out = c->datt;
+    at.trace = dtr;
+    launch_decode_attention(c->cfg.dtype, at, c->cur_B, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(host, dtr, 8 * sizeof(long long), hipMemcpyDeviceToHost);
+    hipFree(dtr);
+    HIPCHK(c, e);
+    return 0;
 }
 
 extern "C" int rdx_decode_step(rdx_ctx* c, void* logits) {
@@ -750,7 +830,7 @@ extern "C" int rdx_generate(rdx_ctx* c, const int32_t* ids, const int32_t* mask,
     HIPCHK(c, hipMemcpy(&herr, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
     if (herr) {
         hipMemset(c->d_err, 0, sizeof(int));
-        return fail(c, -5, "rdx_generate: attention->o_proj hand-off timed out inside the fused launch (results invalid)");
+        return fail(c, -5, "rdx_generate: a workgroup hand-off timed out inside a fused/chained launch (results invalid)");
     }
     return 0;
 }
@@ -812,6 +892,13 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
                 else if (what == 2) { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps; skinny(c, a, EPI_NONE); }
                 else if (what == 3) { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dqkv, H, B); skinny(c, a, EPI_NONE); }
                 else if (what == 4) { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); skinny(c, a, EPI_NONE); }
+                else if (what == 6) {   // decode attention at the current slot (re-appends the same KV row: idempotent)
+                    DecAttnArgs at;
+                    at.d = c->ld; at.qkv = c->dqkv; at.lbq = L.lora_bq; at.lbv = L.lora_bv; at.cos_t = c->rope_cos; at.sin_t = c->rope_sin;
+                    at.pos = c->d_pos; at.slot_b = c->d_slot; at.key_mask = c->key_mask; at.cur_rope = c->d_cur_rope;
+                    at.kcache = kv_ptr(c, c->kcache, same_layer ? 0 : l); at.vcache = kv_ptr(c, c->vcache, same_layer ? 0 : l); at.out = c->datt;
+                    launch_decode_attention(dt, at, B, c->stream);
+                }
                 else return fail(c, -1, "rdx_time: unknown unit %d", what);
                 ++launches;
             }

@@ -246,7 +246,9 @@ constexpr int DA_WAVES_TP = 4;     // throughput variant: >= 256 pairs, 4 workgr
 template <typename T, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void decode_attention_k(DecAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
-    decode_attention_body<T, WAVES, false>(a, blockIdx.x, blockIdx.y, dsm);
+    // latency variant: wave 0 is dedicated to the new token (its operand loads are first in its queue), 15 waves own the cache
+    if (WAVES == 16) decode_attention_body<T, WAVES, true, NoWait, true>(a, blockIdx.x, blockIdx.y, dsm);
+    else decode_attention_body<T, WAVES, false>(a, blockIdx.x, blockIdx.y, dsm);
 }
 
 void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s) {

@@ -1,20 +1,27 @@
 // Body of decode attention (one new token per batch row) as a device function: runs as its own kernel
-// (attn.hip: decode_attention_k, 16 waves) or as the producer role of the fused attention + o_proj launch (fused.hip,
-// 8 waves). head_dim 128: one K/V cache row = 256 B = 16 lanes x 16 B.
+// (attn.hip: decode_attention_k, 16 or 4 waves), as the producer role of the fused attention + o_proj launch
+// (fused.hip, 8 waves) or as a role of the chained decode-layer kernel (mega.hip). head_dim 128: one K/V cache row =
+// 256 B.
 //
-// The cache is small per head (L x 256 B for K and for V), so the work is latency-bound and is organised around three
-// workgroup barriers only:
-//   * every lane issues ALL its cached K row loads up front (position j -> 16 lanes; PRE x WAVES*4 positions are
-//     held in registers, later positions by a second, plain loop); V rows follow as soon as registers allow;
-//   * wave 0 alone handles the new token in registers -- LoRA-B add (peft un-merged), rotate-half RoPE (the partner
-//     d+-64 lives in lane^8), append to the cache -- and publishes q through LDS;
-//   * scores go to LDS once; every wave recomputes the softmax statistics itself (wave shuffles, no block
-//     reduction) and applies the rounded probabilities to its V registers.
+// One workgroup owns one (batch row, head). The cache is small (L x 256 B for K and for V), so the work is latency- and
+// issue-bound on ONE CU, and it is organised to keep both the dependent-load chain and the VALU instruction count short:
+//   * every lane issues ALL its cache loads up front -- K as MFMA A-operand fragments (16 positions x 32 dims per
+//     wave-wide 16-byte load, KG groups of 16 positions per wave), V as rows (VR = 4*KG rows per lane), the key-mask bytes
+//     -- none of these addresses depends on `slot` (rows past it are simply unused);
+//   * wave 0 alone handles the new token in registers: LoRA-B add (peft un-merged), rotate-half RoPE (partner d+-64 =
+//     lane^8 via DPP), append to the cache, publish q (model dtype) through LDS. The cos/sin row comes from the per-row
+//     copy the greedy-step kernel left behind, so there is no position -> table dependent load;
+//   * scores = K . q on the matrix cores: A = 16 cached positions x 32 dims, B = q replicated over the 16 columns, so
+//     after 4 MFMAs a lane holds the finished scores of 4 positions -- no unpacking, no cross-lane reduction;
+//   * every wave recomputes the softmax statistics itself (DPP / readlane reductions, no block reduction);
+//   * P is computed ONCE per cached row (lane `u` of each 16-lane row owns row u) and broadcast inside the row by DPP
+//     row_share; P.V uses v_dot2 on (row u, row u+1) pairs, i.e. one permute + one dot per two MACs.
 // Rounding points are the reference's (modeling_llama_imgemb.py:135-142,:198-234): q/k/v in T, T(T(q.k)/sqrt(d)),
 // fp32 softmax, P rounded to T before PV, output rounded to T.
 #pragma once
 #include "rdx_common.h"
 #include "rdx_kernels.h"
+#include "handoff.h"
 
 namespace rdx {
 
@@ -26,17 +33,31 @@ __device__ __forceinline__ float rope_one(float x, float partner_signed, float c
 
 __host__ __device__ inline size_t decode_attention_smem_floats(int waves, int max_len) { return (size_t)waves * 128 + 128 + max_len; }
 
-template <typename T, int WAVES, bool DED = (WAVES == 8)>
-__device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, const int h, const int b, float* dsm) {
+template <int N> __device__ __forceinline__ float row_share(float v) { return dpp_mov<0x150 + N>(v); }   // lane N of each 16-lane row
+
+// a.x*b.x + a.y*b.y + c on packed model-dtype pairs (v_dot2c_f32_bf16 / v_dot2c_f32_f16)
+template <typename T> __device__ __forceinline__ float dot2(unsigned a, unsigned b, float c);
+template <> __device__ __forceinline__ float dot2<bf16>(unsigned a, unsigned b, float c) {
+    typedef __bf16 v2b __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(v2b, a), __builtin_bit_cast(v2b, b), c, false);
+}
+template <> __device__ __forceinline__ float dot2<f16>(unsigned a, unsigned b, float c) {
+    typedef _Float16 v2h __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, a), __builtin_bit_cast(v2h, b), c, false);
+}
+
+template <typename T, int WAVES, bool DED = (WAVES == 8), typename WaitFn = NoWait, bool V_EARLY_ = !DED, int KG_ = 0, bool COH = false>
+__device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, const int h, const int b, float* dsm,
+                                                      WaitFn wait_inputs = WaitFn()) {
     typedef typename Vec8<T>::type V8;
     constexpr int D = 128;
-    // 8-wave variant (fused launch, 128-VGPR cap): wave 0 is dedicated to the new token and holds no cache rows, so its
-    // register-hungry LoRA/RoPE block never overlaps a live K window; waves 1..7 own the cache rows.
+    // DED (register-tight launches): wave 0 is dedicated to the new token and holds no cache rows, so its register-hungry
+    // LoRA/RoPE block never overlaps a live K window; waves 1.. own the cache rows.
     constexpr int CW = DED ? WAVES - 1 : WAVES;  // waves that own cache rows
-    constexpr int SPAN = CW * 4;                 // positions covered by one block-wide load
-    constexpr int PRE = DED ? 14 : 8;            // register-resident rows per lane: 512 positions at 16 waves, 392 at 8,
-                                                 // 128 at 4 waves (throughput variant for large batches; the rest streams)
-    constexpr bool V_EARLY = !DED;               // enough registers to have K and V in flight together
+    constexpr int KG = KG_ ? KG_ : ((DED && WAVES == 8) ? 4 : 2);   // K groups (16 positions) per wave held in registers
+    constexpr int VR = 4 * KG;                   // V rows per lane held in registers (same coverage: KG*CW*16 positions)
+    constexpr int SPAN = CW * 4;                 // positions covered by one block-wide V row sweep
+    constexpr bool V_EARLY = V_EARLY_;           // enough registers to have K and V in flight together
     const LlamaDims& d = a.d;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
     const T* lbq = reinterpret_cast<const T*>(a.lbq);
@@ -45,134 +66,186 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
     const T* sin_t = reinterpret_cast<const T*>(a.sin_t);
 
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float* part = dsm;                    // [WAVES][D]
-    float* qf = dsm + WAVES * D;          // [D] rotated query
-    float* S = dsm + WAVES * D + D;       // [max_len]
+    float* part = dsm;                                   // [WAVES][D]
+    T* qT = reinterpret_cast<T*>(dsm + WAVES * D);       // [D] rotated query, model dtype (MFMA B operand)
+    float* S = dsm + WAVES * D + D;                      // [max_len]
 
-    const int jsub = lane >> 4, doct = lane & 15;
+    const int jsub = lane >> 4, doct = lane & 15;        // V / new-token view: 16 lanes x 8 dims per cache row
+    const int g = lane >> 4, r = lane & 15;              // K view (MFMA A fragment): position r of the group, dims 32*c + 8*g
     const int H = d.hidden;
     const T* x = qkv + (size_t)b * d.qkv_ld;
     T* kc = reinterpret_cast<T*>(a.kcache) + ((size_t)b * d.heads + h) * d.max_len * D;
     T* vc = reinterpret_cast<T*>(a.vcache) + ((size_t)b * d.heads + h) * d.max_len * D;
     const uint8_t* km = a.key_mask + (size_t)b * d.max_len;
 
-    // ---- cached K rows of this lane in flight first (addresses do not depend on `slot`: rows past it are simply unused)
+    if (a.trace && h == 0 && b == 0 && tid == 0) a.trace[7] = (long long)__builtin_amdgcn_s_memrealtime();   // entry
+    // ---- cache loads of this lane in flight first ------------------------------------------------------------------
     const int cw = DED ? w - 1 : w;              // cache-wave index (-1: the dedicated new-token wave)
     const bool owns_rows = !DED || w > 0;        // wave-uniform
-    u4 kr[PRE], vr[PRE];
-    auto load_k = [&]() {
+    u4 kr[KG][4], vr[VR];
+    unsigned kmw[KG];                            // key-mask bytes of positions gb + 4g .. +3
+    // The lower half of the register window is loaded unconditionally at kernel entry; the upper half only once `slot`
+    // is known and only by the waves whose rows exist (all of a head's cache traffic funnels through ONE CU's L1 at
+    // 64 B/clk, so a fully loaded 480-position window costs ~2 us whatever the context length).
+    constexpr int KG_LO = (KG + 1) / 2, VR_LO = 4 * KG_LO;
+    auto load_k = [&](int u0, int u1, int limit) {
 #pragma unroll
-        for (int u = 0; u < PRE; ++u) {
-            const int j = min(u * SPAN + cw * 4 + jsub, d.max_len - 1);
-            kr[u] = ldg16(kc + (size_t)j * D + doct * 8);
+        for (int u = 0; u < KG; ++u) {
+            const int gb = (u * CW + cw) * 16;
+            if (u >= u0 && u < u1 && gb < limit) {
+                const int j = min(gb + r, d.max_len - 1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) kr[u][c] = ldg16(kc + (size_t)j * D + c * 32 + g * 8);
+                kmw[u] = *reinterpret_cast<const unsigned*>(km + min(gb + 4 * g, d.max_len - 4));
+            }
         }
     };
-    if (!DED) load_k();                          // 16-wave variant: every wave, wave 0 included, owns rows
+    auto load_v = [&](int u0, int u1, int limit) {
+#pragma unroll
+        for (int u = 0; u < VR; ++u) {
+            if (u >= u0 && u < u1 && u * SPAN + cw * 4 < limit) {
+                const int j = min(u * SPAN + cw * 4 + jsub, d.max_len - 1);
+                vr[u] = ldg16(vc + (size_t)j * D + doct * 8);
+            }
+        }
+    };
+    // operands of the new token (wave 0 only; wave-uniform branches). Stand-alone launches issue them FIRST, ahead of every
+    // cache load of the workgroup; chained launches must wait for the producer and issue them after wait_inputs().
+    constexpr bool HAS_WAIT = !__is_same(WaitFn, NoWait);
+    const int n0 = h * D + doct * 8;
+    u4 nq, nk_, nv, ncos, nsin, naq, nav, nbq0, nbq1, nbv0, nbv1;
+    auto load_newtok = [&]() {
+        // COH (chained launches): the qkv row was published write-through by other workgroups of THIS launch -> read it
+        // with agent-scope loads (L1 bypass); everything else this kernel reads predates the launch
+        auto ldx = [&](const T* p) -> u4 {
+            if (!COH) return ldg16(p);
+            const unsigned long long lo = ld8_agent(p), hi = ld8_agent(p + 4);
+            return (u4){(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+        };
+        nq = ldx(x + n0); nk_ = ldx(x + H + n0); nv = ldx(x + 2 * H + n0);
+        // cos/sin row of this token's position: from the per-row copy greedy_step_k left behind (no pos -> table
+        // dependent load on the critical path), else from the tables
+        const T* cs = reinterpret_cast<const T*>(a.cur_rope);
+        const T* cp = cs ? cs + (size_t)b * 2 * D : cos_t + (size_t)a.pos[b] * D;
+        const T* sp = cs ? cs + (size_t)b * 2 * D + D : sin_t + (size_t)a.pos[b] * D;
+        ncos = ldg16(cp + doct * 8); nsin = ldg16(sp + doct * 8);
+        if (d.lora_r == 8) {
+            // The four jsub groups of the wave hold the same 8 dims; each takes two of the eight LoRA-B rows, so all
+            // B loads are ONE round trip (4 x 16 B per lane), and the deltas come back through shuffles.
+            const int e0 = 2 * jsub;
+            naq = ldx(x + 3 * H); nav = ldx(x + 3 * H + 8);
+            nbq0 = ldg16(lbq + (size_t)(n0 + e0) * 8); nbq1 = ldg16(lbq + (size_t)(n0 + e0 + 1) * 8);
+            nbv0 = ldg16(lbv + (size_t)(n0 + e0) * 8); nbv1 = ldg16(lbv + (size_t)(n0 + e0 + 1) * 8);
+        }
+    };
+    if (!HAS_WAIT && w == 0) load_newtok();
+    if (owns_rows) {
+        load_k(0, KG_LO, d.max_len);
+        if (V_EARLY) load_v(0, VR_LO, d.max_len);
+    }
     const int slot = a.slot_b[b];
     const int nk = slot + 1;
+    const int km_new = km[min(slot, d.max_len - 1)];   // mask byte of the new position, off the critical path
+    long long* trc = (a.trace && h == 0 && b == 0 && tid == 0) ? a.trace : nullptr;
+#define ATT_T(i) do { if (trc) trc[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+    ATT_T(0);
+    wait_inputs();      // chained launches: the cache loads are already in flight; block until this step's qkv row is published
+    ATT_T(1);
 
     // ---- new token (wave 0 only, in registers): LoRA add + RoPE for dims doct*8 .. +8 of this head -------------------
-    float k8[8], v8[8];
+    float q8n[8], k8[8], v8[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { k8[e] = 0.f; v8[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { q8n[e] = 0.f; k8[e] = 0.f; v8[e] = 0.f; }
     if (w == 0) {
-        const int n0 = h * D + doct * 8;
-        float q8n[8];
-        const int p = a.pos[b];
-        const V8 qv = as_vec8<T>(ldg16(x + n0)), kv = as_vec8<T>(ldg16(x + H + n0)), vv = as_vec8<T>(ldg16(x + 2 * H + n0));
-        const V8 cv = as_vec8<T>(ldg16(cos_t + (size_t)p * D + doct * 8)), sv_ = as_vec8<T>(ldg16(sin_t + (size_t)p * D + doct * 8));
+        if (HAS_WAIT) load_newtok();
+        const V8 qv = as_vec8<T>(nq), kv = as_vec8<T>(nk_), vv = as_vec8<T>(nv), cv = as_vec8<T>(ncos), sv_ = as_vec8<T>(nsin);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { q8n[e] = tof<T>(qv[e]); k8[e] = tof<T>(kv[e]); v8[e] = tof<T>(vv[e]); }
         if (d.lora_r == 8) {
-            const V8 aq = as_vec8<T>(ldg16(x + 3 * H)), av = as_vec8<T>(ldg16(x + 3 * H + 8));
-#pragma unroll 2
-            for (int e = 0; e < 8; ++e) {                        // partial unroll: stays inside the 128-VGPR budget
-                const V8 bq = as_vec8<T>(ldg16(lbq + (size_t)(n0 + e) * 8)), bv = as_vec8<T>(ldg16(lbv + (size_t)(n0 + e) * 8));
-                float sq = 0.f, sv = 0.f;
+            const V8 aq = as_vec8<T>(naq), av = as_vec8<T>(nav);
+            const V8 bq0 = as_vec8<T>(nbq0), bq1 = as_vec8<T>(nbq1), bv0 = as_vec8<T>(nbv0), bv1 = as_vec8<T>(nbv1);
+            float sq0 = 0.f, sq1 = 0.f, sv0 = 0.f, sv1 = 0.f;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { sq += tof<T>(bq[i]) * tof<T>(aq[i]); sv += tof<T>(bv[i]) * tof<T>(av[i]); }
-                q8n[e] = rnd<T>(q8n[e] + rnd<T>(rnd<T>(sq) * d.lora_scale));   // result += lora_B(lora_A(x)) * scaling
-                v8[e] = rnd<T>(v8[e] + rnd<T>(rnd<T>(sv) * d.lora_scale));
+            for (int i = 0; i < 8; ++i) {
+                sq0 += tof<T>(bq0[i]) * tof<T>(aq[i]); sq1 += tof<T>(bq1[i]) * tof<T>(aq[i]);
+                sv0 += tof<T>(bv0[i]) * tof<T>(av[i]); sv1 += tof<T>(bv1[i]) * tof<T>(av[i]);
+            }
+            sq0 = rnd<T>(rnd<T>(sq0) * d.lora_scale); sq1 = rnd<T>(rnd<T>(sq1) * d.lora_scale);   // lora_B(lora_A(x)) * scaling
+            sv0 = rnd<T>(rnd<T>(sv0) * d.lora_scale); sv1 = rnd<T>(rnd<T>(sv1) * d.lora_scale);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int src = ((e >> 1) << 4) | doct;
+                const float dq = __shfl((e & 1) ? sq1 : sq0, src, 64), dv = __shfl((e & 1) ? sv1 : sv0, src, 64);
+                q8n[e] = rnd<T>(q8n[e] + dq);                                   // result += delta
+                v8[e] = rnd<T>(v8[e] + dv);
             }
         }
         const bool lo = doct < 8;                                               // dims < 64: rotate_half gives -x[d+64]
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float qo = __shfl_xor(q8n[e], 8, 64), ko = __shfl_xor(k8[e], 8, 64);
+            const float qo = dpp_mov<DPP_ROR8>(q8n[e]), ko = dpp_mov<DPP_ROR8>(k8[e]);     // lane ^ 8 inside the 16-lane row
             const float c = tof<T>(cv[e]), sn = tof<T>(sv_[e]);
             q8n[e] = rope_one<T>(q8n[e], lo ? -qo : qo, c, sn);
             k8[e] = rope_one<T>(k8[e], lo ? -ko : ko, c, sn);
         }
         if (jsub == 0) {                                                        // publish q, append k / v to the cache
-            V8 ko, vo;
+            V8 qo, ko, vo;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { qf[doct * 8 + e] = q8n[e]; ko[e] = fromf<T>(k8[e]); vo[e] = fromf<T>(v8[e]); }
+            for (int e = 0; e < 8; ++e) { qo[e] = fromf<T>(q8n[e]); ko[e] = fromf<T>(k8[e]); vo[e] = fromf<T>(v8[e]); }
+            *reinterpret_cast<u4*>(qT + doct * 8) = as_u4<T>(qo);
             stg16(kc + (size_t)slot * D + doct * 8, as_u4<T>(ko));
             stg16(vc + (size_t)slot * D + doct * 8, as_u4<T>(vo));
         }
-    } else if (DED) {
-        load_k();                                // exclusive with the new-token block: the K window is never live inside it
     }
-    if (V_EARLY && owns_rows) {              // V rows in flight now: their latency hides under the scores and the softmax
-#pragma unroll
-        for (int u = 0; u < PRE; ++u) {
-            const int j = min(u * SPAN + cw * 4 + jsub, d.max_len - 1);
-            vr[u] = ldg16(vc + (size_t)j * D + doct * 8);
-        }
+    if (owns_rows) {                             // upper half of the window, now that the context length is known
+        load_k(KG_LO, KG, slot);
+        if (V_EARLY) load_v(VR_LO, VR, slot);
     }
+    ATT_T(2);
     __syncthreads();
-    float q8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) q8[e] = qf[doct * 8 + e];
+    ATT_T(3);
 
-    // ---- scores ---------------------------------------------------------------------------------------------------------
+    // ---- scores: S[j] = T(T(k_j . q) / sqrt(D)) on the matrix cores ----------------------------------------------------------
     const float div = sqrtf((float)D);
-    auto score_store = [&](int j, float acc) {
+    u4 qb[4];                                    // B operand: q[32c + 8g .. +8], the same in all 16 columns
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (doct == 0 && j < nk) {
-            const float sc = rnd<T>(rnd<T>(acc) / div);
-            S[j] = km[j] ? sc : -INFINITY;
+    for (int c = 0; c < 4; ++c) qb[c] = *reinterpret_cast<const u4*>(qT + c * 32 + g * 8);
+    auto score_group = [&](const u4 (&kf)[4], unsigned maskw, int gb) {     // wave-uniform call: MFMA ignores EXEC
+        v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc = mfma16(as_vec8<T>(kf[c]), as_vec8<T>(qb[c]), acc);
+        if (r == 0) {                            // lane (g, r): acc[i] = score of position gb + 4g + i (any column r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = gb + 4 * g + i;
+                if (j < slot) S[j] = ((maskw >> (8 * i)) & 0xffu) ? rnd<T>(rnd<T>(acc[i]) / div) : -INFINITY;
+            }
         }
     };
     if (owns_rows) {
 #pragma unroll
-        for (int u = 0; u < PRE; ++u) {
-            const int j = u * SPAN + cw * 4 + jsub;
-            float acc = 0.f;
-            if (j < slot) {
-                const V8 kv = as_vec8<T>(kr[u]);
+        for (int u = 0; u < KG; ++u)
+            if (u < KG_LO || (u * CW + cw) * 16 < slot) score_group(kr[u], kmw[u], (u * CW + cw) * 16);   // wave-uniform
+        if (!V_EARLY) { load_v(0, VR_LO, d.max_len); load_v(VR_LO, VR, slot); }      // K registers are free now
+        for (int gi = KG * CW + cw; gi * 16 < slot; gi += CW) {                 // contexts beyond the register window
+            const int gb = gi * 16;
+            const int j = min(gb + r, d.max_len - 1);
+            u4 kf[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc += q8[e] * tof<T>(kv[e]);
-            }
-            score_store(j < slot ? j : nk, acc);                                // one wave-wide call (shuffles inside)
-        }
-        if (!V_EARLY) {                                                         // K registers are free now
-#pragma unroll
-            for (int u = 0; u < PRE; ++u) {
-                const int j = min(u * SPAN + cw * 4 + jsub, d.max_len - 1);
-                vr[u] = ldg16(vc + (size_t)j * D + doct * 8);
-            }
+            for (int c = 0; c < 4; ++c) kf[c] = ldg16(kc + (size_t)j * D + c * 32 + g * 8);
+            const unsigned mw = *reinterpret_cast<const unsigned*>(km + min(gb + 4 * g, d.max_len - 4));
+            score_group(kf, mw, gb);
         }
     }
     if (w == 0) {                                                               // the new position itself
         float acc = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc += q8[e] * k8[e];
-        score_store(jsub == 0 ? slot : nk, acc);
-    }
-#pragma unroll 4
-    for (int j0 = PRE * SPAN; owns_rows && j0 < slot; j0 += SPAN) {             // contexts beyond the register window
-        const int j = j0 + cw * 4 + jsub;
-        float acc = 0.f;
-        if (j < slot) {
-            const V8 kv = as_vec8<T>(ldg16(kc + (size_t)j * D + doct * 8));
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc += q8[e] * tof<T>(kv[e]);
-        }
-        score_store(j < slot ? j : nk, acc);
+        for (int e = 0; e < 8; ++e) acc += q8n[e] * k8[e];
+        acc = row16_sum(acc);
+        if (lane == 0) S[slot] = km_new ? rnd<T>(rnd<T>(acc) / div) : -INFINITY;
     }
     __syncthreads();
+    ATT_T(4);
 
     // ---- softmax statistics (fp32), recomputed by every wave -------------------------------------------------------
     float mx = -INFINITY;
@@ -181,18 +254,45 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
     float sum = 0.f;
     for (int j = lane; j < nk; j += 64) sum += expf(S[j] - mx);
     sum = wave_sum(sum);
+    ATT_T(5);
 
     // ---- O = P V with P rounded to T ---------------------------------------------------------------------------------
     float o8[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o8[e] = 0.f;
     if (owns_rows) {
+        // lane `u` of each 16-lane row computes P of cached row u (once), the row fetches it by DPP row_share
+        float myp = 0.f;
+        {
+            const int j = doct * SPAN + cw * 4 + jsub;
+            if (doct < VR && j < slot) myp = rnd<T>(expf(S[j] - mx) / sum);
+        }
+        float pu[16];
+        pu[0] = row_share<0>(myp);   pu[1] = row_share<1>(myp);   pu[2] = row_share<2>(myp);   pu[3] = row_share<3>(myp);
+        pu[4] = row_share<4>(myp);   pu[5] = row_share<5>(myp);   pu[6] = row_share<6>(myp);   pu[7] = row_share<7>(myp);
+        pu[8] = row_share<8>(myp);   pu[9] = row_share<9>(myp);   pu[10] = row_share<10>(myp); pu[11] = row_share<11>(myp);
+        pu[12] = row_share<12>(myp); pu[13] = row_share<13>(myp); pu[14] = row_share<14>(myp); pu[15] = row_share<15>(myp);
 #pragma unroll
-        for (int u = 0; u < PRE; ++u) {
-            const int j = u * SPAN + cw * 4 + jsub;
+        for (int u = 0; u < VR; u += 2) {
+            if (u >= VR_LO && u * SPAN + cw * 4 >= slot) continue;               // wave-uniform: rows were never loaded
+            // rows u, u+1 of this lane: (v_u[d], v_u+1[d]) . (p_u, p_u+1) for its 8 dims; rows >= slot have p = 0
+            // (the cache is zero-initialised, so unused rows hold finite values)
+            const unsigned pp = (unsigned)bits16<T>(fromf<T>(pu[u])) | ((unsigned)bits16<T>(fromf<T>(pu[u + 1])) << 16);
+            const unsigned a0[4] = {vr[u].x, vr[u].y, vr[u].z, vr[u].w};
+            const unsigned a1[4] = {vr[u + 1].x, vr[u + 1].y, vr[u + 1].z, vr[u + 1].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned lo = __builtin_amdgcn_perm(a1[e], a0[e], 0x05040100u);    // (v_u[2e],   v_u+1[2e])
+                const unsigned hi = __builtin_amdgcn_perm(a1[e], a0[e], 0x07060302u);    // (v_u[2e+1], v_u+1[2e+1])
+                o8[2 * e] = dot2<T>(lo, pp, o8[2 * e]);
+                o8[2 * e + 1] = dot2<T>(hi, pp, o8[2 * e + 1]);
+            }
+        }
+        for (int j0 = VR * SPAN; j0 < slot; j0 += SPAN) {                       // contexts beyond the register window
+            const int j = j0 + cw * 4 + jsub;
             if (j < slot) {
                 const float p = rnd<T>(expf(S[j] - mx) / sum);
-                const V8 vv = as_vec8<T>(vr[u]);
+                const V8 vv = as_vec8<T>(ldg16(vc + (size_t)j * D + doct * 8));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o8[e] += p * tof<T>(vv[e]);
             }
@@ -203,31 +303,33 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
 #pragma unroll
         for (int e = 0; e < 8; ++e) o8[e] += p * v8[e];
     }
-    for (int j0 = PRE * SPAN; owns_rows && j0 < slot; j0 += SPAN) {
-        const int j = j0 + cw * 4 + jsub;
-        if (j < slot) {
-            const float p = rnd<T>(expf(S[j] - mx) / sum);
-            const V8 vv = as_vec8<T>(ldg16(vc + (size_t)j * D + doct * 8));
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o8[e] += p * tof<T>(vv[e]);
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        o8[e] += __shfl_xor(o8[e], 16, 64);
-        o8[e] += __shfl_xor(o8[e], 32, 64);
-    }
+    for (int e = 0; e < 8; ++e) o8[e] = xor32_sum(xor16_sum(o8[e]));
     if (jsub == 0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) part[w * D + doct * 8 + e] = o8[e];
     }
     __syncthreads();
-    if (tid < D) {
-        float v = 0.f;
+    ATT_T(6);
+    if (!COH) {
+        if (tid < D) {
+            float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < WAVES; ++i) v += part[i * D + tid];
-        reinterpret_cast<T*>(a.out)[(size_t)b * H + h * D + tid] = fromf<T>(v);
+            for (int i = 0; i < WAVES; ++i) v += part[i * D + tid];
+            reinterpret_cast<T*>(a.out)[(size_t)b * H + h * D + tid] = fromf<T>(v);
+        }
+    } else if (tid < D / 4) {                                  // write-through 8-byte stores (4 dims per lane)
+        unsigned long long pk = 0ull;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < WAVES; ++i) v += part[i * D + tid * 4 + e];
+            pk |= (unsigned long long)bits16<T>(fromf<T>(v)) << (16 * e);
+        }
+        st8_agent(reinterpret_cast<T*>(a.out) + (size_t)b * H + h * D + tid * 4, pk);
     }
+#undef ATT_T
 }
 
 }  // namespace rdx

@@ -324,10 +324,11 @@ __global__ __launch_bounds__(256) void greedy_step_k(const float* __restrict__ p
                                                      int n_tiles, int eos_id, int pad_id, int max_new, int* __restrict__ out_tokens,
                                                      int* __restrict__ unfinished, int* __restrict__ pos, int* __restrict__ slot_b,
                                                      int* __restrict__ step_b, const T* __restrict__ embed, int vocab,
-                                                     T* __restrict__ x_next, int H) {
+                                                     T* __restrict__ x_next, int H, const int* pos_ro,
+                                                     const T* __restrict__ cos_t, const T* __restrict__ sin_t, T* __restrict__ cur_rope) {
     __shared__ float sv[256];
     __shared__ int si[256];
-    __shared__ int tok_s;
+    __shared__ int tok_s, pos_s;
     const int b = blockIdx.x;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
@@ -357,7 +358,9 @@ __global__ __launch_bounds__(256) void greedy_step_k(const float* __restrict__ p
         if (step < max_new) out_tokens[(size_t)b * max_new + step] = tok;
         step_b[b] = step + 1;
         if (slot_b) slot_b[b] += 1;      // null on the prefill call: token 0 is consumed by the first decode step
-        if (pos) pos[b] += 1;
+        int pcur = pos_ro ? pos_ro[b] : 0;
+        if (pos) { pcur = pos[b] + 1; pos[b] = pcur; }
+        pos_s = pcur;
         tok_s = tok;
     }
     __syncthreads();
@@ -365,13 +368,20 @@ __global__ __launch_bounds__(256) void greedy_step_k(const float* __restrict__ p
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     const T* src = embed + (size_t)id * H;
     for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) stg16(x_next + (size_t)b * H + i, ldg16(src + i));
+    // cos | sin row of the position the NEXT decode step works at, so that decode attention needs no pos -> table load chain
+    if (cur_rope && threadIdx.x < 32) {
+        const int half = threadIdx.x >> 4, c8 = (threadIdx.x & 15) * 8;
+        const T* tab = half ? sin_t : cos_t;
+        stg16(cur_rope + (size_t)b * 256 + half * 128 + c8, ldg16(tab + (size_t)pos_s * 128 + c8));
+    }
 }
 void launch_greedy_step(int dtype, const float* part_val, const int* part_idx, int n_tiles, int B, int eos_id, int pad_id,
                         int max_new, int* out_tokens, int* unfinished, int* pos, int* slot_b, int* step_b, const void* embed,
-                        int vocab, void* x_next, int H, hipStream_t s) {
+                        int vocab, void* x_next, int H, const int* pos_ro, const void* cos_t, const void* sin_t, void* cur_rope,
+                        hipStream_t s) {
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((greedy_step_k<T>), dim3(B), dim3(256), 0, s, part_val, part_idx, n_tiles, eos_id,
                                                 pad_id, max_new, out_tokens, unfinished, pos, slot_b, step_b, (const T*)embed, vocab,
-                                                (T*)x_next, H));
+                                                (T*)x_next, H, pos_ro, (const T*)cos_t, (const T*)sin_t, (T*)cur_rope));
 }
 
 }  // namespace rdx

@@ -6,11 +6,11 @@
 // 8 waves) that put their whole K slice of weights in flight at once and only then wait for the attention output, so the
 // weight stream hides under the attention latency.
 //
-// Hand-off (cdna_hip_programming.md G16, counter form): each attention workgroup stores its 128 outputs (plain stores),
-// every storing wave drains vmcnt, __syncthreads, then ONE lane does an agent-scope release fence + asm vmcnt(0) +
-// relaxed agent-scope atomic add on the per-layer counter. Each consumer workgroup: ONE lane polls the counter relaxed
-// (with s_sleep), then one agent-scope acquire fence, __syncthreads, plain loads. The counter is zeroed once per decode
-// step by greedy_step_k (and by prep_prompt_k), never by a consumer.
+// Hand-off (handoff.h, fence-free form): the attention workgroups store their 128 outputs write-through (8-byte
+// agent-scope stores), every storing wave drains vmcnt, __syncthreads, ONE lane bumps a counter shard; each consumer
+// polls the 8 shards with 8 lanes (relaxed, s_sleep), __syncthreads, then reads the activation row with 8-byte agent-scope
+// loads (L1 bypass). No release / acquire fence on either side (those cost 1.7-6.5 us per workgroup). The counter
+// shards are zeroed once per decode step by a memset node.
 //
 // Residency / deadlock freedom: both roles are 512-thread workgroups capped at 128 VGPRs (half a CU each), so 512
 // workgroups fit on the chip; consumers number at most 256 (launcher check), hence producers can always be scheduled,
@@ -20,27 +20,9 @@
 #include "rdx_kernels.h"
 #include "attn_body.h"
 #include "skinny_body.h"
+#include "handoff.h"
 
 namespace rdx {
-
-typedef __attribute__((address_space(1))) int gint;
-
-struct WaitCounter {
-    int* counter; int target; int* err;
-    __device__ __forceinline__ void operator()() const {
-        if (threadIdx.x == 0) {
-            bool ok = false;
-            gint* gc = (gint*)counter;                       // GLOBAL (not flat) agent-scope access, as the G16 recipe requires
-            for (int it = 0; it < (1 << 17); ++it) {         // bounded: ~50 ms worst case, then give up loudly
-                if (__hip_atomic_load(gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = true; break; }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            if (!ok) *err = 1;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-        __syncthreads();
-    }
-};
 
 constexpr int FU_WAVES = 8;
 
@@ -49,18 +31,12 @@ __global__ __launch_bounds__(FU_WAVES * 64, 4) void attn_oproj_k(DecAttnArgs at,
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     if ((int)blockIdx.x < n_attn) {
         const int b = blockIdx.x / at.d.heads, h = blockIdx.x - b * at.d.heads;
-        decode_attention_body<T, FU_WAVES>(at, h, b, reinterpret_cast<float*>(fsm));
-        // publish: drain this wave's stores, workgroup barrier, one lane releases at agent scope and bumps the counter
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_fetch_add((gint*)counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        decode_attention_body<T, FU_WAVES, true, NoWait, false, 0, true>(at, h, b, reinterpret_cast<float*>(fsm));
+        publish_sc1(counter, blockIdx.x);
     } else {
         const int ntiles = gridDim.x - n_attn;
-        skinny_tile<T, MT, EPI_RESID, false, FU_WAVES, XLDS>(g, blockIdx.x - n_attn, ntiles, fsm, WaitCounter{counter, n_attn, err});
+        skinny_tile<T, MT, EPI_RESID, false, FU_WAVES, XLDS, WaitSharded, true>(g, blockIdx.x - n_attn, ntiles, fsm,
+                                                                                WaitSharded{counter, n_attn, err, 1, nullptr});
     }
 }
 

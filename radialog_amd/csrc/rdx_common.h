@@ -29,26 +29,67 @@ template <> struct Vec8<bf16> { typedef v8b type; };
 template <typename T> __device__ __forceinline__ typename Vec8<T>::type as_vec8(u4 v) {
     return __builtin_bit_cast(typename Vec8<T>::type, v);
 }
+template <typename T> __device__ __forceinline__ unsigned short bits16(T v) { return __builtin_bit_cast(unsigned short, v); }
+template <typename T> __device__ __forceinline__ T from_bits16(unsigned short b) { return __builtin_bit_cast(T, b); }
 template <typename T> __device__ __forceinline__ u4 as_u4(typename Vec8<T>::type v) { return __builtin_bit_cast(u4, v); }
 
 __device__ __forceinline__ v4f mfma16(v8h a, v8h b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ v4f mfma16(v8b a, v8b b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
-// 16-byte loads. `ldg_nt` = streamed-once data (decode weights): non-temporal policy.
-__device__ __forceinline__ u4 ldg16(const void* p) { return *reinterpret_cast<const u4*>(p); }
-__device__ __forceinline__ u4 ldg16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const u4*>(p)); }
-__device__ __forceinline__ void stg16(void* p, u4 v) { *reinterpret_cast<u4*>(p) = v; }
+// 16-byte GLOBAL-memory loads/stores. `ldg_nt` = streamed-once data (decode weights): non-temporal policy.
+// The explicit address_space(1) cast matters: a pointer fetched from a device-memory table (mega.hip) is generic, and
+// generic accesses become FLAT instructions, whose completion order is not guaranteed -- the compiler then falls back
+// to s_waitcnt vmcnt(0) everywhere and a software-pipelined weight stream collapses to one batch in flight.
+typedef __attribute__((address_space(1))) u4 g_u4;
+__device__ __forceinline__ u4 ldg16(const void* p) { return *(const g_u4*)p; }
+__device__ __forceinline__ u4 ldg16_nt(const void* p) { return __builtin_nontemporal_load((const g_u4*)p); }
+__device__ __forceinline__ void stg16(void* p, u4 v) { *(g_u4*)p = v; }
 
 // ---- wave (64 lanes) reductions ----------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane traffic goes through DPP / v_readlane / v_permlane*_swap (VALU speed, ~8 cycles each) rather than
+// __shfl_xor (ds_bpermute: an LDS-crossbar round trip of ~100 cycles per step) -- these reductions sit on the critical
+// path of latency-bound kernels (decode attention, the RMSNorm prologue of every GEMV).
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR8 = 0x128;
+// sum / max over each aligned group of 16 lanes (one DPP row); every lane of the group gets the result
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<DPP_XOR1>(v);
+    v += dpp_mov<DPP_XOR2>(v);
+    v += dpp_mov<DPP_HALF_MIRROR>(v);
+    v += dpp_mov<DPP_MIRROR>(v);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+    v = fmaxf(v, dpp_mov<DPP_XOR2>(v));
+    v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v));
+    v = fmaxf(v, dpp_mov<DPP_MIRROR>(v));
     return v;
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane_const) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_const));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (lane_bcast(v, 0) + lane_bcast(v, 16)) + (lane_bcast(v, 32) + lane_bcast(v, 48));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(lane_bcast(v, 0), lane_bcast(v, 16)), fmaxf(lane_bcast(v, 32), lane_bcast(v, 48)));
+}
+// v[l] + v[l ^ 16] and v[l] + v[l ^ 32] (gfx950 v_permlane16_swap / v_permlane32_swap: odd rows of the first operand
+// are exchanged with even rows of the second, so with both operands = v the pair holds {even rows, odd rows} twice)
+__device__ __forceinline__ float xor16_sum(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+    return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+    const int b = __builtin_bit_cast(int, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+    return __builtin_bit_cast(float, (int)r[0]) + __builtin_bit_cast(float, (int)r[1]);
 }
 
 // block reductions through a small LDS scratch (>= 32 floats); all threads get the result.

@@ -74,15 +74,41 @@ void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, cons
 struct DecAttnArgs {
     LlamaDims d;
     const void *qkv, *lbq, *lbv, *cos_t, *sin_t;
+    const void* cur_rope = nullptr;  // optional [B][2][128]: cos | sin row of each batch row's CURRENT position (else pos -> tables)
     const int *pos, *slot_b;
     const uint8_t* key_mask;
     void *kcache, *vcache, *out;
+    long long* trace = nullptr;      // debug: 8 timestamps (100 MHz ticks) of workgroup (b=0,h=0)
 };
 void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s);
 // decode attention + o_proj(+residual) in ONE launch: the o_proj tile workgroups put their weights in flight
 // immediately and wait on `counter` (agent-scope release/acquire hand-off) for the heads*B attention workgroups.
 // `counter` must be zero at launch; `err` is set to 1 if a wait ever times out (never hangs).
 void launch_attn_oproj(int dtype, const DecAttnArgs& a, const GemmArgs& g, int B, int* counter, int* err, hipStream_t s);
+
+// Chained decode-layer kernel (mega.hip): QKV GEMV -> attention -> o_proj -> gate/up -> down of `nlayers` consecutive
+// layers in ONE launch, units chained by counter hand-offs instead of kernel boundaries (batch <= 2).
+struct MegaLayer { const void *wqkv, *wo, *wgu, *wdown, *attn_norm, *mlp_norm, *lbq, *lbv; void *kcache, *vcache; };
+struct MegaArgs {
+    const MegaLayer* layers;         // device table, one entry per decoder layer
+    int layer0;                      // first layer of this launch
+    LlamaDims d;
+    int inter, qkv_n, B;
+    float eps;
+    void *dx, *dqkv, *datt, *dgu;    // [B][hidden] residual stream, [B][qkv_ld], [B][hidden], [B][inter]
+    const void *cos_t, *sin_t, *cur_rope;
+    const int *pos, *slot_b;
+    const uint8_t* key_mask;
+    int* ctr;                        // mega_ctr_ints(layers) ints, zero at the start of every step
+    int* err;
+    long long* trace;                // nullable: [grid][4] = {start, inputs ready, end (100 MHz ticks), role}
+    int naps;                        // poll back-off (x s_sleep(8) between polls)
+    int tiles[5], nwg[5];            // filled by the launcher
+};
+bool mega_supported(const LlamaDims& d, int inter, int B);
+size_t mega_ctr_ints(int layers);
+// occ: 8 = two workgroups per CU (<= 64 VGPRs), 4 = one per CU (<= 128 VGPRs)
+void launch_decode_layers(int dtype, MegaArgs ma, int nlayers, int occ, hipStream_t s);
 
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s);
 void launch_layernorm(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* out_f32,
@@ -107,6 +133,9 @@ void launch_embed_splice(int dtype, const int* ids, const int* img_pos, const vo
 void launch_gather_last(int dtype, const void* x, void* out, int B, int T, int H, hipStream_t s);
 void launch_greedy_step(int dtype, const float* part_val, const int* part_idx, int n_tiles, int B, int eos_id, int pad_id,
                         int max_new, int* out_tokens, int* unfinished, int* pos, int* slot_b, int* step_b,
-                        const void* embed, int vocab, void* x_next, int H, hipStream_t s);
+                        const void* embed, int vocab, void* x_next, int H, const int* pos_ro, const void* cos_t,
+                        const void* sin_t, void* cur_rope, hipStream_t s);
+// pos_ro / cos_t / sin_t / cur_rope: after the update, copy the cos | sin table row of each row's position into
+// cur_rope [B][2][128] (pos_ro = the position array even when `pos` is null, i.e. not advanced)
 
 }  // namespace rdx

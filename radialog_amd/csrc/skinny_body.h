@@ -12,6 +12,7 @@
 #pragma once
 #include "rdx_common.h"
 #include "rdx_kernels.h"
+#include "handoff.h"
 
 namespace rdx {
 
@@ -22,9 +23,8 @@ template <typename T> __device__ __forceinline__ float swiglu(float gate_acc, fl
     return s * up;                                             // product rounded by the caller's store
 }
 
-struct NoWait { __device__ __forceinline__ void operator()() const {} };
 
-template <typename T, int MT, int EPI, bool NORM, int WAVES, bool XLDS, typename WaitFn>
+template <typename T, int MT, int EPI, bool NORM, int WAVES, bool XLDS, typename WaitFn, bool COHX = false>
 __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, const int ntiles, unsigned char* dyn_smem,
                                             WaitFn wait_inputs) {
     typedef typename Vec8<T>::type V8;
@@ -58,6 +58,13 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
 
     wait_inputs();          // fused launches: block until the producer workgroups have published X (and resid)
 
+    // COHX (fused launches with the fence-free hand-off): X was published write-through by other workgroups of THIS
+    // launch -> agent-scope loads (L1 bypass); resid / weights predate the launch
+    auto ldxa = [&](const T* p) -> u4 {
+        if (!COHX) return ldg16(p);
+        const unsigned long long lo = ld8_agent(p), hi = ld8_agent(p + 4);
+        return (u4){(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+    };
     if (XLDS) {
         const int K8 = K >> 3;
         if (NORM) {
@@ -65,7 +72,7 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
             for (int m = 0; m < a.M; ++m) {
                 float ss = 0.f;
                 for (int k8 = threadIdx.x; k8 < K8; k8 += NTHR) {
-                    V8 xv = as_vec8<T>(ldg16(X + (size_t)m * a.ldx + (size_t)k8 * 8));
+                    V8 xv = as_vec8<T>(ldxa(X + (size_t)m * a.ldx + (size_t)k8 * 8));
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { const float f = tof<T>(xv[j]); ss += f * f; }
                 }
@@ -85,7 +92,7 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
         const int total8 = a.M * K8;
         for (int i = threadIdx.x; i < total8; i += NTHR) {
             const int m = i / K8, k8 = i - m * K8;
-            V8 xv = as_vec8<T>(ldg16(X + (size_t)m * a.ldx + (size_t)k8 * 8));
+            V8 xv = as_vec8<T>(ldxa(X + (size_t)m * a.ldx + (size_t)k8 * 8));
             if (NORM) {
                 const float rs = rstd_s[m];
                 V8 nw = as_vec8<T>(ldg16(NW + (size_t)k8 * 8));
@@ -121,7 +128,7 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
             const int c = min(cb + u, clast);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
-                dst[u][mt] = xok[mt] ? ldg16(xrow[mt] + (size_t)c * 32) : (u4){0u, 0u, 0u, 0u};
+                dst[u][mt] = xok[mt] ? ldxa(xrow[mt] + (size_t)c * 32) : (u4){0u, 0u, 0u, 0u};
         }
     };
     if (!XLDS) load_x(xr, c0);

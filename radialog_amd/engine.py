@@ -195,6 +195,19 @@ class RdxEngine:
         return ms.value
 
 
+    def attn_trace(self, layer: int):
+        """Debug: 8 timestamps (100 MHz ticks) inside the stand-alone decode-attention kernel (workgroup 0,0)."""
+        buf = torch.zeros(8, dtype=torch.int64)
+        check(self.ctx, self.lib.rdx_attn_trace(self.ctx, layer, buf.data_ptr()), "rdx_attn_trace")
+        return buf
+
+    def mega_trace(self, max_wgs: int):
+        """Debug: per-workgroup {start, inputs ready, end, role} of one chained decode step (RDX_MEGA), int64 [max_wgs, 4]."""
+        buf = torch.zeros(max_wgs, 4, dtype=torch.int64)
+        check(self.ctx, self.lib.rdx_mega_trace(self.ctx, buf.data_ptr(), max_wgs), "rdx_mega_trace")
+        return buf
+
+
 def synth_getter(cfg: RaDialogCfg, device, lora: bool = True) -> Callable[[str], torch.Tensor]:
     """Lazy deterministic random-init weights (radialog_amd.synth), generated on `device` one tensor at a time."""
     from . import synth

@@ -177,3 +177,34 @@ def test_fused_attention_oproj_launch_matches_oracle(cfg, cpu_w, monkeypatch):
         same = toks.cpu().long() == ref["tokens"]
         assert bool(same.all()) or float(ref["margins"].min()) < 4e-2
     eng.close()
+
+
+@pytest.mark.parametrize("layers_per_launch,occ,B", [(-1, 8, 1), (-1, 4, 2), (1, 8, 2)])
+def test_chained_decode_layer_kernel_matches_oracle(cfg, cpu_w, monkeypatch, layers_per_launch, occ, B):
+    """RDX_MEGA: QKV GEMV -> attention -> o_proj -> gate/up -> down of all layers in one launch, units chained by
+    counter hand-offs instead of kernel boundaries (csrc/mega.hip). Tokens and logits must match the oracle exactly as
+    the kernel-per-unit path does."""
+    from oracle import ref_cpu
+    from radialog_amd.engine import RdxEngine, synth_getter
+    monkeypatch.setenv("RDX_MEGA", str(layers_per_launch))
+    monkeypatch.setenv("RDX_MEGA_OCC", str(occ))
+    T, N = 72, 24
+    ids = _prompt(cfg, B, T, seed=33)
+    qf = synth.synth("t.qf2", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    for dtype in ("f16", "bf16"):
+        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=2, max_len=256, lora=True, vision=False)
+        eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+        with torch.no_grad():
+            ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1)
+        tol = LOGIT_TOL[dtype]
+        for use_graph in (False, True):
+            toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, output_scores=True, use_graph=use_graph)
+            toks = toks.cpu().long()
+            for b in range(B):
+                for s in range(N):
+                    if toks[b, s] != ref["tokens"][b, s]:
+                        assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
+                        break
+                    err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
+                    assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
+        eng.close()
