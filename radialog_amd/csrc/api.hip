@@ -84,7 +84,8 @@ struct rdx_ctx {
     int cur_B = 0, cur_T = 0, cur_max_new = 0, cur_eos = -1, cur_pad = 0;
     int32_t* cur_tokens = nullptr;
     hipGraphExec_t graph = nullptr;
-    bool fuse_attn_oproj = false;    // RDX_FUSE_AO=1: attention + o_proj in one launch with a flag hand-off (measured: no gain at B=1)
+    int fuse_attn_oproj = 2;    // RDX_FUSE_AO: attention + o_proj in ONE launch with a fence-free hand-off: 2 = 16-wave kernel (mega.hip,
+                                // default where supported: batch <= 2), 1 = 8-wave kernel (fused.hip), 0 = one kernel per unit
     int use_mega = 0;                // RDX_MEGA=n: chained decode-layer kernel (mega.hip), n layers per launch (0 = off, -1 = all)
     int mega_naps = 1;               // RDX_MEGA_NAPS: poll back-off
     int mega_occ = 8;                // RDX_MEGA_OCC: 8 = two workgroups per CU, 4 = one
@@ -200,7 +201,7 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
     rdx_ctx* c = new rdx_ctx();
     c->cfg = *cfg;
     c->device = device_id;
-    if (const char* e = getenv("RDX_FUSE_AO")) c->fuse_attn_oproj = atoi(e) != 0;
+    if (const char* e = getenv("RDX_FUSE_AO")) c->fuse_attn_oproj = atoi(e);
     if (const char* e = getenv("RDX_MEGA")) c->use_mega = atoi(e);
     if (const char* e = getenv("RDX_MEGA_NAPS")) c->mega_naps = atoi(e);
     if (const char* e = getenv("RDX_MEGA_OCC")) c->mega_occ = atoi(e) == 4 ? 4 : 8;
@@ -711,7 +712,9 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         at.kcache = kv_ptr(c, c->kcache, l); at.vcache = kv_ptr(c, c->vcache, l); at.out = c->datt;
         GemmArgs ao = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B);
         ao.resid = c->dx; ao.ldr = H;
-        if (c->fuse_attn_oproj && (L.wo.N + 15) / 16 <= 256) {
+        if (c->fuse_attn_oproj == 2 && attn_oproj16_supported(c->ld, L.wo.N, L.wo.K, B)) {
+            launch_attn_oproj16(dt, at, ao, B, c->d_ctr + (size_t)l * 128, c->d_err, s);
+        } else if (c->fuse_attn_oproj == 1 && (L.wo.N + 15) / 16 <= 256) {
             launch_attn_oproj(dt, at, ao, B, c->d_ctr + (size_t)l * 128, c->d_err, s);
         } else {
             launch_decode_attention(dt, at, B, s);

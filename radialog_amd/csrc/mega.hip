@@ -39,11 +39,11 @@ struct MegaGemm {                                // one weight-streaming unit
     const void* norm_w; float eps;
 };
 
-template <typename T, int EPI, bool NORM, int SUB, int XL, typename WaitFn>
+template <typename T, int EPI, bool NORM, int SUB, int XL, typename WaitFn, int U = 4, bool RESID_EARLY = false>
 __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const int ntiles, unsigned char* smem, WaitFn wait_inputs) {
     typedef typename Vec8<T>::type V8;
     constexpr int WPS = MG_WAVES / SUB;           // waves per tile
-    constexpr int U = 4;                          // 2 x 4 KiB per wave in flight; keeps every role <= 64 VGPRs
+    // U chunks per register batch, two batches in flight: U = 4 keeps every role of the chained kernel <= 64 VGPRs
     float* red = reinterpret_cast<float*>(smem);                        // [MG_WAVES][256]
     float* ssq = red + MG_WAVES * 256;                                  // [MG_WAVES][MG_MAXM]
     float* rstd_s = ssq + MG_WAVES * MG_MAXM;                           // [MG_MAXM] (+pad)
@@ -67,6 +67,16 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
     for (int u = 0; u < U; ++u) wa_[u] = ldg16_nt(wbase + (size_t)min(c0 + u, clast) * 64);
 #pragma unroll
     for (int u = 0; u < U; ++u) wb_[u] = ldg16_nt(wbase + (size_t)min(c0 + U + u, clast) * 64);
+
+    // RESID_EARLY: the residual predates the launch (fused attention + o_proj) -> fetch it now, off the critical tail
+    constexpr int QPT_E = EPI == EPI_SILU_MUL ? 2 : 4;
+    unsigned long long rs8_early = 0ull;
+    if (RESID_EARLY && EPI == EPI_RESID && (int)threadIdx.x < SUB * a.M * QPT_E) {
+        const int so = threadIdx.x / (a.M * QPT_E), rem = threadIdx.x - so * (a.M * QPT_E);
+        const int m = rem / QPT_E, q = rem - m * QPT_E;
+        const int n = (wg * SUB + so) * 16 + q * 4;
+        if (wg * SUB + so < ntiles && n < a.N) rs8_early = ld8_agent(reinterpret_cast<const T*>(a.resid) + (size_t)m * a.ldr + n);
+    }
 
     wait_inputs();
 
@@ -188,7 +198,7 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
             if (ok) st8_agent(out + (size_t)m * a.ldo + n, pk);
         } else if (EPI == EPI_RESID) {
             if (ok) {
-                const unsigned long long rs8 = ld8_agent(reinterpret_cast<const T*>(a.resid) + (size_t)m * a.ldr + n);
+                const unsigned long long rs8 = RESID_EARLY ? rs8_early : ld8_agent(reinterpret_cast<const T*>(a.resid) + (size_t)m * a.ldr + n);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float rsd = tof<T>(from_bits16<T>((unsigned short)(rs8 >> (16 * j))));
@@ -271,6 +281,39 @@ __global__ __launch_bounds__(MG_THREADS, OCC) void decode_layers_k(MegaArgs ma) 
         publish_sc1(ctr + MG_DOWN * MG_CTR_STRIDE, rb);
         MG_DONE(MG_DOWN);
     }
+}
+
+// ---- decode attention + o_proj(+residual) in ONE launch, 16-wave workgroups -------------------------------------------------
+// Workgroups [0, heads*B): attention exactly as the stand-alone latency kernel (wave 0 = new token, 15 cache waves),
+// output stored write-through. Workgroups [heads*B, +ntiles/2): two o_proj tiles each (8 waves per tile), whose WHOLE
+// K slice (16 chunks per wave) goes in flight at entry and sits in registers while attention runs; then the fence-free
+// hand-off (handoff.h) and ~2 us of work. heads*B + ntiles/2 <= 256 workgroups of <= 128 VGPRs: all resident, one per CU.
+template <typename T>
+__global__ __launch_bounds__(MG_THREADS, 4) void attn_oproj16_k(DecAttnArgs at, MegaGemm g, int n_attn, int ntiles, int* counter, int* err) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char msm[];
+    if ((int)blockIdx.x < n_attn) {
+        const int b = blockIdx.x / at.d.heads, h = blockIdx.x - b * at.d.heads;
+        decode_attention_body<T, MG_WAVES, true, NoWait, true, 0, true>(at, h, b, reinterpret_cast<float*>(msm));
+        publish_sc1(counter, blockIdx.x);
+    } else {
+        mega_tile<T, EPI_RESID, false, 2, 2, WaitSharded, 8, true>(g, blockIdx.x - n_attn, ntiles, msm, WaitSharded{counter, n_attn, err, 1, nullptr});
+    }
+}
+
+bool attn_oproj16_supported(const LlamaDims& d, int N, int K, int B) {
+    const int ntiles = (N + 15) / 16;
+    return B <= MG_MAXM && d.head_dim == 128 && K % 32 == 0 && N % 4 == 0 && (size_t)B * K <= 8192 &&
+           d.heads * B + (ntiles + 1) / 2 <= 256;
+}
+
+void launch_attn_oproj16(int dtype, const DecAttnArgs& a, const GemmArgs& ga, int B, int* counter, int* err, hipStream_t s) {
+    const int n_attn = a.d.heads * B, ntiles = (ga.N + 15) / 16;
+    MegaGemm g = {ga.X, ga.ldx, ga.W, ga.resid, ga.ldr, ga.out, ga.ldo, ga.M, ga.N, ga.K, nullptr, 0.f};
+    const size_t sm_gemm = (size_t)(MG_WAVES * 256 + MG_WAVES * MG_MAXM + 16) * 4 + (size_t)B * ga.K * 2;
+    const size_t sm_att = decode_attention_smem_floats(MG_WAVES, a.d.max_len) * sizeof(float);
+    const size_t smem = sm_gemm > sm_att ? sm_gemm : sm_att;
+    dim3 grid(n_attn + (ntiles + 1) / 2), block(MG_THREADS);
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((attn_oproj16_k<T>), grid, block, smem, s, a, g, n_attn, ntiles, counter, err));
 }
 
 bool mega_supported(const LlamaDims& d, int inter, int B) {

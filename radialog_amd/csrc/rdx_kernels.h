@@ -105,6 +105,10 @@ struct MegaArgs {
     int naps;                        // poll back-off (x s_sleep(8) between polls)
     int tiles[5], nwg[5];            // filled by the launcher
 };
+// 16-wave variant of the fused attention + o_proj launch (mega.hip): fast attention body, two o_proj tiles per workgroup with
+// their whole K slice in registers, fence-free hand-off. `counter` = 128 ints (8 shards), zero at launch.
+bool attn_oproj16_supported(const LlamaDims& d, int N, int K, int B);
+void launch_attn_oproj16(int dtype, const DecAttnArgs& a, const GemmArgs& g, int B, int* counter, int* err, hipStream_t s);
 bool mega_supported(const LlamaDims& d, int inter, int B);
 size_t mega_ctr_ints(int layers);
 // occ: 8 = two workgroups per CU (<= 64 VGPRs), 4 = one per CU (<= 128 VGPRs)

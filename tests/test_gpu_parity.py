@@ -159,15 +159,17 @@ def test_eos_and_padding_rule(engine, cfg, cpu_w):
         assert int(toks[0, 3:].abs().sum()) == 0      # row 0 finished at step 2 -> pads afterwards
 
 
-def test_fused_attention_oproj_launch_matches_oracle(cfg, cpu_w, monkeypatch):
-    """RDX_FUSE_AO=1: decode attention and o_proj in ONE launch with an agent-scope release/acquire hand-off
-    (csrc/fused.hip). Off by default (no speed-up at batch 1); must still be exact."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_fused_attention_oproj_launch_matches_oracle(cfg, cpu_w, monkeypatch, mode):
+    """RDX_FUSE_AO: decode attention and o_proj in ONE launch with a fence-free workgroup hand-off (write-through stores,
+    sharded arrival counter): 1 = 8-wave workgroups (csrc/fused.hip), 2 = 16-wave workgroups, two o_proj tiles each
+    (csrc/mega.hip). Must be exactly as accurate as the kernel-per-unit path."""
     from oracle import ref_cpu
     from radialog_amd.engine import RdxEngine, synth_getter
-    monkeypatch.setenv("RDX_FUSE_AO", "1")
+    monkeypatch.setenv("RDX_FUSE_AO", str(mode))
     eng = RdxEngine(cfg, dtype="f16", device=0, max_batch=4, max_len=256, lora=True, vision=False)
     eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
-    B, T, N = 3, 72, 24
+    B, T, N = (3 if mode == 1 else 2), 72, 24
     ids = _prompt(cfg, B, T, seed=33)
     qf = synth.synth("t.qf2", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
     with torch.no_grad():
