@@ -87,6 +87,7 @@ struct rdx_ctx {
     int fuse_attn_oproj = 2;    // RDX_FUSE_AO: attention + o_proj in ONE launch with a fence-free hand-off: 2 = 16-wave kernel (mega.hip,
                                 // default where supported: batch <= 2), 1 = 8-wave kernel (fused.hip), 0 = one kernel per unit
     int use_mega = 0;                // RDX_MEGA=n: chained decode-layer kernel (mega.hip), n layers per launch (0 = off, -1 = all)
+    int chain_mlp = 0;               // RDX_CHAIN=1: gate/up -> down -> next qkv as one chained launch per layer
     int mega_naps = 1;               // RDX_MEGA_NAPS: poll back-off
     int mega_occ = 8;                // RDX_MEGA_OCC: 8 = two workgroups per CU, 4 = one
     void* d_cur_rope = nullptr;      // [B][2][128] cos | sin row of each row's current position (written by greedy_step_k)
@@ -203,6 +204,7 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
     c->device = device_id;
     if (const char* e = getenv("RDX_FUSE_AO")) c->fuse_attn_oproj = atoi(e);
     if (const char* e = getenv("RDX_MEGA")) c->use_mega = atoi(e);
+    if (const char* e = getenv("RDX_CHAIN")) c->chain_mlp = atoi(e);
     if (const char* e = getenv("RDX_MEGA_NAPS")) c->mega_naps = atoi(e);
     if (const char* e = getenv("RDX_MEGA_OCC")) c->mega_occ = atoi(e) == 4 ? 4 : 8;
     if (const char* e = getenv("RDX_DMA")) c->use_dma_gemm = atoi(e) != 0;
@@ -702,10 +704,23 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         return;
     }
     if (c->fuse_attn_oproj) hipMemsetAsync(c->d_ctr, 0, (size_t)f.layers * 128 * sizeof(int), s);   // hand-off counter shards, once per step
+    // RDX_CHAIN=1: gate/up(l) -> down(l) -> qkv(l+1) as ONE chained launch per layer (mega.hip roles, <= 64 VGPRs)
+    const bool chain = c->chain_mlp && mega_supported(c->ld, f.inter, B) && attn_oproj16_supported(c->ld, f.hidden, f.hidden, B) && c->fuse_attn_oproj == 2;
+    MegaArgs ma;
+    if (chain) {
+        hipMemsetAsync(c->d_mctr, 0, mega_ctr_ints(f.layers) * sizeof(int), s);
+        memset(&ma, 0, sizeof(ma));
+        ma.layers = c->d_mlayers; ma.d = c->ld; ma.inter = f.inter; ma.qkv_n = c->ll[0].wqkv.Npad; ma.B = B; ma.eps = f.rms_eps;
+        ma.dx = c->dx; ma.dqkv = c->dqkv; ma.datt = c->datt; ma.dgu = c->dgu; ma.cos_t = c->rope_cos; ma.sin_t = c->rope_sin;
+        ma.cur_rope = c->d_cur_rope; ma.pos = c->d_pos; ma.slot_b = c->d_slot; ma.key_mask = c->key_mask; ma.ctr = c->d_mctr; ma.err = c->d_err;
+        ma.naps = c->mega_naps; ma.trace = nullptr;
+    }
     for (int l = 0; l < f.layers; ++l) {
         const LlamaLayer& L = c->ll[l];
-        { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps;
-          skinny(c, a, EPI_NONE); }
+        if (!chain || l == 0) {
+            GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps;
+            skinny(c, a, EPI_NONE);
+        }
         DecAttnArgs at;
         at.d = c->ld; at.qkv = c->dqkv; at.lbq = L.lora_bq; at.lbv = L.lora_bv; at.cos_t = c->rope_cos; at.sin_t = c->rope_sin;
         at.pos = c->d_pos; at.slot_b = c->d_slot; at.key_mask = c->key_mask; at.cur_rope = c->d_cur_rope;
@@ -719,6 +734,10 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         } else {
             launch_decode_attention(dt, at, B, s);
             skinny(c, ao, EPI_RESID);
+        }
+        if (chain) {
+            launch_decode_roles(dt, ma, l * 5 + 3, std::min((l + 1) * 5 + 1, f.layers * 5), c->mega_occ, s);
+            continue;
         }
         { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps;
           skinny(c, a, EPI_SILU_MUL); }

@@ -221,12 +221,13 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
 
 // OCC = waves per SIMD the register budget is sized for: 8 -> <= 64 VGPRs, two workgroups per CU (attention keeps a
 // small K window and loads V late); 4 -> <= 128 VGPRs, one workgroup per CU (attention as in the stand-alone kernel)
-template <typename T, int OCC>
+template <typename T, int OCC, bool WITH_ATT>
 __global__ __launch_bounds__(MG_THREADS, OCC) void decode_layers_k(MegaArgs ma) {
     extern __shared__ __attribute__((aligned(16))) unsigned char msm[];
     const int per_layer = ma.nwg[0] + ma.nwg[1] + ma.nwg[2] + ma.nwg[3] + ma.nwg[4];
-    const int li = blockIdx.x / per_layer;                  // layer index inside this launch
-    int rb = blockIdx.x - li * per_layer;
+    const int bid = blockIdx.x + ma.blk_offset;             // the launch may start in the middle of its first layer
+    const int li = bid / per_layer;                         // layer index inside this launch
+    int rb = bid - li * per_layer;
     const int l = ma.layer0 + li;
     const MegaLayer& L = ma.layers[l];
     int* ctr = ma.ctr + (size_t)l * MG_NROLE * MG_CTR_STRIDE;
@@ -239,19 +240,20 @@ __global__ __launch_bounds__(MG_THREADS, OCC) void decode_layers_k(MegaArgs ma) 
     if (rb < ma.nwg[MG_QKV]) {
         MegaGemm g = {ma.dx, H, L.wqkv, nullptr, 0, ma.dqkv, ma.d.qkv_ld, B, ma.qkv_n, H, L.attn_norm, ma.eps};
         // first layer of the launch: the kernel boundary already ordered it after the previous launch
-        mega_tile<T, EPI_NONE, true, 4, 2>(g, rb, ma.tiles[MG_QKV], msm, WaitSharded{prev_down, li ? ma.nwg[MG_DOWN] : 0, ma.err, ma.naps, tr});
+        mega_tile<T, EPI_NONE, true, 4, 2>(g, rb, ma.tiles[MG_QKV], msm,
+                                           WaitSharded{prev_down, li ? ma.nwg[MG_DOWN] : 0, ma.err, ma.naps, tr});
         publish_sc1(ctr + MG_QKV * MG_CTR_STRIDE, rb);
         MG_DONE(MG_QKV);
         return;
     }
     rb -= ma.nwg[MG_QKV];
-    if (rb < ma.nwg[MG_ATT]) {
+    if (WITH_ATT && rb < ma.nwg[MG_ATT]) {
         DecAttnArgs at;
         at.d = ma.d; at.qkv = ma.dqkv; at.lbq = L.lbq; at.lbv = L.lbv; at.cos_t = ma.cos_t; at.sin_t = ma.sin_t; at.cur_rope = ma.cur_rope;
         at.pos = ma.pos; at.slot_b = ma.slot_b; at.key_mask = ma.key_mask; at.kcache = L.kcache; at.vcache = L.vcache; at.out = ma.datt;
         at.trace = ma.trace ? ma.trace + (size_t)gridDim.x * 4 + (size_t)l * 8 : nullptr;
         const int b = rb / ma.d.heads, h = rb - b * ma.d.heads;
-        const WaitSharded wq{ctr + MG_QKV * MG_CTR_STRIDE, ma.nwg[MG_QKV], ma.err, ma.naps, tr};
+        const WaitSharded wq{ctr + MG_QKV * MG_CTR_STRIDE, (li || ma.r_begin != MG_ATT) ? ma.nwg[MG_QKV] : 0, ma.err, ma.naps, tr};
         if (OCC == 8) decode_attention_body<T, MG_WAVES, true, WaitSharded, false, 1, true>(at, h, b, reinterpret_cast<float*>(msm), wq);
         else decode_attention_body<T, MG_WAVES, true, WaitSharded, true, 0, true>(at, h, b, reinterpret_cast<float*>(msm), wq);
         publish_sc1(ctr + MG_ATT * MG_CTR_STRIDE, rb);
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(MG_THREADS, OCC) void decode_layers_k(MegaArgs ma) 
     rb -= ma.nwg[MG_ATT];
     if (rb < ma.nwg[MG_O]) {
         MegaGemm g = {ma.datt, H, L.wo, ma.dx, H, ma.dx, H, B, H, H, nullptr, 0.f};
-        mega_tile<T, EPI_RESID, false, 1, 2>(g, rb, ma.tiles[MG_O], msm, WaitSharded{ctr + MG_ATT * MG_CTR_STRIDE, ma.nwg[MG_ATT], ma.err, ma.naps, tr});
+        mega_tile<T, EPI_RESID, false, 1, 2>(g, rb, ma.tiles[MG_O], msm, WaitSharded{ctr + MG_ATT * MG_CTR_STRIDE, (li || ma.r_begin != MG_O) ? ma.nwg[MG_ATT] : 0, ma.err, ma.naps, tr});
         publish_sc1(ctr + MG_O * MG_CTR_STRIDE, rb);
         MG_DONE(MG_O);
         return;
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(MG_THREADS, OCC) void decode_layers_k(MegaArgs ma) 
     rb -= ma.nwg[MG_O];
     if (rb < ma.nwg[MG_GU]) {
         MegaGemm g = {ma.dx, H, L.wgu, nullptr, 0, ma.dgu, ma.inter, B, 2 * ma.inter, H, L.mlp_norm, ma.eps};
-        mega_tile<T, EPI_SILU_MUL, true, 4, 2>(g, rb, ma.tiles[MG_GU], msm, WaitSharded{ctr + MG_O * MG_CTR_STRIDE, ma.nwg[MG_O], ma.err, ma.naps, tr});
+        mega_tile<T, EPI_SILU_MUL, true, 4, 2>(g, rb, ma.tiles[MG_GU], msm, WaitSharded{ctr + MG_O * MG_CTR_STRIDE, (li || ma.r_begin != MG_GU) ? ma.nwg[MG_O] : 0, ma.err, ma.naps, tr});
         publish_sc1(ctr + MG_GU * MG_CTR_STRIDE, rb);
         MG_DONE(MG_GU);
         return;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(MG_THREADS, OCC) void decode_layers_k(MegaArgs ma) 
     rb -= ma.nwg[MG_GU];
     {
         MegaGemm g = {ma.dgu, ma.inter, L.wdown, ma.dx, H, ma.dx, H, B, H, ma.inter, nullptr, 0.f};
-        mega_tile<T, EPI_RESID, false, 1, 6>(g, rb, ma.tiles[MG_DOWN], msm, WaitSharded{ctr + MG_GU * MG_CTR_STRIDE, ma.nwg[MG_GU], ma.err, ma.naps, tr});
+        mega_tile<T, EPI_RESID, false, 1, 6>(g, rb, ma.tiles[MG_DOWN], msm, WaitSharded{ctr + MG_GU * MG_CTR_STRIDE, (li || ma.r_begin != MG_DOWN) ? ma.nwg[MG_GU] : 0, ma.err, ma.naps, tr});
         publish_sc1(ctr + MG_DOWN * MG_CTR_STRIDE, rb);
         MG_DONE(MG_DOWN);
     }
@@ -325,22 +327,39 @@ bool mega_supported(const LlamaDims& d, int inter, int B) {
 
 size_t mega_ctr_ints(int layers) { return (size_t)layers * MG_NROLE * MG_CTR_STRIDE; }
 
-void launch_decode_layers(int dtype, MegaArgs ma, int nlayers, int occ, hipStream_t s) {
+static void mega_fill(MegaArgs& ma) {
     ma.tiles[MG_QKV] = (ma.qkv_n + 15) / 16;  ma.nwg[MG_QKV] = (ma.tiles[MG_QKV] + 3) / 4;
     ma.tiles[MG_ATT] = ma.d.heads * ma.B;     ma.nwg[MG_ATT] = ma.tiles[MG_ATT];
     ma.tiles[MG_O] = ma.d.hidden / 16;        ma.nwg[MG_O] = ma.tiles[MG_O];
     ma.tiles[MG_GU] = (2 * ma.inter) / 16;    ma.nwg[MG_GU] = (ma.tiles[MG_GU] + 3) / 4;
     ma.tiles[MG_DOWN] = ma.d.hidden / 16;     ma.nwg[MG_DOWN] = ma.tiles[MG_DOWN];
+}
+
+void launch_decode_roles(int dtype, MegaArgs ma, int R0, int R1, int occ, hipStream_t s) {
+    mega_fill(ma);
+    const int l0 = R0 / MG_NROLE, r0 = R0 % MG_NROLE, l1 = (R1 - 1) / MG_NROLE, r1 = (R1 - 1) % MG_NROLE;
+    bool with_att = false;
+    for (int R = R0; R < R1; ++R) with_att |= (R % MG_NROLE) == MG_ATT;
     const int per_layer = ma.nwg[0] + ma.nwg[1] + ma.nwg[2] + ma.nwg[3] + ma.nwg[4];
+    int off = 0, tail = 0;
+    for (int r = 0; r < r0; ++r) off += ma.nwg[r];
+    for (int r = r1 + 1; r < MG_NROLE; ++r) tail += ma.nwg[r];
+    ma.layer0 = l0; ma.r_begin = r0; ma.blk_offset = off;
     const int kmax = ma.inter > ma.d.hidden ? ma.inter : ma.d.hidden;
     const size_t sm_gemm = (size_t)(MG_WAVES * 256 + MG_WAVES * MG_MAXM + 16) * 4 + (size_t)ma.B * kmax * 2;
-    const size_t sm_att = decode_attention_smem_floats(MG_WAVES, ma.d.max_len) * sizeof(float);
+    const size_t sm_att = with_att ? decode_attention_smem_floats(MG_WAVES, ma.d.max_len) * sizeof(float) : 0;
     const size_t smem = sm_gemm > sm_att ? sm_gemm : sm_att;
-    dim3 grid(per_layer * nlayers), block(MG_THREADS);
+    dim3 grid((l1 - l0 + 1) * per_layer - off - tail), block(MG_THREADS);
     RDX_DISPATCH_T(dtype, T, {
-        if (occ == 8) hipLaunchKernelGGL((decode_layers_k<T, 8>), grid, block, smem, s, ma);
-        else hipLaunchKernelGGL((decode_layers_k<T, 4>), grid, block, smem, s, ma);
+        if (!with_att) hipLaunchKernelGGL((decode_layers_k<T, 8, false>), grid, block, smem, s, ma);
+        else if (occ == 8) hipLaunchKernelGGL((decode_layers_k<T, 8, true>), grid, block, smem, s, ma);
+        else hipLaunchKernelGGL((decode_layers_k<T, 4, true>), grid, block, smem, s, ma);
     });
 }
+
+void launch_decode_layers(int dtype, MegaArgs ma, int nlayers, int occ, hipStream_t s) {
+    launch_decode_roles(dtype, ma, ma.layer0 * MG_NROLE, (ma.layer0 + nlayers) * MG_NROLE, occ, s);
+}
+
 
 }  // namespace rdx

@@ -104,6 +104,7 @@ struct MegaArgs {
     long long* trace;                // nullable: [grid][4] = {start, inputs ready, end (100 MHz ticks), role}
     int naps;                        // poll back-off (x s_sleep(8) between polls)
     int tiles[5], nwg[5];            // filled by the launcher
+    int r_begin, blk_offset;         // filled by the launcher: first role of the launch (it does not wait), blocks skipped before it
 };
 // 16-wave variant of the fused attention + o_proj launch (mega.hip): fast attention body, two o_proj tiles per workgroup with
 // their whole K slice in registers, fence-free hand-off. `counter` = 128 ints (8 shards), zero at launch.
@@ -113,6 +114,9 @@ bool mega_supported(const LlamaDims& d, int inter, int B);
 size_t mega_ctr_ints(int layers);
 // occ: 8 = two workgroups per CU (<= 64 VGPRs), 4 = one per CU (<= 128 VGPRs)
 void launch_decode_layers(int dtype, MegaArgs ma, int nlayers, int occ, hipStream_t s);
+// any contiguous range [R0, R1) of the role sequence R = layer*5 + {0 qkv, 1 attention, 2 o_proj, 3 gate/up, 4 down}
+// (ma.layer0 is ignored); ranges without an attention role use a <= 64-VGPR build (two workgroups per CU)
+void launch_decode_roles(int dtype, MegaArgs ma, int R0, int R1, int occ, hipStream_t s);
 
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s);
 void launch_layernorm(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* out_f32,

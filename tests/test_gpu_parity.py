@@ -210,3 +210,31 @@ def test_chained_decode_layer_kernel_matches_oracle(cfg, cpu_w, monkeypatch, lay
                     err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
                     assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
         eng.close()
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_chained_mlp_qkv_launch_matches_oracle(cfg, cpu_w, monkeypatch, B):
+    """RDX_CHAIN=1: gate/up(l) -> down(l) -> qkv(l+1) as one chained launch per layer (roles of csrc/mega.hip with the
+    fence-free hand-off), attention + o_proj in the fused 16-wave launch."""
+    from oracle import ref_cpu
+    from radialog_amd.engine import RdxEngine, synth_getter
+    monkeypatch.setenv("RDX_CHAIN", "1")
+    T, N = 72, 24
+    ids = _prompt(cfg, B, T, seed=33)
+    qf = synth.synth("t.qf2", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    for dtype in ("f16", "bf16"):
+        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=2, max_len=256, lora=True, vision=False)
+        eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+        with torch.no_grad():
+            ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1)
+        tol = LOGIT_TOL[dtype]
+        toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, output_scores=True, use_graph=True)
+        toks = toks.cpu().long()
+        for b in range(B):
+            for s in range(N):
+                if toks[b, s] != ref["tokens"][b, s]:
+                    assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
+                    break
+                err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
+                assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
+        eng.close()
