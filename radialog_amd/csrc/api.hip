@@ -354,8 +354,10 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         HIPCHK(c, hipMemset(c->key_mask, 0, (size_t)B * f.max_len));
         ALLOC(c, c->d_img_pos, B * sizeof(int)); ALLOC(c, c->d_pos, B * sizeof(int)); ALLOC(c, c->d_slot, B * sizeof(int));
         ALLOC(c, c->d_step, B * sizeof(int)); ALLOC(c, c->d_unf, B * sizeof(int));
-        ALLOC(c, c->d_ctr, (size_t)f.layers * 128 * sizeof(int)); ALLOC(c, c->d_err, sizeof(int));   // 8 shards x 64 B per layer
-        HIPCHK(c, hipMemset(c->d_ctr, 0, (size_t)f.layers * 128 * sizeof(int)));
+        // hand-off counters: fused attention+o_proj (8 shards x 64 B per layer), then the chained kernel's (mega_ctr_ints)
+        ALLOC(c, c->d_ctr, ((size_t)f.layers * 128 + mega_ctr_ints(f.layers)) * sizeof(int)); ALLOC(c, c->d_err, sizeof(int));
+        HIPCHK(c, hipMemset(c->d_ctr, 0, ((size_t)f.layers * 128 + mega_ctr_ints(f.layers)) * sizeof(int)));
+        c->d_mctr = c->d_ctr + (size_t)f.layers * 128;
         HIPCHK(c, hipMemset(c->d_err, 0, sizeof(int)));
         {
             std::vector<MegaLayer> ml(f.layers);
@@ -366,7 +368,6 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
             }
             ALLOC(c, c->d_mlayers, ml.size() * sizeof(MegaLayer));
             HIPCHK(c, hipMemcpy(c->d_mlayers, ml.data(), ml.size() * sizeof(MegaLayer), hipMemcpyHostToDevice));
-            ALLOC(c, c->d_mctr, mega_ctr_ints(f.layers) * sizeof(int));
         }
         ALLOC(c, c->d_cur_rope, (size_t)B * 256 * 2);
         ALLOC(c, c->d_pos_ids, (size_t)B * f.max_len * sizeof(int));
@@ -629,7 +630,9 @@ static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, c
     skinny(c, a, EPI_LOGITS);
     launch_greedy_step(f.dtype, c->part_val, c->part_idx, c->n_vtiles, B, c->cur_eos, c->cur_pad, c->cur_max_new,
                        c->cur_tokens, c->d_unf, advance ? c->d_pos : nullptr, advance ? c->d_slot : nullptr, c->d_step,
-                       c->embed, f.vocab, c->dx, f.hidden, c->d_pos, c->rope_cos, c->rope_sin, c->d_cur_rope, c->stream);
+                       c->embed, f.vocab, c->dx, f.hidden, c->d_pos, c->rope_cos, c->rope_sin, c->d_cur_rope,
+                       (c->fuse_attn_oproj || c->use_mega || c->chain_mlp) ? c->d_ctr : nullptr,
+                       f.layers * 128 + ((c->use_mega || c->chain_mlp) ? (int)mega_ctr_ints(f.layers) : 0), c->stream);
 }
 
 extern "C" int rdx_prefill(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int T, const float* qformer_embs,
@@ -689,7 +692,6 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
     const int dt = f.dtype, H = f.hidden, B = c->cur_B;
     hipStream_t s = c->stream;
     if (c->use_mega && mega_supported(c->ld, f.inter, B)) {
-        hipMemsetAsync(c->d_mctr, 0, mega_ctr_ints(f.layers) * sizeof(int), s);   // hand-off counters, once per step
         MegaArgs ma;
         memset(&ma, 0, sizeof(ma));
         ma.layers = c->d_mlayers; ma.d = c->ld; ma.inter = f.inter; ma.qkv_n = c->ll[0].wqkv.Npad; ma.B = B; ma.eps = f.rms_eps;
@@ -703,12 +705,12 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
         return;
     }
-    if (c->fuse_attn_oproj) hipMemsetAsync(c->d_ctr, 0, (size_t)f.layers * 128 * sizeof(int), s);   // hand-off counter shards, once per step
+    // the hand-off counter shards of the fused launches are cleared by greedy_step_k at the end of the previous step
+    // (and of the prefill): a memset node at the head of the step graph was observed to race with the first producers
     // RDX_CHAIN=1: gate/up(l) -> down(l) -> qkv(l+1) as ONE chained launch per layer (mega.hip roles, <= 64 VGPRs)
     const bool chain = c->chain_mlp && mega_supported(c->ld, f.inter, B) && attn_oproj16_supported(c->ld, f.hidden, f.hidden, B) && c->fuse_attn_oproj == 2;
     MegaArgs ma;
     if (chain) {
-        hipMemsetAsync(c->d_mctr, 0, mega_ctr_ints(f.layers) * sizeof(int), s);
         memset(&ma, 0, sizeof(ma));
         ma.layers = c->d_mlayers; ma.d = c->ld; ma.inter = f.inter; ma.qkv_n = c->ll[0].wqkv.Npad; ma.B = B; ma.eps = f.rms_eps;
         ma.dx = c->dx; ma.dqkv = c->dqkv; ma.datt = c->datt; ma.dgu = c->dgu; ma.cos_t = c->rope_cos; ma.sin_t = c->rope_sin;

@@ -325,11 +325,14 @@ __global__ __launch_bounds__(256) void greedy_step_k(const float* __restrict__ p
                                                      int* __restrict__ unfinished, int* __restrict__ pos, int* __restrict__ slot_b,
                                                      int* __restrict__ step_b, const T* __restrict__ embed, int vocab,
                                                      T* __restrict__ x_next, int H, const int* pos_ro,
-                                                     const T* __restrict__ cos_t, const T* __restrict__ sin_t, T* __restrict__ cur_rope) {
+                                                     const T* __restrict__ cos_t, const T* __restrict__ sin_t, T* __restrict__ cur_rope,
+                                                     int* __restrict__ ctr_zero, int n_zero) {
     __shared__ float sv[256];
     __shared__ int si[256];
     __shared__ int tok_s, pos_s;
     const int b = blockIdx.x;
+    // hand-off counters of the NEXT decode step's fused launches: zeroed here, by the last kernel of this step
+    if (ctr_zero && b == 0) for (int i = threadIdx.x; i < n_zero; i += blockDim.x) ctr_zero[i] = 0;
     float bv = -INFINITY;
     int bi = 0x7fffffff;
     for (int i = threadIdx.x; i < n_tiles; i += blockDim.x) {
@@ -378,10 +381,10 @@ __global__ __launch_bounds__(256) void greedy_step_k(const float* __restrict__ p
 void launch_greedy_step(int dtype, const float* part_val, const int* part_idx, int n_tiles, int B, int eos_id, int pad_id,
                         int max_new, int* out_tokens, int* unfinished, int* pos, int* slot_b, int* step_b, const void* embed,
                         int vocab, void* x_next, int H, const int* pos_ro, const void* cos_t, const void* sin_t, void* cur_rope,
-                        hipStream_t s) {
+                        int* ctr_zero, int n_zero, hipStream_t s) {
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((greedy_step_k<T>), dim3(B), dim3(256), 0, s, part_val, part_idx, n_tiles, eos_id,
                                                 pad_id, max_new, out_tokens, unfinished, pos, slot_b, step_b, (const T*)embed, vocab,
-                                                (T*)x_next, H, pos_ro, (const T*)cos_t, (const T*)sin_t, (T*)cur_rope));
+                                                (T*)x_next, H, pos_ro, (const T*)cos_t, (const T*)sin_t, (T*)cur_rope, ctr_zero, n_zero));
 }
 
 }  // namespace rdx

@@ -142,8 +142,9 @@ void launch_gather_last(int dtype, const void* x, void* out, int B, int T, int H
 void launch_greedy_step(int dtype, const float* part_val, const int* part_idx, int n_tiles, int B, int eos_id, int pad_id,
                         int max_new, int* out_tokens, int* unfinished, int* pos, int* slot_b, int* step_b,
                         const void* embed, int vocab, void* x_next, int H, const int* pos_ro, const void* cos_t,
-                        const void* sin_t, void* cur_rope, hipStream_t s);
+                        const void* sin_t, void* cur_rope, int* ctr_zero, int n_zero, hipStream_t s);
 // pos_ro / cos_t / sin_t / cur_rope: after the update, copy the cos | sin table row of each row's position into
-// cur_rope [B][2][128] (pos_ro = the position array even when `pos` is null, i.e. not advanced)
+// cur_rope [B][2][128] (pos_ro = the position array even when `pos` is null, i.e. not advanced).
+// ctr_zero / n_zero: hand-off counter words to clear for the next decode step (nullable).
 
 }  // namespace rdx

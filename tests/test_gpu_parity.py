@@ -238,3 +238,22 @@ def test_chained_mlp_qkv_launch_matches_oracle(cfg, cpu_w, monkeypatch, B):
                 err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
                 assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
         eng.close()
+
+
+def test_step_graph_replays_after_generate_keep_the_handoff_sound(engine, cfg):
+    """Regression: encode -> generate twice, then replay the captured step graph on its own (rdx_time) and generate
+    again. The fused attention + o_proj launch waits on arrival counters; they are cleared by the last kernel of every
+    step, so no replay may time out (a timeout makes the next rdx_generate fail with -5)."""
+    B, T, N = 1, 72, 16
+    ids = _prompt(cfg, B, T, seed=33)
+    img = synth.synth_images(B, cfg.vision.img).to(engine.device)
+    first = None
+    for _ in range(2):
+        q, _ = engine.encode_image(img, want_image_embeds=False)
+        toks, _, n = engine.generate(ids, q, max_new=N, eos_id=-1, use_graph=True)
+        first = toks.clone() if first is None else first
+        assert torch.equal(first, toks)
+    ms = engine.time_unit(0, 10)
+    assert ms < 50.0, f"step graph replay took {ms} ms: a hand-off wait timed out"
+    toks, _, n = engine.generate(ids, q, max_new=N, eos_id=-1, use_graph=True)
+    assert torch.equal(first, toks)
