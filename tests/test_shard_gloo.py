@@ -32,7 +32,7 @@ def _worker(rank, world, port, total, n_new, q):
         else:
             counts = [shard_range(total, world, r)[1] - shard_range(total, world, r)[0] for r in range(world)]
             out = allgather_ragged(toks, counts, world)
-        q.put((rank, out.clone()))
+        q.put((rank, out.tolist()))      # by value: a shared-memory tensor would need this process to outlive the read
     finally:
         dist.destroy_process_group()
 
@@ -53,11 +53,11 @@ def _run(total, n_new, world=2):
 
 def test_allgather_tokens_world2():
     res = _run(total=8, n_new=16)
-    expect = _fake_generate(0, 8, 16)
-    assert torch.equal(res[0], expect) and torch.equal(res[1], expect)
+    expect = _fake_generate(0, 8, 16).tolist()
+    assert res[0] == expect and res[1] == expect
 
 
 def test_allgather_ragged_world2():
     res = _run(total=7, n_new=5)
-    expect = _fake_generate(0, 7, 5)
-    assert torch.equal(res[0], expect) and torch.equal(res[1], expect)
+    expect = _fake_generate(0, 7, 5).tolist()
+    assert res[0] == expect and res[1] == expect
