@@ -140,8 +140,8 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
     };
     if (!HAS_WAIT && w == 0) load_newtok();
     if (owns_rows) {
-        load_k(0, KG_LO, d.max_len);
-        if (V_EARLY) load_v(0, VR_LO, d.max_len);
+        load_k(0, KG_LO, 0x7fffffff);            // unconditional (addresses clamped into the cache): these registers are
+        if (V_EARLY) load_v(0, VR_LO, 0x7fffffff);   // always consumed, with P = 0 for rows past the context
     }
     const int slot = a.slot_b[b];
     const int nk = slot + 1;
@@ -226,7 +226,7 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
 #pragma unroll
         for (int u = 0; u < KG; ++u)
             if (u < KG_LO || (u * CW + cw) * 16 < slot) score_group(kr[u], kmw[u], (u * CW + cw) * 16);   // wave-uniform
-        if (!V_EARLY) { load_v(0, VR_LO, d.max_len); load_v(VR_LO, VR, slot); }      // K registers are free now
+        if (!V_EARLY) { load_v(0, VR_LO, 0x7fffffff); load_v(VR_LO, VR, slot); }     // K registers are free now
         for (int gi = KG * CW + cw; gi * 16 < slot; gi += CW) {                 // contexts beyond the register window
             const int gb = gi * 16;
             const int j = min(gb + r, d.max_len - 1);

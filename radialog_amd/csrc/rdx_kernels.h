@@ -60,6 +60,10 @@ void launch_pack_weight(int dtype, const float* src, void* dst, int N, int K, in
 // must normalise first (launch_rmsnorm) and pass norm_w = null.
 bool skinny_fits_lds(int M, int K);
 void launch_skinny_gemm(int dtype, const GemmArgs& a, int epi, hipStream_t s);
+// 16 < M <= 32 weight-streaming GEMM with the activations staged through LDS and shared by several tiles (skinny32.hip);
+// no fused RMSNorm (a.norm_w must be null)
+bool skinny32_supported(const GemmArgs& a, int epi);
+void launch_skinny32(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 void launch_tiled_gemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s);
 // LDS-DMA GEMM for plain row-major activations (M > 32, K % 64 == 0); `ws` = fp32 split-K workspace (nullable)
 bool gemm_dma_supported(const GemmArgs& a);

@@ -1,0 +1,191 @@
+// Weight-streaming GEMM for 16 < M <= 32 activation rows (batch-32 decode), gfx950.
+//
+// The batch-1 GEMV (skinny_body.h) stages the whole activation block in LDS; at M = 32, K = 4096 that is 256 KiB and does not
+// fit, and streaming the activation fragments from L2 per wave costs 2x the weight bytes per tile (352 MB of L2 traffic for
+// the 180 MB gate/up weights: the kernel ran at half the HBM rate). Here a 16-wave workgroup owns SUB output tiles
+// (16 columns each) with WPS = 16/SUB waves splitting K per tile, exactly like the batch-1 kernel, but the activations
+// are staged through LDS in K stages shared by all the workgroup's tiles: per stage every wave consumes CH chunks of 32
+// (its own K range), so the stage buffer holds [WPS ranges][CH chunks][32 rows][32] elements = 32 KiB at WPS = CH = 4,
+// double-buffered; the activation traffic drops to (rows x K x 2 B) per SUB tiles. Weights: fragment-packed (gemm.hip), one
+// stage ahead in registers (unconditional clamped loads, counted waits). The LDS image of a chunk is [row][32] so a wave's
+// MFMA B-operand read is one contiguous KiB. Fixed-order LDS reduction over the WPS partial tiles, fused epilogues as in
+// skinny_body.h (same rounding points).
+#include "rdx_common.h"
+#include "rdx_kernels.h"
+#include "skinny_body.h"   // swiglu()
+
+namespace rdx {
+
+constexpr int S32_WAVES = 16, S32_THREADS = 1024;
+
+template <typename T, int EPI, int SUB>
+__global__ __launch_bounds__(S32_THREADS, 8) void skinny32_k(GemmArgs a) {
+    typedef typename Vec8<T>::type V8;
+    constexpr int WPS = S32_WAVES / SUB, CH = 16 / WPS, MT = 2;   // WPS * CH = 16 chunk slots per stage: a 32 KiB stage image
+    constexpr int NWS = 8 / CH;                                    // weight ring: 8 chunks (8 KiB) per wave in flight
+    constexpr int STAGE_U4 = WPS * CH * 32 * 4;                  // 16-byte pieces per stage buffer
+    constexpr int XPT = STAGE_U4 / S32_THREADS;                  // pieces per thread per stage
+    static_assert(STAGE_U4 % S32_THREADS == 0, "stage must tile over the workgroup");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm32[];
+    u4* xbuf = reinterpret_cast<u4*>(sm32);                      // [2][WPS][CH][32 rows][4 pieces]
+    float* red = reinterpret_cast<float*>(sm32);                 // after the K loop: [16 waves][MT][256]
+
+    const int lane = threadIdx.x & 63, wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int sub = wa / WPS, w = wa - sub * WPS;
+    const int ntiles = (a.N + 15) >> 4;
+    const int tile = blockIdx.x * SUB + sub, tile_c = min(tile, ntiles - 1);
+    const int r = lane & 15, g = lane >> 4;
+    const int K = a.K, KC = K >> 5;
+    const int c0 = (KC * w) / WPS, c1 = (KC * (w + 1)) / WPS;
+    const int span = (KC + WPS - 1) / WPS;                       // longest K range in chunks
+    const int nst = (span + CH - 1) / CH;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const u4* wbase = reinterpret_cast<const u4*>(a.W) + (size_t)tile_c * KC * 64 + lane;
+    const int clast = min(max(c1 - 1, c0), KC - 1);
+
+    // activation piece -> (range q, chunk j, row m, piece p) of the stage image; global address per stage
+    int xq[XPT], xj[XPT], xm[XPT], xp[XPT];
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+        const int idx = threadIdx.x + i * S32_THREADS;
+        xp[i] = idx & 3; xm[i] = (idx >> 2) & 31; xj[i] = (idx >> 7) % CH; xq[i] = (idx >> 7) / CH;
+    }
+    auto load_x = [&](u4 (&dst)[XPT], int s) {
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) {
+            const int q0 = (KC * xq[i]) / WPS, q1 = (KC * (xq[i] + 1)) / WPS;
+            const int c = q0 + s * CH + xj[i];
+            const bool ok = c < q1 && xm[i] < a.M;
+            const u4 v = ldg16(X + (size_t)min(xm[i], a.M - 1) * a.ldx + (size_t)min(c, KC - 1) * 32 + xp[i] * 8);
+            dst[i] = ok ? v : (u4){0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_x = [&](const u4 (&src)[XPT], int buf) {
+#pragma unroll
+        for (int i = 0; i < XPT; ++i) xbuf[buf * STAGE_U4 + threadIdx.x + i * S32_THREADS] = src[i];
+    };
+    auto load_w = [&](u4 (&dst)[CH], int s) {
+#pragma unroll
+        for (int j = 0; j < CH; ++j) dst[j] = ldg16_nt(wbase + (size_t)min(c0 + s * CH + j, clast) * 64);
+    };
+
+    v4f acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const u4 (&wr)[CH], int s, int buf) {
+        // stage image: piece index ((q*CH + j)*32 + m)*4 + p ; this wave: q = w, lane (g, r) reads row 16*mt + r, piece g
+        const u4* xb = xbuf + buf * STAGE_U4 + (size_t)(w * CH) * 128;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            if (c0 + s * CH + j < c1) {                              // wave-uniform (MFMA ignores EXEC)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const u4 xv = xb[(j * 32 + mt * 16 + r) * 4 + g];
+                    acc[mt] = mfma16(as_vec8<T>(wr[j]), as_vec8<T>(xv), acc[mt]);
+                }
+            }
+        }
+    };
+
+    // Weight ring NWS stages deep, activation image one stage ahead. Every load is unconditional (addresses clamped), so
+    // the waits are counted; stages past the end only issue a few clamped loads and compute nothing (guards in compute()).
+    u4 wr[NWS][CH], xr[XPT];
+#pragma unroll
+    for (int k = 0; k + 1 < NWS; ++k) load_w(wr[k], k);
+    load_x(xr, 0);
+    store_x(xr, 0);
+    __syncthreads();
+    for (int s0 = 0; s0 < nst; s0 += NWS) {
+#pragma unroll
+        for (int k = 0; k < NWS; ++k) {
+            const int s = s0 + k;
+            load_w(wr[(k + NWS - 1) % NWS], s + NWS - 1);
+            load_x(xr, s + 1);
+            compute(wr[k], s, s & 1);
+            store_x(xr, (s + 1) & 1);
+            __syncthreads();
+        }
+    }
+
+    // D[n_local = g*4+reg][m_local = r] -> red[wave][mt][m_local*16 + n_local]   (the stage buffers are free: barrier above)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+        *reinterpret_cast<float4*>(&red[(wa * MT + mt) * 256 + r * 16 + g * 4]) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
+    __syncthreads();
+
+    T* out = reinterpret_cast<T*>(a.out);
+    if (a.out_step && out) out += (size_t)(*a.out_step) * a.out_step_stride;
+    for (int o = threadIdx.x; o < SUB * MT * 256; o += S32_THREADS) {
+        const int so = o / (MT * 256), mt = (o >> 8) % MT, idx = o & 255, m_local = idx >> 4, n_local = idx & 15;
+        const int t_o = blockIdx.x * SUB + so;
+        const int m = mt * 16 + m_local, n = t_o * 16 + n_local;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < WPS; ++i) v += red[((so * WPS + i) * MT + mt) * 256 + idx];
+        if (a.bias && n < a.N) v += a.bias[n];
+        const bool ok = (m < a.M) && (t_o < ntiles) && (n < a.N);
+        if (EPI == EPI_NONE) {
+            if (ok) out[(size_t)m * a.ldo + n] = fromf<T>(v);
+        } else if (EPI == EPI_RESID) {
+            if (ok) {
+                const float rsd = tof<T>(reinterpret_cast<const T*>(a.resid)[(size_t)m * a.ldr + n]);
+                out[(size_t)m * a.ldo + n] = fromf<T>(rsd + rnd<T>(v));
+            }
+        } else if (EPI == EPI_SILU_MUL) {
+            float u = 0.f;
+#pragma unroll
+            for (int i = 0; i < WPS; ++i) u += red[((so * WPS + i) * MT + mt) * 256 + ((idx + 8) & 255)];
+            if (n_local < 8 && ok) out[(size_t)m * a.ldo + t_o * 8 + n_local] = fromf<T>(swiglu<T>(v, u));
+        } else if (EPI == EPI_LOGITS) {
+            float lv = rnd<T>(v);
+            int li = n;
+            const bool valid = n < a.n_valid && t_o < ntiles;
+            if (valid && m < a.M && out) out[(size_t)m * a.ldo + n] = fromf<T>(lv);
+            if (!valid) { lv = -INFINITY; li = 0x7fffffff; }
+            // argmax over the tile's 16 columns (16 consecutive lanes share m); ties -> lowest index (torch.argmax)
+#pragma unroll
+            for (int sh = 8; sh > 0; sh >>= 1) {
+                const float ov = __shfl_xor(lv, sh, 64);
+                const int oi = __shfl_xor(li, sh, 64);
+                if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
+            }
+            if (n_local == 0 && m < a.M && t_o < ntiles) {
+                a.part_val[(size_t)m * ntiles + t_o] = lv;
+                a.part_idx[(size_t)m * ntiles + t_o] = li;
+            }
+        }
+    }
+}
+
+bool skinny32_supported(const GemmArgs& a, int epi) {
+    // measured at M = 32: 4-tile workgroups win for the many-tile GEMMs (gate/up 69 -> 55 us, QKV 46 -> 33, lm_head 92 -> 65);
+    // with <= 512 tiles the 2-tile variant loses to the L2-streaming kernel (o_proj 12.8 -> 19 us, down 31 -> 48)
+    return a.M > 16 && a.M <= 32 && a.K % 32 == 0 && a.K >= 512 && !a.norm_w && (a.N + 15) / 16 > 512 &&
+           (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL || epi == EPI_LOGITS);
+}
+
+template <typename T, int SUB>
+static void launch_skinny32_sub(const GemmArgs& a, int epi, hipStream_t s) {
+    const int nt = (a.N + 15) / 16;
+    dim3 grid((nt + SUB - 1) / SUB), block(S32_THREADS);
+    const size_t stage = (size_t)2 * 16 * 32 * 4 * 16, redb = (size_t)S32_WAVES * 2 * 256 * 4;   // 2 x 32 KiB stage images
+    const size_t smem = stage > redb ? stage : redb;
+    switch (epi) {
+        case EPI_NONE: hipLaunchKernelGGL((skinny32_k<T, EPI_NONE, SUB>), grid, block, smem, s, a); break;
+        case EPI_RESID: hipLaunchKernelGGL((skinny32_k<T, EPI_RESID, SUB>), grid, block, smem, s, a); break;
+        case EPI_SILU_MUL: hipLaunchKernelGGL((skinny32_k<T, EPI_SILU_MUL, SUB>), grid, block, smem, s, a); break;
+        case EPI_LOGITS: hipLaunchKernelGGL((skinny32_k<T, EPI_LOGITS, SUB>), grid, block, smem, s, a); break;
+        default: break;
+    }
+}
+
+void launch_skinny32(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
+    // many tiles: 4 tiles x 4 waves per workgroup; few tiles (<= 512): 2 tiles x 8 waves so that >= 128 CUs stream
+    const int nt = (a.N + 15) / 16;
+    RDX_DISPATCH_T(dtype, T, {
+        if (nt > 512) launch_skinny32_sub<T, 4>(a, epi, s);
+        else launch_skinny32_sub<T, 2>(a, epi, s);
+    });
+}
+
+}  // namespace rdx

@@ -257,3 +257,29 @@ def test_step_graph_replays_after_generate_keep_the_handoff_sound(engine, cfg):
     assert ms < 50.0, f"step graph replay took {ms} ms: a hand-off wait timed out"
     toks, _, n = engine.generate(ids, q, max_new=N, eos_id=-1, use_graph=True)
     assert torch.equal(first, toks)
+
+
+def test_batch18_greedy_tokens_match_oracle(cfg, cpu_w):
+    """16 < batch <= 32 takes the LDS-staged weight-streaming GEMM (csrc/skinny32.hip) for every decode projection and
+    the lm_head, and the 4-wave throughput attention; tokens and logits must match the oracle row by row."""
+    from oracle import ref_cpu
+    from radialog_amd.engine import RdxEngine, synth_getter
+    B, T, N = 18, 96, 8
+    ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, pad_rows=True, seed=3)
+    qf = synth.synth("t.qf18", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    for dtype in ("f16", "bf16"):
+        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=128, lora=True, vision=False)
+        eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+        with torch.no_grad():
+            ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
+        toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
+        toks = toks.cpu().long()
+        tol = LOGIT_TOL[dtype]
+        for b in range(B):
+            for s in range(N):
+                if toks[b, s] != ref["tokens"][b, s]:
+                    assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
+                    break
+                err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
+                assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
+        eng.close()
