@@ -6,8 +6,8 @@
 // (16 columns each) with WPS = 16/SUB waves splitting K per tile, exactly like the batch-1 kernel, but the activations
 // are staged through LDS in K stages shared by all the workgroup's tiles: per stage every wave consumes CH chunks of 32
 // (its own K range), so the stage buffer holds [WPS ranges][CH chunks][32 rows][32] elements = 32 KiB at WPS = CH = 4,
-// double-buffered; the activation traffic drops to (rows x K x 2 B) per SUB tiles. Weights: fragment-packed (gemm.hip), one
-// stage ahead in registers (unconditional clamped loads, counted waits). The LDS image of a chunk is [row][32] so a wave's
+// double-buffered; the activation traffic drops to (rows x K x 2 B) per SUB tiles. Weights: fragment-packed (gemm.hip), a ring of
+// 8 chunks per wave in registers (unconditional clamped loads, counted waits). The LDS image of a chunk is [row][32] so a wave's
 // MFMA B-operand read is one contiguous KiB. Fixed-order LDS reduction over the WPS partial tiles, fused epilogues as in
 // skinny_body.h (same rounding points).
 #include "rdx_common.h"
@@ -37,28 +37,25 @@ __global__ __launch_bounds__(S32_THREADS, 8) void skinny32_k(GemmArgs a) {
     const int r = lane & 15, g = lane >> 4;
     const int K = a.K, KC = K >> 5;
     const int c0 = (KC * w) / WPS, c1 = (KC * (w + 1)) / WPS;
-    const int span = (KC + WPS - 1) / WPS;                       // longest K range in chunks
-    const int nst = (span + CH - 1) / CH;
+    const int nst = KC / (WPS * CH);                             // stages: every wave consumes CH chunks per stage
     const T* X = reinterpret_cast<const T*>(a.X);
-    const u4* wbase = reinterpret_cast<const u4*>(a.W) + (size_t)tile_c * KC * 64 + lane;
+    const u4* wtile = reinterpret_cast<const u4*>(a.W) + (size_t)tile_c * KC * 64;   // wave-uniform
     const int clast = min(max(c1 - 1, c0), KC - 1);
 
-    // activation piece -> (range q, chunk j, row m, piece p) of the stage image; global address per stage
-    int xq[XPT], xj[XPT], xm[XPT], xp[XPT];
+    // activation piece idx -> (range q, chunk j, row m, piece p) of the stage image. K is a multiple of 16 chunks
+    // (skinny32_supported), so every range is a whole number of stages and a piece's address advances by CH chunks per
+    // stage: one base pointer per piece. Rows >= M read row M-1 (finite; their outputs are never stored).
+    unsigned xoff[XPT];                                            // 32-bit element offsets: scalar base + VGPR offset addressing
 #pragma unroll
     for (int i = 0; i < XPT; ++i) {
         const int idx = threadIdx.x + i * S32_THREADS;
-        xp[i] = idx & 3; xm[i] = (idx >> 2) & 31; xj[i] = (idx >> 7) % CH; xq[i] = (idx >> 7) / CH;
+        const int xp = idx & 3, xm = (idx >> 2) & 31, xj = (idx >> 7) % CH, xq = (idx >> 7) / CH;
+        xoff[i] = (unsigned)(min(xm, a.M - 1) * a.ldx + (xq * (KC / WPS) + xj) * 32 + xp * 8);
     }
     auto load_x = [&](u4 (&dst)[XPT], int s) {
+        const unsigned so = (unsigned)(min(s, nst - 1) * (CH * 32));  // stages past the end re-read the last one (unused)
 #pragma unroll
-        for (int i = 0; i < XPT; ++i) {
-            const int q0 = (KC * xq[i]) / WPS, q1 = (KC * (xq[i] + 1)) / WPS;
-            const int c = q0 + s * CH + xj[i];
-            const bool ok = c < q1 && xm[i] < a.M;
-            const u4 v = ldg16(X + (size_t)min(xm[i], a.M - 1) * a.ldx + (size_t)min(c, KC - 1) * 32 + xp[i] * 8);
-            dst[i] = ok ? v : (u4){0u, 0u, 0u, 0u};
-        }
+        for (int i = 0; i < XPT; ++i) dst[i] = ldg16(X + (size_t)(xoff[i] + so));
     };
     auto store_x = [&](const u4 (&src)[XPT], int buf) {
 #pragma unroll
@@ -66,7 +63,7 @@ __global__ __launch_bounds__(S32_THREADS, 8) void skinny32_k(GemmArgs a) {
     };
     auto load_w = [&](u4 (&dst)[CH], int s) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) dst[j] = ldg16_nt(wbase + (size_t)min(c0 + s * CH + j, clast) * 64);
+        for (int j = 0; j < CH; ++j) dst[j] = ldg16_nt(wtile + (size_t)(unsigned)(min(c0 + s * CH + j, clast) * 64 + lane));
     };
 
     v4f acc[MT];
@@ -77,18 +74,19 @@ __global__ __launch_bounds__(S32_THREADS, 8) void skinny32_k(GemmArgs a) {
         const u4* xb = xbuf + buf * STAGE_U4 + (size_t)(w * CH) * 128;
 #pragma unroll
         for (int j = 0; j < CH; ++j) {
-            if (c0 + s * CH + j < c1) {                              // wave-uniform (MFMA ignores EXEC)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const u4 xv = xb[(j * 32 + mt * 16 + r) * 4 + g];
-                    acc[mt] = mfma16(as_vec8<T>(wr[j]), as_vec8<T>(xv), acc[mt]);
-                }
+            for (int mt = 0; mt < MT; ++mt) {
+                const u4 xv = xb[(j * 32 + mt * 16 + r) * 4 + g];
+                acc[mt] = mfma16(as_vec8<T>(wr[j]), as_vec8<T>(xv), acc[mt]);
             }
         }
     };
 
-    // Weight ring NWS stages deep, activation image one stage ahead. Every load is unconditional (addresses clamped), so
-    // the waits are counted; stages past the end only issue a few clamped loads and compute nothing (guards in compute()).
+    // Weight ring NWS stages deep, activation image one stage ahead. Within a stage the activation loads are issued
+    // BEFORE the weight loads: vmcnt is in-order, so the wait in front of the LDS store then leaves this stage's weight
+    // loads in flight (the other order drains the ring every stage). Every load is unconditional (addresses clamped) ->
+    // counted waits; stages past the end compute nothing (guards in compute()). Register budget: 64 VGPRs (two workgroups
+    // per CU) -- a spill reload inside the loop would force vmcnt(0).
     u4 wr[NWS][CH], xr[XPT];
 #pragma unroll
     for (int k = 0; k + 1 < NWS; ++k) load_w(wr[k], k);
@@ -99,9 +97,9 @@ __global__ __launch_bounds__(S32_THREADS, 8) void skinny32_k(GemmArgs a) {
 #pragma unroll
         for (int k = 0; k < NWS; ++k) {
             const int s = s0 + k;
-            load_w(wr[(k + NWS - 1) % NWS], s + NWS - 1);
             load_x(xr, s + 1);
-            compute(wr[k], s, s & 1);
+            load_w(wr[(k + NWS - 1) % NWS], s + NWS - 1);
+            if (s < nst) compute(wr[k], s, s & 1);                  // workgroup-uniform (MFMA ignores EXEC)
             store_x(xr, (s + 1) & 1);
             __syncthreads();
         }
@@ -160,7 +158,7 @@ __global__ __launch_bounds__(S32_THREADS, 8) void skinny32_k(GemmArgs a) {
 bool skinny32_supported(const GemmArgs& a, int epi) {
     // measured at M = 32: 4-tile workgroups win for the many-tile GEMMs (gate/up 69 -> 55 us, QKV 46 -> 33, lm_head 92 -> 65);
     // with <= 512 tiles the 2-tile variant loses to the L2-streaming kernel (o_proj 12.8 -> 19 us, down 31 -> 48)
-    return a.M > 16 && a.M <= 32 && a.K % 32 == 0 && a.K >= 512 && !a.norm_w && (a.N + 15) / 16 > 512 &&
+    return a.M > 16 && a.M <= 32 && a.K % 512 == 0 && !a.norm_w && (a.N + 15) / 16 > 512 &&
            (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL || epi == EPI_LOGITS);
 }
 
@@ -180,12 +178,8 @@ static void launch_skinny32_sub(const GemmArgs& a, int epi, hipStream_t s) {
 }
 
 void launch_skinny32(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
-    // many tiles: 4 tiles x 4 waves per workgroup; few tiles (<= 512): 2 tiles x 8 waves so that >= 128 CUs stream
-    const int nt = (a.N + 15) / 16;
-    RDX_DISPATCH_T(dtype, T, {
-        if (nt > 512) launch_skinny32_sub<T, 4>(a, epi, s);
-        else launch_skinny32_sub<T, 2>(a, epi, s);
-    });
+    // 4 tiles x 4 waves per workgroup (2 tiles x 8 waves measured slower at every shape of the decode step)
+    RDX_DISPATCH_T(dtype, T, launch_skinny32_sub<T, 4>(a, epi, s));
 }
 
 }  // namespace rdx
