@@ -15,6 +15,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from radialog_amd import synth                                              # noqa: E402
 from radialog_amd.blip2_qformer import Config, tasks                        # noqa: E402
+from radialog_amd.chexpert_model import CHEXPERT_COLS, ChexpertClassifier   # noqa: E402
 from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM             # noqa: E402
 from radialog_amd.prompter import new_conversation, report_prompt          # noqa: E402
 from radialog_amd.tokenizer import load_tokenizer                          # noqa: E402
@@ -25,7 +26,10 @@ def parse_args():
     p.add_argument("--cfg-path", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "blip2_pretrain_stage1_emb.yaml"))
     p.add_argument("--options", nargs="+")
     p.add_argument("--image", default=None, help=".png/.jpg chest X-ray; default: synthetic 448x448 image")
-    p.add_argument("--findings", default="no finding")
+    p.add_argument("--findings", default=None, help="predicted-findings text for the prompt; default: run the findings classifier "
+                   "(demo.py:256-261), or 'no finding' with --no-classifier")
+    p.add_argument("--no-classifier", action="store_true")
+    p.add_argument("--chexpert_ckpt", default=None, help="ChexpertClassifier Lightning checkpoint (random-init when absent)")
     p.add_argument("--vicuna", default=None, help="local lmsys/vicuna-7b-v1.3 directory (weights + tokenizer)")
     p.add_argument("--lora_model", default=None, help="adapter dir (adapter_model.bin incl. img_proj_layer)")
     p.add_argument("--max_new_tokens", type=int, default=300)
@@ -33,8 +37,9 @@ def parse_args():
     return p.parse_args()
 
 
-def load_image(path):
-    """demo.py:173-218 (remap_to_uint8 -> PIL 'L') + the inference transform (ReportDataset.py:96-106)."""
+def load_image(path, crop=448):
+    """demo.py:173-218 (remap_to_uint8 -> PIL 'L') + the inference transform (ReportDataset.py:96-106); crop=488 gives the
+    findings classifier's `cp_transforms` (demo.py:169)."""
     import numpy as np
     from PIL import Image
     arr = np.asarray(Image.open(path)).astype(float)
@@ -45,8 +50,8 @@ def load_image(path):
     s = 512 / min(w, h)                                                       # Resize(512): shorter side, bilinear
     img = img.resize((max(512, round(w * s)), max(512, round(h * s))), Image.BILINEAR)
     w, h = img.size
-    l, t = (w - 448) // 2, (h - 448) // 2                                     # CenterCrop(448)
-    img = img.crop((l, t, l + 448, t + 448))
+    l, t = (w - crop) // 2, (h - crop) // 2                                   # CenterCrop(448 | 488)
+    img = img.crop((l, t, l + crop, t + crop))
     x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0)[None]     # ToTensor
     return torch.repeat_interleave(x, 3, dim=0)                               # ExpandChannels
 
@@ -63,6 +68,15 @@ def init_vicuna(args):
     if args.lora_model:
         lang_model.load_adapter(args.lora_model)
     return lang_model.eval(), tok
+
+
+def init_chexpert_predictor(args):
+    """demo.py:155-170: the classifier that fills "Predicted Findings:" for images without precomputed labels."""
+    if args.chexpert_ckpt:
+        return ChexpertClassifier.load_from_checkpoint(args.chexpert_ckpt, num_classes=14, class_names=CHEXPERT_COLS).eval().half()
+    from radialog_amd.engine import synth_getter
+    m = ChexpertClassifier(num_classes=14)
+    return m.set_weight_getter(synth_getter(m.cfg, torch.device("cuda", 0), lora=False)).eval().half()
 
 
 def get_response(blip_model, lang_model, tok, conv, image, findings, max_new_tokens=300):
@@ -88,7 +102,13 @@ def main():
     blip_model = init_blip(cfg).eval()
     lang_model, tok = init_vicuna(args)
     image = load_image(args.image) if args.image else synth.synth_images(1, 448)[0]
-    pred, out = get_response(blip_model, lang_model, tok, new_conversation(), image, args.findings, args.max_new_tokens)
+    findings = args.findings
+    if findings is None and not args.no_classifier:
+        cp_image = load_image(args.image, crop=488) if args.image else synth.synth_images(1, 488)[0]
+        findings = init_chexpert_predictor(args).predict_findings(cp_image[None].half().cuda())[0]
+        print("predicted findings:", findings or "(none)")
+    findings = findings or "no finding"
+    pred, out = get_response(blip_model, lang_model, tok, new_conversation(), image, findings, args.max_new_tokens)
     print(f"generated {out.sequences.shape[1]} ids, {len(out.scores)} steps")
     print("ASSISTANT:", pred[:400])
 

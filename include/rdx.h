@@ -43,6 +43,9 @@ typedef struct rdx_config {
     int max_batch;                                 /* decode rows held in the KV cache                             */
     int max_len;                                   /* KV slots per row (prompt + generated), multiple of 32        */
     int enable_vision, enable_llama;               /* build only one half if 0                                     */
+    /* findings classifier (findings_classifier/chexpert_model.py:7-21): the same trunk + projector (v_*) followed by
+     * avg_pool2d(cls_pool), fc1 -> ReLU -> fc2. A classifier context sets enable_cls = 1 and enable_vision = 0.    */
+    int enable_cls, cls_hidden, cls_classes, cls_pool;
 } rdx_config;
 
 /* lifecycle -- replaces model construction (demo.py:149-153 init_blip, :221-236 init_vicuna) */
@@ -66,6 +69,10 @@ int rdx_encode_image(rdx_ctx* ctx, const float* image, int batch, float* qformer
  * (biovil_t/transformer.py:73-224). No RaDialog caller passes a previous image; optional mode of the encoder. */
 int rdx_encode_image2(rdx_ctx* ctx, const float* image, const float* previous_image, int batch, float* qformer_out,
                       float* image_embeds);
+
+/* ChexpertClassifier.forward (findings_classifier/chexpert_model.py:15-21; call site demo.py:155-170,:256-261):
+ * image float32[B,3,S,S] (S = v_img, 488 in demo.py) -> logits float32[B,cls_classes]; the caller applies sigmoid > 0.5. */
+int rdx_classify_findings(rdx_ctx* ctx, const float* image, int batch, float* logits);
 
 /* LlamaForCausalLM.generate(..., num_beams=1) as the reference calls it (demo.py:290-297, test.py:339-348):
  * greedy search (transformers 4.28.1 GenerationMixin.greedy_search) over LlamaForCausalLM.forward with the image

@@ -48,10 +48,10 @@ def _bn(x, W, pre, eps):
                         training=False, eps=eps)
 
 
-def resnet50_trunk(x: torch.Tensor, W: Dict[str, torch.Tensor], vcfg) -> torch.Tensor:
+def resnet50_trunk(x: torch.Tensor, W: Dict[str, torch.Tensor], vcfg, prefix: str = "visual_encoder.") -> torch.Tensor:
     """torchvision ResNet-50 v1.5 without avgpool/fc (ResNetHIML.forward, biovil_t/resnet.py:25-47).
     x: [B,3,S,S] fp32 -> [B, 4*planes[-1], S/32, S/32]."""
-    P = "visual_encoder.encoder.encoder."
+    P = prefix + "encoder.encoder."
     eps = vcfg.bn_eps
     x = F.conv2d(x, W[P + "conv1.weight"], stride=2, padding=3)
     x = F.relu(_bn(x, W, P + "bn1", eps))
@@ -70,11 +70,11 @@ def resnet50_trunk(x: torch.Tensor, W: Dict[str, torch.Tensor], vcfg) -> torch.T
     return x
 
 
-def patch_fused(images: torch.Tensor, W, vcfg, previous: Optional[torch.Tensor] = None) -> torch.Tensor:
+def patch_fused(images: torch.Tensor, W, vcfg, previous: Optional[torch.Tensor] = None, prefix: str = "visual_encoder.") -> torch.Tensor:
     """MultiImageEncoder.forward (biovil_t/encoder.py:110-136). Single-image branch (:124-130): trunk -> 1x1 conv ->
     concat with the learned constant `missing_previous_emb`. Two-image branch (:117-123): both images through the
     trunk and the 1x1 conv, difference features from the ViT pooler."""
-    E = "visual_encoder.encoder."
+    E = prefix + "encoder."
     B = images.shape[0]
     if previous is not None:
         x = resnet50_trunk(torch.cat([images, previous], dim=0), W, vcfg)
@@ -82,7 +82,7 @@ def patch_fused(images: torch.Tensor, W, vcfg, previous: Optional[torch.Tensor] 
         patch_x, patch_prev = x[:B], x[B:]
         diff_x = vit_pooler(patch_x, patch_prev, W, vcfg)
     else:
-        x = resnet50_trunk(images, W, vcfg)
+        x = resnet50_trunk(images, W, vcfg, prefix)
         patch_x = F.conv2d(x, W[E + "backbone_to_vit.weight"])
         _, _, h, w = patch_x.shape
         diff_x = W[E + "missing_previous_emb"].repeat(B, 1, h, w)
@@ -118,9 +118,9 @@ def vit_pooler(cur: torch.Tensor, prev: torch.Tensor, W, vcfg) -> torch.Tensor:
     return x[:, :L].transpose(1, 2).reshape(B, C, g, g)
 
 
-def projector(patch: torch.Tensor, W, vcfg) -> torch.Tensor:
+def projector(patch: torch.Tensor, W, vcfg, prefix: str = "visual_encoder.") -> torch.Tensor:
     """MLP(use_1x1_convs=True): conv(no bias) -> BN2d -> ReLU -> conv(bias) (biovil_t/modules.py:30-47,:51-54)."""
-    J = "visual_encoder.projector.model."
+    J = prefix + "projector.model."
     x = F.conv2d(patch, W[J + "0.weight"])
     x = F.relu(_bn(x, W, J + "1", vcfg.bn_eps))
     return F.conv2d(x, W[J + "3.weight"], W[J + "3.bias"])
@@ -133,6 +133,18 @@ def image_embeds(images: torch.Tensor, W, vcfg, previous: Optional[torch.Tensor]
     B, C = pp.shape[0], pp.shape[1]
     tok = pp.reshape(B, -1, C)                                           # flat re-chunking (finding 4)
     return F.layer_norm(tok.float(), (C,), W["ln_vision.weight"], W["ln_vision.bias"], vcfg.ln_eps)
+
+
+def findings_logits(images: torch.Tensor, W, vcfg, ccfg) -> torch.Tensor:
+    """ChexpertClassifier.forward (findings_classifier/chexpert_model.py:15-21) -- PARITY UNPINNED (its ImageModel needs
+    torchvision's ResNet, absent here): projected_patch_embeddings [B, C, g, g] -> avg_pool2d(pool) -> view(B, -1) ->
+    relu(fc1) -> fc2. images: [B, 3, S, S] fp32 -> logits [B, classes]; demo.py:258-260 applies sigmoid > 0.5."""
+    pre = "biovil_encoder."
+    pp = projector(patch_fused(images, W, vcfg, None, pre), W, vcfg, pre)
+    x = F.avg_pool2d(pp, ccfg.pool)
+    x = x.view(x.shape[0], -1)
+    x = torch.relu(F.linear(x, W["fc1.weight"], W["fc1.bias"]))
+    return F.linear(x, W["fc2.weight"], W["fc2.bias"])
 
 
 # =====================================================================================================

@@ -41,6 +41,7 @@ class RdxConfig(C.Structure):
         ("v_ln_eps", C.c_float),
         ("max_batch", C.c_int), ("max_len", C.c_int),
         ("enable_vision", C.c_int), ("enable_llama", C.c_int),
+        ("enable_cls", C.c_int), ("cls_hidden", C.c_int), ("cls_classes", C.c_int), ("cls_pool", C.c_int),
     ]
 
 
@@ -56,6 +57,7 @@ SYMBOLS = {
     "rdx_finalize_weights": (C.c_int, [_P]),
     "rdx_encode_image": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "rdx_encode_image2": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
+    "rdx_classify_findings": (C.c_int, [_P, _P, C.c_int, _P]),
     "rdx_generate": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P,
                                C.POINTER(C.c_int), C.c_int]),
     "rdx_prefill": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),

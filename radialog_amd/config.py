@@ -74,7 +74,12 @@ class VisionCfg:
 
     @property
     def grid(self) -> int:
-        return self.img // 32
+        """Side of the trunk's output grid: conv1 /2, maxpool /2, then three stride-2 stages of (g - 1) // 2 + 1
+        (448 -> 14; 488, the findings classifier's crop, -> 16)."""
+        g = self.img // 4
+        for _ in range(3):
+            g = (g - 1) // 2 + 1
+        return g
 
     @property
     def trunk_out(self) -> int:
@@ -86,15 +91,37 @@ class VisionCfg:
 
 
 @dataclass(frozen=True)
+class ClsCfg:
+    """ChexpertClassifier head (findings_classifier/chexpert_model.py:7-21): avg_pool2d(pool) over the projected patch grid,
+    fc1 -> ReLU -> fc2; 14 CheXpert classes (demo.py:157-163)."""
+    hidden: int = 512
+    classes: int = 14
+    pool: int = 4
+
+
+@dataclass(frozen=True)
 class RaDialogCfg:
     llama: LlamaCfg = field(default_factory=LlamaCfg)
     qformer: QFormerCfg = field(default_factory=QFormerCfg)
     vision: VisionCfg = field(default_factory=VisionCfg)
+    cls: ClsCfg = field(default_factory=ClsCfg)
 
 
 def full_cfg(vocab: int = 32001) -> RaDialogCfg:
     """The shapes BASELINE.json's configs are quoted on."""
     return RaDialogCfg(llama=LlamaCfg(vocab=vocab))
+
+
+def classifier_cfg() -> RaDialogCfg:
+    """The findings classifier as demo.py runs it: BioViL-T with its stock 128-wide projector (get_biovil_t_image_encoder,
+    joint_feature_size 128) on a 488 px centre crop -> 16x16 grid -> avg_pool2d(4) -> 128*4*4 -> 512 -> 14."""
+    return RaDialogCfg(vision=VisionCfg(img=488, proj=128), cls=ClsCfg())
+
+
+def small_classifier_cfg() -> RaDialogCfg:
+    """Reduced classifier for parity tests; 136 px exercises the odd intermediate grid sizes (34 -> 17 -> 9 -> 5)."""
+    return RaDialogCfg(vision=VisionCfg(img=136, stem=32, planes=(32, 64, 128, 256), blocks=(1, 2, 2, 1), b2v=64, proj=64),
+                       cls=ClsCfg(hidden=96, classes=14, pool=2))
 
 
 def small_cfg() -> RaDialogCfg:

@@ -90,6 +90,8 @@ struct rdx_ctx {
     int chain_mlp = 0;               // RDX_CHAIN=1: gate/up -> down -> next qkv as one chained launch per layer
     int mega_naps = 1;               // RDX_MEGA_NAPS: poll back-off
     int mega_occ = 8;                // RDX_MEGA_OCC: 8 = two workgroups per CU, 4 = one
+    GemmW cls_fc1, cls_fc2; const float *cls_fc1_b = nullptr, *cls_fc2_b = nullptr;   // findings classifier head
+    void *cls_pooled = nullptr, *cls_h = nullptr, *cls_out = nullptr;
     void* d_cur_rope = nullptr;      // [B][2][128] cos | sin row of each row's current position (written by greedy_step_k)
     MegaLayer* d_mlayers = nullptr; int* d_mctr = nullptr;
     long long* d_mtrace = nullptr;   // set only during rdx_mega_trace
@@ -197,7 +199,14 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
     if (cfg->enable_vision) {
         if (cfg->q_hidden / cfg->q_heads != 64 || cfg->q_hidden % cfg->q_heads)
             return fail(nullptr, -1, "rdx_create: Q-Former head_dim must be 64");
-        if (cfg->v_img % 32) return fail(nullptr, -1, "rdx_create: image size must be a multiple of 32");
+    }
+    if (cfg->enable_vision || cfg->enable_cls) {
+        if (cfg->v_img % 4 || cfg->v_img < 32) return fail(nullptr, -1, "rdx_create: image size must be a multiple of 4, >= 32");
+    }
+    if (cfg->enable_cls) {
+        if (cfg->enable_vision) return fail(nullptr, -1, "rdx_create: a classifier context has enable_vision = 0 (its projector differs)");
+        if (cfg->cls_pool <= 0 || cfg->cls_hidden % 32 || cfg->cls_classes <= 0 || cfg->cls_classes > 16)
+            return fail(nullptr, -1, "rdx_create: classifier needs pool > 0, hidden %% 32 == 0, 1..16 classes");
     }
     rdx_ctx* c = new rdx_ctx();
     c->cfg = *cfg;
@@ -277,6 +286,8 @@ extern "C" int rdx_set_weight(rdx_ctx* c, const char* name, const float* data, i
     HIPCHK(c, hipGetLastError());
     return 0;
 }
+
+static int v_grid(const rdx_config& f);
 
 namespace {
 struct Resolver {
@@ -400,6 +411,8 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         }
         c->q_wkv = R.g("q.cross.wkv", c->n_cross * 2 * H, f.q_enc_width);
         c->q_bkv = R.f("q.cross.bkv", (int64_t)c->n_cross * 2 * H);
+    }
+    if (f.enable_vision || f.enable_cls) {
         // vision trunk
         c->v_conv1 = R.g("v.conv1.w", f.v_stem, 7 * 8 * 4); c->v_conv1_b = R.f("v.conv1.b", f.v_stem);
         int cin = f.v_stem;
@@ -422,10 +435,18 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         c->v_b2v = R.g("v.b2v.w", f.v_b2v, cin);
         c->v_p1 = R.g("v.proj1.w", f.v_proj, f.v_b2v); c->v_p1_b = R.f("v.proj1.b", f.v_proj);
         c->v_p2 = R.g("v.proj2.w", f.v_proj, f.v_proj); c->v_p2_b = R.f("v.proj2.b", f.v_proj);
+    }
+    if (f.enable_cls) {
+        const int gp = v_grid(f) / f.cls_pool;
+        if (gp <= 0 || (f.v_proj * gp * gp) % 32) return fail(c, -1, "classifier: pooled feature width %d must be a positive multiple of 32", f.v_proj * gp * gp);
+        c->cls_fc1 = R.g("cls.fc1.w", f.cls_hidden, f.v_proj * gp * gp); c->cls_fc1_b = R.f("cls.fc1.b", f.cls_hidden);
+        c->cls_fc2 = R.g("cls.fc2.w", f.cls_classes, f.cls_hidden); c->cls_fc2_b = R.f("cls.fc2.b", f.cls_classes);
+    }
+    if (f.enable_vision) {
         c->v_ln_g = R.f("v.ln.g", f.v_proj); c->v_ln_b = R.f("v.ln.b", f.v_proj);
         if (f.q_enc_width != f.v_proj) return fail(c, -1, "q_enc_width %d != v_proj %d", f.q_enc_width, f.v_proj);
         if (c->tens.count("v.pool.emb")) {          // two-image mode is optional: resolve it only when its weights are there
-            const int Cv = f.v_b2v, Pn = (f.v_img / 32) * (f.v_img / 32);
+            const int Cv = f.v_b2v, Pn = v_grid(f) * v_grid(f);
             if (Cv % 32) return fail(c, -1, "ViT pooler needs b2v %% 32 == 0");
             c->pool_emb = R.t("v.pool.emb", (int64_t)2 * Pn * Cv);
             c->pool_ng = R.f("v.pool.norm_g", Cv); c->pool_nb = R.f("v.pool.norm_b", Cv);
@@ -450,6 +471,14 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
 // ------------------------------------------------------------------------------------------------------------------
 // image encode
 // ------------------------------------------------------------------------------------------------------------------
+// side of the trunk's output grid: conv1 /2, maxpool /2, then three stride-2 stages of (g - 1) / 2 + 1 (3x3 pad 1 and the
+// 1x1 downsample agree): 448 -> 14, 488 -> 16
+static int v_grid(const rdx_config& f) {
+    int g = f.v_img / 4;
+    for (int i = 0; i < 3; ++i) g = (g - 1) / 2 + 1;
+    return g;
+}
+
 static int ensure_enc_ws(rdx_ctx* c, int B) {
     if (B <= c->enc_batch) return 0;
     const rdx_config& f = c->cfg;
@@ -458,10 +487,15 @@ static int ensure_enc_ws(rdx_ctx* c, int B) {
     const size_t act = (size_t)B * (S_ / 2) * (S_ / 2) * (size_t)std::max(f.v_stem, 1) * 2;   // conv1 output
     size_t act2 = (size_t)B * (S_ / 4) * (S_ / 4) * (size_t)f.v_planes[0] * 4 * 2;           // layer1 output
     size_t mx = std::max(act, act2);
-    const int P = (S_ / 32) * (S_ / 32);
+    const int P = v_grid(f) * v_grid(f);
     mx = std::max(mx, (size_t)B * P * f.v_proj * 2);
     ALLOC(c, c->vin, (size_t)B * Hp * Hp * 4 * 2);
     for (int i = 0; i < 4; ++i) ALLOC(c, c->vbuf[i], mx);
+    if (f.enable_cls) {
+        ALLOC(c, c->cls_pooled, (size_t)B * c->cls_fc1.K * 2); ALLOC(c, c->cls_h, (size_t)B * f.cls_hidden * 2);
+        ALLOC(c, c->cls_out, (size_t)B * 16 * 2 + (size_t)B * f.cls_classes * 2);
+    }
+    if (!f.enable_vision) { c->enc_batch = B; return 0; }
     ALLOC(c, c->v_imgemb, (size_t)B * P * f.v_proj * 2);
     const size_t M = (size_t)B * f.q_nquery;
     ALLOC(c, c->qx, M * f.q_hidden * 2); ALLOC(c, c->qt, M * f.q_hidden * 2);
@@ -485,10 +519,16 @@ static void conv_gemm(rdx_ctx* c, const void* X, const GemmW& W, const float* bi
     else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
 }
 
-static int encode_impl(rdx_ctx* c, const float* image, const float* previous, int Bimg, float* qformer_out, float* image_embeds) {
+static int encode_impl(rdx_ctx* c, const float* image, const float* previous, int Bimg, float* qformer_out, float* image_embeds,
+                       float* cls_logits = nullptr) {
     if (!c) return -1;
-    if (!c->finalized || !c->cfg.enable_vision) return fail(c, -1, "rdx_encode_image: vision weights not finalized");
-    if (!image || !qformer_out || Bimg <= 0) return fail(c, -1, "rdx_encode_image: bad arguments");
+    if (cls_logits) {
+        if (!c->finalized || !c->cfg.enable_cls) return fail(c, -1, "rdx_classify_findings: classifier weights not finalized");
+        if (!image || Bimg <= 0) return fail(c, -1, "rdx_classify_findings: bad arguments");
+    } else {
+        if (!c->finalized || !c->cfg.enable_vision) return fail(c, -1, "rdx_encode_image: vision weights not finalized");
+        if (!image || !qformer_out || Bimg <= 0) return fail(c, -1, "rdx_encode_image: bad arguments");
+    }
     if (previous && !c->pool_emb) return fail(c, -1, "rdx_encode_image2: the ViT-pooler weights (two-image mode) were not loaded");
     HIPCHK(c, hipSetDevice(c->device));
     int B = previous ? 2 * Bimg : Bimg;            // trunk batch: [current ; previous] like torch.cat (encoder.py:119)
@@ -508,7 +548,7 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
     int C = f.v_stem;
     void *cur = c->vbuf[1], *t1 = c->vbuf[0], *t2 = c->vbuf[2], *t3 = c->vbuf[3];
     for (const VBlock& vb : c->vb) {
-        const int Ho = Hc / vb.stride;
+        const int Ho = (Hc - 1) / vb.stride + 1;      // 3x3 pad 1 and the 1x1 downsample agree (odd sizes: 61 -> 31)
         conv_gemm(c, cur, vb.c1, vb.b1, nullptr, t1, B, Hc, Hc, C, 1, 1, 1, 0, Hc, Hc, EPI_RELU);
         conv_gemm(c, t1, vb.c2, vb.b2, nullptr, t2, B, Hc, Hc, vb.planes, 3, 3, vb.stride, 1, Ho, Ho, EPI_RELU);
         const void* idt = cur;
@@ -552,6 +592,17 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
         { GemmArgs a = gargs(qkv, 2 * Cv, c->v_p1f, c->v_p1f_b, t2, f.v_proj, MP); run_gemm(c, a, EPI_RELU); }
     }
     { GemmArgs a = gargs(t2, f.v_proj, c->v_p2, c->v_p2_b, t3, f.v_proj, MP); run_gemm(c, a, EPI_NONE); }
+    if (cls_logits) {
+        // findings classifier head (chexpert_model.py:16-21): avg_pool2d + flatten, fc1 + ReLU, fc2
+        const int G = Hc, gp = G / f.cls_pool;
+        launch_avgpool_flatten(dt, t3, c->cls_pooled, Bimg, G, f.v_proj, f.cls_pool, s);
+        { GemmArgs a = gargs(c->cls_pooled, f.v_proj * gp * gp, c->cls_fc1, c->cls_fc1_b, c->cls_h, f.cls_hidden, Bimg); run_gemm(c, a, EPI_RELU); }
+        { GemmArgs a = gargs(c->cls_h, f.cls_hidden, c->cls_fc2, c->cls_fc2_b, c->cls_out, f.cls_classes, Bimg); run_gemm(c, a, EPI_NONE); }
+        launch_to_f32(dt, c->cls_out, cls_logits, (size_t)Bimg * f.cls_classes, s);
+        HIPCHK(c, hipStreamSynchronize(s));
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     // a5: NCHW reshape scramble + ln_vision
     launch_scramble_layernorm(dt, t3, c->v_ln_g, c->v_ln_b, c->v_imgemb, image_embeds, Bimg, P, f.v_proj, f.v_ln_eps, s);
     B = Bimg;
@@ -594,6 +645,11 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
 
 extern "C" int rdx_encode_image(rdx_ctx* c, const float* image, int B, float* qformer_out, float* image_embeds) {
     return encode_impl(c, image, nullptr, B, qformer_out, image_embeds);
+}
+
+extern "C" int rdx_classify_findings(rdx_ctx* c, const float* image, int batch, float* logits) {
+    if (!logits) return fail(c, -1, "rdx_classify_findings: null output");
+    return encode_impl(c, image, nullptr, batch, nullptr, nullptr, logits);
 }
 
 extern "C" int rdx_encode_image2(rdx_ctx* c, const float* image, const float* previous_image, int B, float* qformer_out,

@@ -1,4 +1,5 @@
 // Normalisation, layout and bookkeeping kernels (HBM-bound, vectorised where the layout allows).
+#include <algorithm>
 #include "rdx_common.h"
 #include "rdx_kernels.h"
 
@@ -378,6 +379,26 @@ __global__ __launch_bounds__(256) void greedy_step_k(const float* __restrict__ p
         stg16(cur_rope + (size_t)b * 256 + half * 128 + c8, ldg16(tab + (size_t)pos_s * 128 + c8));
     }
 }
+// ---- avg_pool2d(pool) + NCHW flatten of the NHWC projector output (chexpert_model.py:17-18) ----------------------------
+template <typename T>
+__global__ void avgpool_flatten_k(const T* __restrict__ in, T* __restrict__ out, int B, int G, int C, int pool) {
+    const int Gp = G / pool;                       // floor, like F.avg_pool2d
+    const size_t total = (size_t)B * C * Gp * Gp;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % Gp), h = (int)((i / Gp) % Gp), c = (int)((i / ((size_t)Gp * Gp)) % C), b = (int)(i / ((size_t)Gp * Gp * C));
+        float acc = 0.f;
+        for (int dy = 0; dy < pool; ++dy)
+            for (int dx = 0; dx < pool; ++dx)
+                acc += tof<T>(in[(((size_t)b * G + h * pool + dy) * G + w * pool + dx) * C + c]);
+        out[i] = fromf<T>(acc / (float)(pool * pool));      // x.view(B, -1) of [B][C][Gp][Gp]
+    }
+}
+void launch_avgpool_flatten(int dtype, const void* in, void* out, int B, int G, int C, int pool, hipStream_t s) {
+    const size_t total = (size_t)B * C * (G / pool) * (G / pool);
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((avgpool_flatten_k<T>), dim3(blocks), dim3(256), 0, s, (const T*)in, (T*)out, B, G, C, pool));
+}
+
 void launch_greedy_step(int dtype, const float* part_val, const int* part_idx, int n_tiles, int B, int eos_id, int pad_id,
                         int max_new, int* out_tokens, int* unfinished, int* pos, int* slot_b, int* step_b, const void* embed,
                         int vocab, void* x_next, int H, const int* pos_ro, const void* cos_t, const void* sin_t, void* cur_rope,

@@ -134,6 +134,7 @@ void launch_scramble_layernorm(int dtype, const void* pp_nhwc, const float* gamm
 void launch_img_prep(int dtype, const float* img, void* out, int B, int S, int pad, int Hp, int Wp, hipStream_t s);
 void launch_maxpool(int dtype, const void* in, void* out, int B, int H, int W, int C, hipStream_t s);
 void launch_broadcast_rows(int dtype, const void* src, void* dst, int rows, int H, int B, hipStream_t s);
+void launch_avgpool_flatten(int dtype, const void* in, void* out, int B, int G, int C, int pool, hipStream_t s);
 void launch_to_f32(int dtype, const void* src, float* dst, size_t n, hipStream_t s);
 void launch_from_f32(int dtype, const float* src, void* dst, size_t n, hipStream_t s);
 

@@ -25,7 +25,7 @@ def _ptr(t: Optional[torch.Tensor]):
 
 class RdxEngine:
     def __init__(self, cfg: RaDialogCfg, dtype: str = "bf16", device: int = 0, max_batch: int = 1, max_len: int = 512,
-                 lora: bool = True, vision: bool = True, llama: bool = True):
+                 lora: bool = True, vision: bool = True, llama: bool = True, classifier: bool = False):
         if dtype not in _RDX_DT:
             raise ValueError(f"dtype must be 'f16' or 'bf16', got {dtype!r}")
         self.lib = _lib.load()                       # raises RdxLibraryError when the HIP library is absent
@@ -48,7 +48,11 @@ class RdxEngine:
             rc.v_planes[i] = v.planes[i]
             rc.v_blocks[i] = v.blocks[i]
         rc.max_batch, rc.max_len = max_batch, max_len
+        if classifier:                                   # a findings-classifier context: trunk + its own projector + head
+            vision = llama = False
         rc.enable_vision, rc.enable_llama = int(vision), int(llama)
+        rc.enable_cls, rc.cls_hidden, rc.cls_classes, rc.cls_pool = int(classifier), cfg.cls.hidden, cfg.cls.classes, cfg.cls.pool
+        self.classifier = classifier
         self.max_batch, self.max_len = max_batch, max_len
         self.ctx = C.c_void_p()
         rcode = self.lib.rdx_create(C.byref(self.ctx), device, C.byref(rc))
@@ -86,6 +90,12 @@ class RdxEngine:
 
     def load_weights(self, get: Callable[[str], torch.Tensor], vision: bool = True, llama: bool = True):
         """`get(name)` returns the fp32 reference-named tensor (any device). Uploads and finalizes."""
+        if self.classifier:
+            with torch.no_grad():
+                self._upload(W.classifier_items(get, self.cfg.vision, self.cfg.cls))
+            check(self.ctx, self.lib.rdx_finalize_weights(self.ctx), "rdx_finalize_weights")
+            self._finalized = True
+            return
         with torch.no_grad():
             if vision:
                 self._upload(W.vision_items(get, self.cfg.vision))
@@ -189,6 +199,15 @@ class RdxEngine:
                                                eps, force), "rdx_gemm_test")
         return out
 
+    def classify_findings(self, image: torch.Tensor) -> torch.Tensor:
+        """ChexpertClassifier.forward: float32[B,3,S,S] on the device -> float32[B,classes] logits."""
+        image = image.to(self.device, torch.float32).contiguous()
+        B = image.shape[0]
+        out = torch.empty(B, self.cfg.cls.classes, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        check(self.ctx, self.lib.rdx_classify_findings(self.ctx, _ptr(image), B, _ptr(out)), "rdx_classify_findings")
+        return out
+
     def time_unit(self, what: int, iters: int) -> float:
         ms = C.c_float(0)
         check(self.ctx, self.lib.rdx_time(self.ctx, what, iters, C.byref(ms)), "rdx_time")
@@ -215,6 +234,7 @@ def synth_getter(cfg: RaDialogCfg, device, lora: bool = True) -> Callable[[str],
     specs.update(synth.vision_specs(cfg.vision))
     specs.update(synth.qformer_specs(cfg.qformer))
     specs.update(synth.llama_specs(cfg.llama, lora=lora))
+    specs.update(synth.classifier_specs(cfg.vision, cfg.cls))       # `biovil_encoder.*`, fc1, fc2 (classifier contexts)
 
     def get(name: str) -> torch.Tensor:
         shape, gen = specs[name]

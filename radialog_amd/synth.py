@@ -84,9 +84,9 @@ def _u(lo, hi):
     return lambda name, shape, dev: synth(name, shape, lo, hi, dev)
 
 
-def vision_specs(v: VisionCfg) -> Dict[str, Spec]:
+def vision_specs(v: VisionCfg, prefix: str = "visual_encoder.", with_ln: bool = True) -> Dict[str, Spec]:
     sp: Dict[str, Spec] = {}
-    P = "visual_encoder.encoder.encoder."
+    P = prefix + "encoder.encoder."
 
     def conv(name, cout, cin, k):
         sp[name] = ((cout, cin, k, k), _w(math.sqrt(2.0 / (cin * k * k))))
@@ -113,7 +113,7 @@ def vision_specs(v: VisionCfg) -> Dict[str, Spec]:
                 conv(pre + "downsample.0.weight", planes * 4, cin, 1)
                 bn(pre + "downsample.1", planes * 4, gamma=(0.5, 0.9))
             cin = planes * 4
-    E = "visual_encoder.encoder."
+    E = prefix + "encoder."
     sp[E + "backbone_to_vit.weight"] = ((v.b2v, v.trunk_out, 1, 1), _w(math.sqrt(1.0 / v.trunk_out)))
     sp[E + "missing_previous_emb"] = ((1, v.b2v, 1, 1), _w(0.5))
     Pp = E + "vit_pooler."                                   # two-image mode (biovil_t/transformer.py:28-65,:137-224)
@@ -133,13 +133,26 @@ def vision_specs(v: VisionCfg) -> Dict[str, Spec]:
     sp[Pp + "norm_post.weight"] = ((C,), _u(0.8, 1.2))
     sp[Pp + "norm_post.bias"] = ((C,), _u(-0.1, 0.1))
     sp[Pp + "type_embed"] = ((2, 1, C), _w(0.2))
-    J = "visual_encoder.projector.model."
+    J = prefix + "projector.model."
     sp[J + "0.weight"] = ((v.proj, 2 * v.b2v, 1, 1), _w(math.sqrt(2.0 / (2 * v.b2v))))
     bn(J + "1", v.proj)
     sp[J + "3.weight"] = ((v.proj, v.proj, 1, 1), _w(math.sqrt(1.0 / v.proj)))
     sp[J + "3.bias"] = ((v.proj,), _u(-0.05, 0.05))
-    sp["ln_vision.weight"] = ((v.proj,), _u(0.8, 1.2))
-    sp["ln_vision.bias"] = ((v.proj,), _u(-0.1, 0.1))
+    if with_ln:
+        sp["ln_vision.weight"] = ((v.proj,), _u(0.8, 1.2))
+        sp["ln_vision.bias"] = ((v.proj,), _u(-0.1, 0.1))
+    return sp
+
+
+def classifier_specs(v: VisionCfg, c) -> Dict[str, Spec]:
+    """ChexpertClassifier (findings_classifier/chexpert_model.py:8-13): ImageModel under `biovil_encoder.` + fc1, fc2."""
+    sp = vision_specs(v, prefix="biovil_encoder.", with_ln=False)
+    gp = v.grid // c.pool
+    feat = v.proj * gp * gp
+    sp["fc1.weight"] = ((c.hidden, feat), _w(math.sqrt(2.0 / feat)))
+    sp["fc1.bias"] = ((c.hidden,), _u(-0.1, 0.1))
+    sp["fc2.weight"] = ((c.classes, c.hidden), _w(math.sqrt(1.0 / c.hidden)))
+    sp["fc2.bias"] = ((c.classes,), _u(-0.5, 0.5))
     return sp
 
 

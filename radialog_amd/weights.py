@@ -42,8 +42,10 @@ def _khwc(w: torch.Tensor) -> torch.Tensor:
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
 
-def vision_items(get: Getter, v: VisionCfg) -> Iterator[Item]:
-    P = "visual_encoder.encoder.encoder."
+def vision_items(get: Getter, v: VisionCfg, prefix: str = "visual_encoder.", with_ln: bool = True) -> Iterator[Item]:
+    """`prefix` = attribute name of the ImageModel in the owning module: `visual_encoder.` in Blip2Qformer
+    (blip2_qformer.py), `biovil_encoder.` in ChexpertClassifier (chexpert_model.py:10), which has no ln_vision."""
+    P = prefix + "encoder.encoder."
     w, b = _bn_fold(get, get(P + "conv1.weight"), P + "bn1", v.bn_eps)           # [stem,3,7,7]
     w = F.pad(w.permute(0, 2, 3, 1), (0, 1, 0, 1))                                # [stem,7,8,4], zero kw=7 / c=3
     yield "v.conv1.w", w.reshape(v.stem, 7 * 8 * 4).contiguous(), RDX_W_GEMM
@@ -59,9 +61,9 @@ def vision_items(get: Getter, v: VisionCfg) -> Iterator[Item]:
                 w, b = _bn_fold(get, get(pre + "downsample.0.weight"), pre + "downsample.1", v.bn_eps)
                 yield out + "ds.w", _khwc(w), RDX_W_GEMM
                 yield out + "ds.b", b.view(1, -1), RDX_W_F32
-    E = "visual_encoder.encoder."
+    E = prefix + "encoder."
     yield "v.b2v.w", get(E + "backbone_to_vit.weight").reshape(v.b2v, v.trunk_out).contiguous(), RDX_W_GEMM
-    J = "visual_encoder.projector.model."
+    J = prefix + "projector.model."
     w0 = get(J + "0.weight").reshape(v.proj, 2 * v.b2v)
     miss = get(E + "missing_previous_emb").reshape(v.b2v)
     const = w0[:, v.b2v:] @ miss                                                   # contribution of the constant half
@@ -99,8 +101,20 @@ def vision_items(get: Getter, v: VisionCfg) -> Iterator[Item]:
         yield "v.proj1f.b", (get(J + "1.bias") - get(J + "1.running_mean") * scale).view(1, -1), RDX_W_F32
     yield "v.proj2.w", get(J + "3.weight").reshape(v.proj, v.proj).contiguous(), RDX_W_GEMM
     yield "v.proj2.b", get(J + "3.bias").view(1, -1), RDX_W_F32
-    yield "v.ln.g", get("ln_vision.weight").view(1, -1), RDX_W_F32
-    yield "v.ln.b", get("ln_vision.bias").view(1, -1), RDX_W_F32
+    if with_ln:
+        yield "v.ln.g", get("ln_vision.weight").view(1, -1), RDX_W_F32
+        yield "v.ln.b", get("ln_vision.bias").view(1, -1), RDX_W_F32
+
+
+def classifier_items(get: Getter, v: VisionCfg, c) -> Iterator[Item]:
+    """ChexpertClassifier state_dict (findings_classifier/chexpert_model.py:8-13) -> engine tensors: the BioViL-T trunk +
+    projector under `biovil_encoder.`, then fc1 / fc2. fc1's input is x.view(B, -1) of [B, C, g/pool, g/pool] -- the
+    engine's pooling kernel writes exactly that (c, h, w) order, so the weight is used as is."""
+    yield from vision_items(get, v, prefix="biovil_encoder.", with_ln=False)
+    yield "cls.fc1.w", get("fc1.weight").contiguous(), RDX_W_GEMM
+    yield "cls.fc1.b", get("fc1.bias").view(1, -1), RDX_W_F32
+    yield "cls.fc2.w", get("fc2.weight").contiguous(), RDX_W_GEMM
+    yield "cls.fc2.b", get("fc2.bias").view(1, -1), RDX_W_F32
 
 
 def sine_pos_embed(grid: int, dim: int, temperature: float = 10000.0) -> torch.Tensor:

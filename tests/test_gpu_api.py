@@ -47,3 +47,32 @@ def test_forward_image_then_generate_like_demo_and_test_py(tmp_path, monkeypatch
     # plain ids without return_dict
     seq = lm.generate(input_ids=ids, dicom=["a", "b"], max_new_tokens=2, eos_token_id=-1)
     assert torch.is_tensor(seq) and seq.shape == (2, 50)
+
+
+def test_findings_classifier_matches_oracle():
+    """§8f rank 3: ChexpertClassifier inference (trunk + stock projector at an odd-sized grid, avg_pool2d, fc1, fc2)
+    through rdx_classify_findings against the fp32 CPU oracle; predicted label sets must agree wherever the oracle's
+    logit is not within tolerance of the decision boundary."""
+    import torch
+    from oracle import ref_cpu
+    from radialog_amd import synth
+    from radialog_amd.chexpert_model import ChexpertClassifier
+    from radialog_amd.config import small_classifier_cfg
+    cfg = small_classifier_cfg()
+    W = synth.make_weights(synth.classifier_specs(cfg.vision, cfg.cls))
+    img = synth.synth_images(3, cfg.vision.img, seed=5)
+    with torch.no_grad():
+        ref = ref_cpu.findings_logits(img, W, cfg.vision, cfg.cls)
+    for dtype, tol in (("f16", 5e-3), ("bf16", 3e-2)):
+        m = ChexpertClassifier(num_classes=cfg.cls.classes, cfg=cfg, dtype=dtype)
+        m.load_state_dict(W)
+        out = m(img.cuda()).float().cpu()
+        assert out.shape == ref.shape and torch.isfinite(out).all()
+        scale = float(ref.abs().max().clamp_min(1.0))
+        err = float((out - ref).abs().max())
+        assert err < 4 * tol * scale, f"{dtype}: logits differ by {err}"
+        far = ref.abs() > 4 * tol * scale
+        assert torch.equal((out > 0)[far], (ref > 0)[far])
+        labels = m.predict_findings(img.cuda())
+        assert len(labels) == 3 and all(isinstance(s, str) for s in labels)
+        m._engine.close()

@@ -113,3 +113,26 @@ def test_llama_fused_layouts():
     cos, _ = items["rope.cos"]
     ref_cos, _ = ref_cpu.rope_tables(cfg.head_dim, cfg.max_pos, cfg.rope_base, torch.float32)
     assert torch.equal(cos, ref_cos)
+
+
+def test_classifier_items_cover_the_reference_state_dict():
+    """ChexpertClassifier weights (`biovil_encoder.*`, fc1, fc2) -> engine tensors: every reference tensor is consumed, the
+    head keeps its shapes, the odd-sized grid is computed like torch's conv arithmetic."""
+    from radialog_amd import synth, weights
+    from radialog_amd.config import classifier_cfg, small_classifier_cfg
+    assert classifier_cfg().vision.grid == 16 and small_classifier_cfg().vision.grid == 5
+    cfg = small_classifier_cfg()
+    W = synth.make_weights(synth.classifier_specs(cfg.vision, cfg.cls))
+    used = set()
+
+    def get(name):
+        used.add(name)
+        return W[name]
+
+    items = {n: (t, k) for n, t, k in weights.classifier_items(get, cfg.vision, cfg.cls)}
+    gp = cfg.vision.grid // cfg.cls.pool
+    assert items["cls.fc1.w"][0].shape == (cfg.cls.hidden, cfg.vision.proj * gp * gp)
+    assert items["cls.fc2.w"][0].shape == (cfg.cls.classes, cfg.cls.hidden)
+    assert "v.ln.g" not in items and "v.proj2.w" in items
+    unused = {k for k in W if k not in used and "vit_pooler" not in k and "num_batches" not in k}
+    assert not unused, sorted(unused)[:5]
