@@ -10,6 +10,7 @@
 //   decode_attention_k   one new token per row: LoRA + RoPE + in-place KV append + attention over the HBM KV cache.
 //                        Bandwidth-bound: K/V rows are streamed once with 16-byte loads (one cache row = 16 lanes),
 //                        wavefront-shuffle reductions for the dot products and the softmax.
+#include <stdlib.h>
 #include "rdx_common.h"
 #include "rdx_kernels.h"
 #include "attn_body.h"
@@ -253,7 +254,9 @@ __global__ __launch_bounds__(WAVES * 64) void decode_attention_k(DecAttnArgs a) 
 
 void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s) {
     dim3 grid(a.d.heads, B);
-    if (a.d.heads * B <= 256) {
+    const char* tp_env = getenv("RDX_ATT_TP");                       // tests: force the throughput variant
+    const int force_tp = tp_env ? atoi(tp_env) : 0;
+    if (a.d.heads * B <= 256 && !force_tp) {
         const size_t smem = decode_attention_smem_floats(DA_WAVES, a.d.max_len) * sizeof(float);
         RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T, DA_WAVES>), grid, dim3(DA_WAVES * 64), smem, s, a));
     } else {

@@ -283,3 +283,33 @@ def test_batch18_greedy_tokens_match_oracle(cfg, cpu_w):
                 err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
                 assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
         eng.close()
+
+
+@pytest.mark.parametrize("B,tp", [(1, 0), (3, 0), (3, 1)])
+def test_long_context_decode_streams_past_the_register_window(cfg, cpu_w, B, tp, monkeypatch):
+    """Multi-turn prompts (test.py:440-674: report + follow-up question, 400-700 tokens) put the context beyond the 480
+    positions decode attention holds in registers; the rest streams through the MFMA / dot2 tail loops. T = 600 here.
+    tp = 1 forces the 4-wave throughput variant that batch-32 decode uses (128-position window)."""
+    from oracle import ref_cpu
+    if tp:
+        monkeypatch.setenv("RDX_ATT_TP", "1")
+    from radialog_amd.engine import RdxEngine, synth_getter
+    T, N = 600, 6
+    ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, pad_rows=False, seed=11)
+    qf = synth.synth("t.qfL", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    for dtype in ("f16", "bf16"):
+        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=640, lora=True, vision=False)
+        eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+        with torch.no_grad():
+            ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
+        toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
+        toks = toks.cpu().long()
+        tol = LOGIT_TOL[dtype]
+        for b in range(B):
+            for s in range(N):
+                if toks[b, s] != ref["tokens"][b, s]:
+                    assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
+                    break
+                err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
+                assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
+        eng.close()
