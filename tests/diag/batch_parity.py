@@ -1,3 +1,5 @@
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import sys, torch
 from radialog_amd import synth
 from radialog_amd.config import small_cfg

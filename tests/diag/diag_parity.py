@@ -1,6 +1,6 @@
 """Print actual parity errors (GPU box)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 from radialog_amd import synth
 from radialog_amd.config import small_cfg
