@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--prompt-len", type=int, default=160)
+    ap.add_argument("--fp8", action="store_true", help="decoder GEMM weights in e4m3 + per-row scale (BASELINE configs[4] weight path); "
+                    "not the parity configuration: its oracle is the reference math on the fake-quantised weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     return ap.parse_args()
@@ -159,7 +161,7 @@ def main():
     cfg = full_cfg()
     B, T, N = args.batch, args.prompt_len, args.new_tokens
     max_len = (T + N + 64 + 31) // 32 * 32
-    eng = RdxEngine(cfg, dtype=args.dtype, device=local_rank, max_batch=B, max_len=max_len, lora=True)
+    eng = RdxEngine(cfg, dtype=args.dtype, device=local_rank, max_batch=B, max_len=max_len, lora=True, weights_fp8=args.fp8)
     eng.load_weights(synth_getter(cfg, eng.device, lora=True))
 
     # this rank's shard of the (synthetic) image batch and prompts, resident in HBM before the timed region
@@ -208,7 +210,8 @@ def main():
         # dominant kernel: gate/up SwiGLU GEMV, HIP events on the library's stream
         lc = cfg.llama
         gu_ms = eng.time_unit(1, 10)
-        gu_bytes = 2 * lc.inter * lc.hidden * 2 + B * lc.hidden * 2 + lc.hidden * 2 + B * lc.inter * 2
+        wb = 1 if (args.fp8 and B <= 4) else 2                          # bytes per streamed weight element in the decode GEMVs
+        gu_bytes = 2 * lc.inter * lc.hidden * wb + B * lc.hidden * 2 + lc.hidden * 2 + B * lc.inter * 2
         # whole-decode average: one report minus its encode and its prefill (+ first token), over the N-1 graph-replayed steps
         torch.cuda.synchronize()
         t2 = time.perf_counter()
@@ -220,12 +223,11 @@ def main():
         kv_bytes = B * (T + N / 2.0) * 524288 + B * 524288          # 2 x 32 layers x 4096 x 2 B per cached token
         step_ms = eng.time_unit(0, 20)
         L_avg = T + 64      # rdx_time(0) replays from the state left by the last generate (slot ~ T+N) -- report as measured
-        step_bytes = (32 * (4 * lc.hidden ** 2 + 3 * lc.hidden * lc.inter + 2 * lc.hidden) + lc.hidden + lc.vocab * lc.hidden) * 2
+        step_bytes = (32 * (4 * lc.hidden ** 2 + 3 * lc.hidden * lc.inter) + lc.vocab * lc.hidden) * wb + (32 * 2 * lc.hidden + lc.hidden) * 2
         roof = {
-            "bound": "hbm", "kernel": "skinny_gemm_k<bf16,MT,EPI_SILU_MUL,NORM> (gate/up SwiGLU GEMV)" if args.dtype == "bf16"
-            else "skinny_gemm_k<f16,MT,EPI_SILU_MUL,NORM> (gate/up SwiGLU GEMV)",
+            "bound": "hbm", "kernel": f"skinny_gemm_k<{args.dtype},MT,EPI_SILU_MUL,NORM{',W8' if wb == 1 else ''}> (gate/up SwiGLU GEMV)",
             "achieved": gu_bytes / (gu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(B, args.dtype),
+            "frac": gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None if args.fp8 else pmc_traffic(B, args.dtype),      # PMC pass exists for the bf16 configuration only
             "bytes_per_launch": gu_bytes, "us_per_launch": gu_ms * 1e3,
             "decode_step_ms": step_ms, "decode_step_weight_GBs": step_bytes / (step_ms * 1e-3) / 1e9,
             "decode_step_frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -238,9 +240,10 @@ def main():
             "value": args.steps * B * world / elapsed, "unit": "reports/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype + ("+fp8w" if args.fp8 else ""), "data": "synthetic",
             "config": {"workload": f"configs[{1 if B == 1 else 2}]: per-GPU batch {B} BioViL-T(ResNet-50)+Q-Former encode 448px, "
-                                   f"Vicuna-7B prefill T={T}, {N}-token greedy decode (LoRA r=8 un-merged, hipGraph step={use_graph})",
+                                   f"Vicuna-7B prefill T={T}, {N}-token greedy decode (LoRA r=8 un-merged, hipGraph step={use_graph}"
+                                   + (", fp8 e4m3 decoder weights + per-row scale [configs[4] weight path]" if args.fp8 else "") + ")",
                        "per_gpu_batch": B, "global_batch": B * world, "prompt_len": T, "new_tokens": N,
                        "parallelism": f"dp{world}", "weights": "random-init (deterministic generator)"},
             "encoder_ms_per_img": enc_ms,

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librdx.so")
 
 RDX_DTYPE_F16, RDX_DTYPE_BF16 = 0, 1
-RDX_W_GEMM, RDX_W_TENSOR, RDX_W_F32 = 0, 1, 2
+RDX_W_GEMM, RDX_W_TENSOR, RDX_W_F32, RDX_W_GEMM_FP8 = 0, 1, 2, 3
 
 
 class RdxLibraryError(RuntimeError):

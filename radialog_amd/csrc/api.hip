@@ -20,7 +20,7 @@ using namespace rdx;
 
 namespace {
 
-struct GemmW { void* w = nullptr; int N = 0, K = 0, Npad = 0; };
+struct GemmW { void* w = nullptr; int N = 0, K = 0, Npad = 0; void* w8 = nullptr; float* scale = nullptr; };   // w8/scale: fp8 copy
 struct RawW { void* p = nullptr; int64_t rows = 0, cols = 0; };
 
 struct LlamaLayer {
@@ -155,6 +155,7 @@ static GemmArgs gargs(const void* X, int ldx, const GemmW& W, const float* bias,
     memset(&a, 0, sizeof(a));
     a.X = X; a.ldx = ldx; a.W = W.w; a.bias = bias; a.out = out; a.ldo = ldo;
     a.M = M; a.N = W.N; a.K = W.K; a.n_valid = W.N;
+    a.W8 = W.w8; a.wscale = W.scale;
     return a;
 }
 
@@ -265,6 +266,16 @@ extern "C" int rdx_set_weight(rdx_ctx* c, const char* name, const float* data, i
         w.N = (int)rows; w.K = (int)cols; w.Npad = (int)((rows + 15) / 16 * 16);
         ALLOC(c, w.w, (size_t)w.Npad * w.K * esz(c));
         launch_pack_weight(c->cfg.dtype, data, w.w, w.N, w.K, w.Npad, nullptr, c->stream);
+        c->gemm[key] = w;
+    } else if (kind == RDX_W_GEMM_FP8) {
+        if (cols % 64) return fail(c, -1, "rdx_set_weight(%s): fp8 GEMM K=%lld must be a multiple of 64", name, (long long)cols);
+        if (c->gemm.count(key)) return fail(c, -1, "rdx_set_weight(%s): duplicate", name);
+        GemmW w;
+        w.N = (int)rows; w.K = (int)cols; w.Npad = (int)((rows + 15) / 16 * 16);
+        ALLOC(c, w.w, (size_t)w.Npad * w.K * esz(c));            // dequantised copy (prefill, batch > 4)
+        ALLOC(c, w.w8, (size_t)w.Npad * w.K);
+        ALLOC(c, w.scale, (size_t)w.Npad * sizeof(float));
+        launch_pack_weight_fp8(c->cfg.dtype, data, w.w8, w.scale, w.w, w.N, w.K, w.Npad, c->stream);
         c->gemm[key] = w;
     } else if (kind == RDX_W_TENSOR) {
         if (c->tens.count(key)) return fail(c, -1, "rdx_set_weight(%s): duplicate", name);
@@ -1003,8 +1014,15 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
     GemmW w;
     w.N = N; w.K = K; w.Npad = N;
     void* wp = nullptr;
-    HIPCHK(c, hipMalloc(&wp, (size_t)N * K * 2));
+    HIPCHK(c, hipMalloc(&wp, (size_t)N * K * 2 + (force == 4 ? (size_t)N * K + (size_t)N * 4 : 0)));
     w.w = wp;
+    if (force == 4) {                     // fp8 weights: quantise here, stream the e4m3 bytes
+        if (K % 64) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: fp8 needs K %% 64 == 0"); }
+        w.w8 = (char*)wp + (size_t)N * K * 2;
+        w.scale = (float*)((char*)wp + (size_t)N * K * 3);
+        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, wp, N, K, N, c->stream);
+        force = 1;
+    } else
     launch_pack_weight(c->cfg.dtype, W, wp, N, K, N, nullptr, c->stream);
     GemmArgs a = gargs(X, K, w, bias, out, epi == EPI_SILU_MUL ? N / 2 : N, M);
     a.resid = resid; a.ldr = N;

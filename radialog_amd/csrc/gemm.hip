@@ -58,21 +58,74 @@ void launch_pack_weight(int dtype, const float* src, void* dst, int N, int K, in
                                                 Npad, rowmap));
 }
 
+// fp8 weights: one workgroup per output row. scale = absmax / 448 (e4m3 max), q = RNE(w * (448 / absmax)); stored in the
+// 64-deep fragment order Wq[n_tile16][k_chunk64][lane][16]: lane (g<<4)|r <-> W[16*nt + r][64*kc + 16*g .. +16], so one
+// wave-wide 16-byte load feeds TWO mfma_16x16x32 (bytes 0..7 and 8..15 of every lane; the activation fragment is read at the
+// matching k offsets). Also writes the dequantised model-dtype copy T(q * scale) in the standard order for the kernels
+// that do not read fp8 (prefill, batch > 4).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_fp8_k(const float* __restrict__ src, unsigned char* __restrict__ dst8,
+                                                         float* __restrict__ scale, T* __restrict__ dst, int N, int K, int Npad) {
+    __shared__ float red[32];
+    const int i = blockIdx.x;                              // output row (padded rows are zero)
+    const bool real = i < N;
+    float mx = 0.f;
+    if (real) for (int k = threadIdx.x; k < K; k += blockDim.x) mx = fmaxf(mx, fabsf(src[(size_t)i * K + k]));
+    mx = block_max(mx, red);
+    const float sc = mx > 0.f ? mx / 448.0f : 1.0f, inv = mx > 0.f ? 448.0f / mx : 1.0f;
+    if (threadIdx.x == 0) scale[i] = sc;
+    const int KC8 = K >> 6, KC = K >> 5, nt = i >> 4, r = i & 15;
+    for (int q = threadIdx.x; q < (K >> 4); q += blockDim.x) {          // 16 consecutive k per step
+        float w[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) w[j] = real ? src[(size_t)i * K + (size_t)q * 16 + j] * inv : 0.f;
+        unsigned d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int v = 0;
+            v = __builtin_amdgcn_cvt_pk_fp8_f32(w[4 * j], w[4 * j + 1], v, false);
+            v = __builtin_amdgcn_cvt_pk_fp8_f32(w[4 * j + 2], w[4 * j + 3], v, true);
+            d[j] = (unsigned)v;
+        }
+        const int kc = q >> 2, g = q & 3;
+        reinterpret_cast<u4*>(dst8)[((size_t)nt * KC8 + kc) * 64 + (g * 16 + r)] = (u4){d[0], d[1], d[2], d[3]};
+        // dequantised copy, standard order: chunks of 8 k -> ((nt*KC + k/32)*64 + ((k%32)/8)*16 + r)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            typename Vec8<T>::type v;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const auto f0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)d[2 * h + j], false);
+                const auto f1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)d[2 * h + j], true);
+                v[4 * j] = fromf<T>(f0[0] * sc); v[4 * j + 1] = fromf<T>(f0[1] * sc);
+                v[4 * j + 2] = fromf<T>(f1[0] * sc); v[4 * j + 3] = fromf<T>(f1[1] * sc);
+            }
+            const int k0 = q * 16 + h * 8;
+            reinterpret_cast<u4*>(dst)[((size_t)nt * KC + (k0 >> 5)) * 64 + (((k0 & 31) >> 3) * 16 + r)] = as_u4<T>(v);
+        }
+    }
+}
+
+void launch_pack_weight_fp8(int dtype, const float* src, void* dst8, float* scale, void* dst, int N, int K, int Npad, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((pack_weight_fp8_k<T>), dim3(Npad), dim3(256), 0, s, src, (unsigned char*)dst8,
+                                                scale, (T*)dst, N, K, Npad));
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // skinny GEMM (body in skinny_body.h)
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T, int MT, int EPI, bool NORM, int WAVES, bool XLDS>
+template <typename T, int MT, int EPI, bool NORM, int WAVES, bool XLDS, bool W8 = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 8 : 1) void skinny_gemm_k(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dyn_smem[];
-    skinny_tile<T, MT, EPI, NORM, WAVES, XLDS>(a, blockIdx.x, gridDim.x, dyn_smem, NoWait());
+    skinny_tile<T, MT, EPI, NORM, WAVES, XLDS, NoWait, false, W8>(a, blockIdx.x, gridDim.x, dyn_smem, NoWait());
 }
 
-template <typename T, int MT, bool NORM, int WAVES, bool XLDS>
+template <typename T, int MT, bool NORM, int WAVES, bool XLDS, bool W8 = false>
 static void launch_skinny_epi(const GemmArgs& a, int epi, hipStream_t s) {
     const int nt = (a.N + 15) / 16;
     dim3 grid(nt), block(WAVES * 64);
     const size_t dyn = XLDS ? (size_t)a.M * a.K * 2 : 0;
-#define RDX_SK(E) hipLaunchKernelGGL((skinny_gemm_k<T, MT, E, NORM, WAVES, XLDS>), grid, block, dyn, s, a)
+#define RDX_SK(E) hipLaunchKernelGGL((skinny_gemm_k<T, MT, E, NORM, WAVES, XLDS, W8>), grid, block, dyn, s, a)
     switch (epi) {
         case EPI_NONE: RDX_SK(EPI_NONE); break;
         case EPI_RELU: RDX_SK(EPI_RELU); break;
@@ -95,7 +148,9 @@ static void launch_skinny_T(const GemmArgs& a, int epi, hipStream_t s) {
     // few output tiles (N <= 4096 -> at most one workgroup per CU): 16 waves per workgroup put twice as many
     // weight loads in flight per CU
     static const int wide = getenv("RDX_SK_WIDE") ? atoi(getenv("RDX_SK_WIDE")) : 1;
+    const bool w8 = a.W8 && a.wscale && skinny_fits_lds(a.M, a.K) && a.K % 64 == 0;   // fp8 weight stream (else: the dequantised copy)
     if (wide && skinny_fits_lds(a.M, a.K) && (a.N + 15) / 16 <= 256 && a.K >= 4096) {
+        if (w8) { if (norm) launch_skinny_epi<T, 1, true, 16, true, true>(a, epi, s); else launch_skinny_epi<T, 1, false, 16, true, true>(a, epi, s); return; }
         if (norm) launch_skinny_epi<T, 1, true, 16, true>(a, epi, s); else launch_skinny_epi<T, 1, false, 16, true>(a, epi, s);
         return;
     }
@@ -103,10 +158,12 @@ static void launch_skinny_T(const GemmArgs& a, int epi, hipStream_t s) {
     // whole GEMV runs as ONE round of workgroups sharing HBM evenly instead of 2-4 quantised rounds
     static const int smallwg = getenv("RDX_SK_SMALLWG") ? atoi(getenv("RDX_SK_SMALLWG")) : 1;
     if (smallwg && skinny_fits_lds(a.M, a.K) && (a.N + 15) / 16 > 512 && (size_t)a.M * a.K * 2 <= 16 * 1024) {
+        if (w8) { if (norm) launch_skinny_epi<T, 1, true, 4, true, true>(a, epi, s); else launch_skinny_epi<T, 1, false, 4, true, true>(a, epi, s); return; }
         if (norm) launch_skinny_epi<T, 1, true, 4, true>(a, epi, s); else launch_skinny_epi<T, 1, false, 4, true>(a, epi, s);
         return;
     }
     if (skinny_fits_lds(a.M, a.K)) {
+        if (w8) { if (norm) launch_skinny_epi<T, 1, true, WV, true, true>(a, epi, s); else launch_skinny_epi<T, 1, false, WV, true, true>(a, epi, s); return; }
         if (norm) launch_skinny_epi<T, 1, true, WV, true>(a, epi, s); else launch_skinny_epi<T, 1, false, WV, true>(a, epi, s);
     } else if (a.M <= 16) {
         launch_skinny_epi<T, 1, false, WV, false>(a, epi, s);     // caller pre-normalises (rmsnorm_k) when needed

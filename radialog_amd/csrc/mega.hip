@@ -37,9 +37,10 @@ struct MegaGemm {                                // one weight-streaming unit
     void* out; int ldo;
     int M, N, K;
     const void* norm_w; float eps;
+    const void* W8; const float* wscale;         // fp8 weights (64-deep fragment order) + per-row scale, see skinny_body.h
 };
 
-template <typename T, int EPI, bool NORM, int SUB, int XL, typename WaitFn, int U = 4, bool RESID_EARLY = false>
+template <typename T, int EPI, bool NORM, int SUB, int XL, typename WaitFn, int U = 4, bool RESID_EARLY = false, bool W8 = false>
 __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const int ntiles, unsigned char* smem, WaitFn wait_inputs) {
     typedef typename Vec8<T>::type V8;
     constexpr int WPS = MG_WAVES / SUB;           // waves per tile
@@ -54,10 +55,10 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
     const int tile = wg * SUB + sub;
     const int tile_c = min(tile, ntiles - 1);     // ragged last workgroup: duplicate loads, masked stores
     const int r = lane & 15, g = lane >> 4;
-    const int K = a.K, KC = K >> 5;
+    const int K = a.K, KC = W8 ? (K >> 6) : (K >> 5);                   // W8: a chunk is 64 k-values (16 fp8 bytes per lane, two MFMAs)
     const int c0 = (KC * w) / WPS, c1 = (KC * (w + 1)) / WPS;
     const T* X = reinterpret_cast<const T*>(a.X);
-    const u4* wbase = reinterpret_cast<const u4*>(a.W) + (size_t)tile_c * KC * 64 + lane;
+    const u4* wbase = reinterpret_cast<const u4*>(W8 ? a.W8 : a.W) + (size_t)tile_c * KC * 64 + lane;
     const int clast = min(max(c1 - 1, c0), KC - 1);
 
     // two register batches (A, B) in flight before anything else; the main loop ping-pongs between them (no register
@@ -145,7 +146,7 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
     }
 
     const bool xok = r < a.M;
-    const T* xrow = xs + (size_t)(xok ? r : 0) * K + g * 8;
+    const T* xrow = xs + (size_t)(xok ? r : 0) * K + g * (W8 ? 16 : 8);
     v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
     // Main loop: loads are UNCONDITIONAL (addresses clamped into the slice) and no MFMA is guarded, so the compiler can
     // wait with counted vmcnt (one batch stays in flight); a conditional load anywhere in the loop makes it fall back
@@ -154,8 +155,17 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!guard || cb + u < c1) {
-                const u4 xv = xok ? *reinterpret_cast<const u4*>(xrow + (size_t)(cb + u) * 32) : (u4){0u, 0u, 0u, 0u};
-                acc = mfma16(as_vec8<T>(wreg[u]), as_vec8<T>(xv), acc);
+                if (W8) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u4 wd = dequant8<T>(h ? wreg[u].z : wreg[u].x, h ? wreg[u].w : wreg[u].y);
+                        const u4 xv = xok ? *reinterpret_cast<const u4*>(xrow + (size_t)(cb + u) * 64 + h * 8) : (u4){0u, 0u, 0u, 0u};
+                        acc = mfma16(as_vec8<T>(wd), as_vec8<T>(xv), acc);
+                    }
+                } else {
+                    const u4 xv = xok ? *reinterpret_cast<const u4*>(xrow + (size_t)(cb + u) * 32) : (u4){0u, 0u, 0u, 0u};
+                    acc = mfma16(as_vec8<T>(wreg[u]), as_vec8<T>(xv), acc);
+                }
             }
         }
     };
@@ -190,6 +200,7 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
             v[j] = 0.f;
 #pragma unroll
             for (int i = 0; i < WPS; ++i) v[j] += red[(so * WPS + i) * 256 + m * 16 + q * 4 + j];
+            if (W8) v[j] *= a.wscale[t_o * 16 + q * 4 + j];
         }
         unsigned long long pk = 0ull;
         if (EPI == EPI_NONE) {
@@ -212,6 +223,7 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
                 float u = 0.f;
 #pragma unroll
                 for (int i = 0; i < WPS; ++i) u += red[(so * WPS + i) * 256 + m * 16 + 8 + q * 4 + j];
+                if (W8) u *= a.wscale[t_o * 16 + 8 + q * 4 + j];
                 pk |= (unsigned long long)bits16<T>(fromf<T>(swiglu<T>(v[j], u))) << (16 * j);
             }
             if (ok) st8_agent(out + (size_t)m * a.ldo + t_o * 8 + q * 4, pk);
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(MG_THREADS, OCC) void decode_layers_k(MegaArgs ma) 
 // output stored write-through. Workgroups [heads*B, +ntiles/2): two o_proj tiles each (8 waves per tile), whose WHOLE
 // K slice (16 chunks per wave) goes in flight at entry and sits in registers while attention runs; then the fence-free
 // hand-off (handoff.h) and ~2 us of work. heads*B + ntiles/2 <= 256 workgroups of <= 128 VGPRs: all resident, one per CU.
-template <typename T>
+template <typename T, bool W8>
 __global__ __launch_bounds__(MG_THREADS, 4) void attn_oproj16_k(DecAttnArgs at, MegaGemm g, int n_attn, int ntiles, int* counter, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char msm[];
     if ((int)blockIdx.x < n_attn) {
@@ -298,7 +310,7 @@ __global__ __launch_bounds__(MG_THREADS, 4) void attn_oproj16_k(DecAttnArgs at, 
         decode_attention_body<T, MG_WAVES, true, NoWait, true, 0, true>(at, h, b, reinterpret_cast<float*>(msm));
         publish_sc1(counter, blockIdx.x);
     } else {
-        mega_tile<T, EPI_RESID, false, 2, 2, WaitSharded, 8, true>(g, blockIdx.x - n_attn, ntiles, msm, WaitSharded{counter, n_attn, err, 1, nullptr});
+        mega_tile<T, EPI_RESID, false, 2, 2, WaitSharded, W8 ? 4 : 8, true, W8>(g, blockIdx.x - n_attn, ntiles, msm, WaitSharded{counter, n_attn, err, 1, nullptr});
     }
 }
 
@@ -310,12 +322,16 @@ bool attn_oproj16_supported(const LlamaDims& d, int N, int K, int B) {
 
 void launch_attn_oproj16(int dtype, const DecAttnArgs& a, const GemmArgs& ga, int B, int* counter, int* err, hipStream_t s) {
     const int n_attn = a.d.heads * B, ntiles = (ga.N + 15) / 16;
-    MegaGemm g = {ga.X, ga.ldx, ga.W, ga.resid, ga.ldr, ga.out, ga.ldo, ga.M, ga.N, ga.K, nullptr, 0.f};
+    const bool w8 = ga.W8 && ga.wscale && ga.K % 64 == 0;
+    MegaGemm g = {ga.X, ga.ldx, ga.W, ga.resid, ga.ldr, ga.out, ga.ldo, ga.M, ga.N, ga.K, nullptr, 0.f, ga.W8, ga.wscale};
     const size_t sm_gemm = (size_t)(MG_WAVES * 256 + MG_WAVES * MG_MAXM + 16) * 4 + (size_t)B * ga.K * 2;
     const size_t sm_att = decode_attention_smem_floats(MG_WAVES, a.d.max_len) * sizeof(float);
     const size_t smem = sm_gemm > sm_att ? sm_gemm : sm_att;
     dim3 grid(n_attn + (ntiles + 1) / 2), block(MG_THREADS);
-    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((attn_oproj16_k<T>), grid, block, smem, s, a, g, n_attn, ntiles, counter, err));
+    RDX_DISPATCH_T(dtype, T, {
+        if (w8) hipLaunchKernelGGL((attn_oproj16_k<T, true>), grid, block, smem, s, a, g, n_attn, ntiles, counter, err);
+        else hipLaunchKernelGGL((attn_oproj16_k<T, false>), grid, block, smem, s, a, g, n_attn, ntiles, counter, err);
+    });
 }
 
 bool mega_supported(const LlamaDims& d, int inter, int B) {

@@ -45,6 +45,27 @@ __device__ __forceinline__ u4 ldg16(const void* p) { return *(const g_u4*)p; }
 __device__ __forceinline__ u4 ldg16_nt(const void* p) { return __builtin_nontemporal_load((const g_u4*)p); }
 __device__ __forceinline__ void stg16(void* p, u4 v) { *(g_u4*)p = v; }
 
+// ---- fp8 (OCP e4m3) -> model dtype, exact (every e4m3 value is representable in bf16 and f16) --------------------------------
+// two dwords = 8 fp8 bytes -> 8 model-dtype values in one 16-byte register quad (an MFMA A-operand chunk)
+template <typename T> __device__ __forceinline__ u4 dequant8(unsigned lo, unsigned hi);
+template <> __device__ __forceinline__ u4 dequant8<bf16>(unsigned lo, unsigned hi) {
+    const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+    const auto c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    // bf16 = upper half of the f32 (exact here): (f0.hi16) | (f1.hi16 << 16). The elements are copied to scalars first:
+    // __builtin_bit_cast on a vector ELEMENT (a[1]) reads element 0 with this compiler.
+    const float a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1], c0 = c[0], c1 = c[1], d0 = d[0], d1 = d[1];
+    return (u4){__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, a0), 0x07060302u),
+                __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b1), __builtin_bit_cast(unsigned, b0), 0x07060302u),
+                __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, c1), __builtin_bit_cast(unsigned, c0), 0x07060302u),
+                __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, d1), __builtin_bit_cast(unsigned, d0), 0x07060302u)};
+}
+template <> __device__ __forceinline__ u4 dequant8<f16>(unsigned lo, unsigned hi) {
+    const auto a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+    const auto c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    return (u4){__builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a[0], a[1])), __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(b[0], b[1])),
+                __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(c[0], c[1])), __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d[0], d[1]))};
+}
+
 // ---- wave (64 lanes) reductions ----------------------------------------------------------------------------------
 // Cross-lane traffic goes through DPP / v_readlane / v_permlane*_swap (VALU speed, ~8 cycles each) rather than
 // __shfl_xor (ds_bpermute: an LDS-crossbar round trip of ~100 cycles per step) -- these reductions sit on the critical

@@ -26,6 +26,9 @@ struct GemmArgs {
     float* part_val; int* part_idx;  // EPI_LOGITS: [M][n_tiles]
     int n_valid;                     // EPI_LOGITS: real vocab size (N is padded to 16)
     const int* out_step; long out_step_stride;   // optional: out += (*out_step) * stride elements (per-step score rows)
+    // fp8 weights (skinny / fused decode paths only): e4m3 bytes in the 64-deep fragment order (gemm.hip) + one fp32 scale per
+    // output row; `W` then holds the dequantised model-dtype copy the other kernels use
+    const void* W8; const float* wscale;
 };
 
 struct ConvGeom {        // mode 0: plain row-major A.  mode 1: im2col gather from NHWC, K ordered (kh, kw, c)
@@ -56,6 +59,9 @@ struct LlamaDims {
 };
 
 void launch_pack_weight(int dtype, const float* src, void* dst, int N, int K, int Npad, const int* rowmap, hipStream_t s);
+// per-row absmax e4m3 quantisation: dst8 = fp8 bytes in the 64-deep fragment order, scale[Npad], dst = the dequantised weights in
+// the model dtype, standard fragment order (K % 64 == 0)
+void launch_pack_weight_fp8(int dtype, const float* src, void* dst8, float* scale, void* dst, int N, int K, int Npad, hipStream_t s);
 // skinny GEMM. A fused RMSNorm (a.norm_w != null) is only honoured when skinny_fits_lds(M, K); otherwise the caller
 // must normalise first (launch_rmsnorm) and pass norm_w = null.
 bool skinny_fits_lds(int M, int K);

@@ -24,10 +24,14 @@ template <typename T> __device__ __forceinline__ float swiglu(float gate_acc, fl
 }
 
 
-template <typename T, int MT, int EPI, bool NORM, int WAVES, bool XLDS, typename WaitFn, bool COHX = false>
+template <typename T, int MT, int EPI, bool NORM, int WAVES, bool XLDS, typename WaitFn, bool COHX = false, bool W8 = false>
 __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, const int ntiles, unsigned char* dyn_smem,
                                             WaitFn wait_inputs) {
     typedef typename Vec8<T>::type V8;
+    // W8: fp8 (e4m3) weights with one fp32 scale per output row. A chunk is then 64 k-values (16 bytes per lane, two MFMAs:
+    // lane (g, r) holds W[16*tile + r][64*c + 16*g .. +16]); the bytes are expanded to the model dtype in registers (exact)
+    // and the scale is applied to the fp32 sums in the epilogue. LDS-staged activations only.
+    static_assert(!W8 || (XLDS && MT == 1), "fp8 weights: LDS-staged activations, one M tile");
     constexpr int U = (XLDS && WAVES >= 8) ? 8 : 4;    // 4-wave workgroups stay <= 64 VGPRs: 8 workgroups per CU
     constexpr int NTHR = WAVES * 64;
     __shared__ __attribute__((aligned(16))) float red[WAVES][MT][256];   // [wave][mt][m_local*16 + n_local]
@@ -39,10 +43,10 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
     // EXEC-masked per-lane branch (MFMA ignores EXEC -- a masked-off MFMA would still accumulate)
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
-    const int K = a.K, KC = K >> 5;
+    const int K = a.K, KC = W8 ? (K >> 6) : (K >> 5);
     const int c0 = (KC * w) / WAVES, c1 = (KC * (w + 1)) / WAVES;
     const T* X = reinterpret_cast<const T*>(a.X);
-    const u4* wbase = reinterpret_cast<const u4*>(a.W) + (size_t)tile * KC * 64 + lane;
+    const u4* wbase = reinterpret_cast<const u4*>(W8 ? a.W8 : a.W) + (size_t)tile * KC * 64 + lane;
     const int clast = min(max(c1 - 1, c0), KC - 1);
 
     // two weight batches in flight before anything else (HBM latency overlaps the wait and the prologue)
@@ -113,7 +117,7 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
     for (int mt = 0; mt < MT; ++mt) {
         const int m = mt * 16 + r;
         xok[mt] = m < a.M;
-        xrow[mt] = XLDS ? (xs + (size_t)(xok[mt] ? m : 0) * K + g * 8) : (X + (size_t)(xok[mt] ? m : 0) * a.ldx + g * 8);
+        xrow[mt] = XLDS ? (xs + (size_t)(xok[mt] ? m : 0) * K + g * (W8 ? 16 : 8)) : (X + (size_t)(xok[mt] ? m : 0) * a.ldx + g * 8);
     }
 
     v4f acc[MT];
@@ -137,7 +141,16 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
         if (!XLDS && cb + U < c1) load_x(xn, cb + U);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            if (cb + u < c1) {
+            if (W8) {
+                if (cb + u < c1) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u4 wd = dequant8<T>(h ? wv[u].z : wv[u].x, h ? wv[u].w : wv[u].y);
+                        const u4 xv = xok[0] ? *reinterpret_cast<const u4*>(xrow[0] + (size_t)(cb + u) * 64 + h * 8) : (u4){0u, 0u, 0u, 0u};
+                        acc[0] = mfma16(as_vec8<T>(wd), as_vec8<T>(xv), acc[0]);
+                    }
+                }
+            } else if (cb + u < c1) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     u4 xv;
@@ -175,6 +188,7 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
         float v = 0.f;
 #pragma unroll
         for (int i = 0; i < WAVES; ++i) v += red[i][mt][idx];
+        if (W8) v *= a.wscale[n];                                      // per-row dequantisation scale (padded rows: 1)
         if (a.bias && n < a.N) v += a.bias[n];
         T* out = reinterpret_cast<T*>(a.out);
         if (a.out_step && out) out += (size_t)(*a.out_step) * a.out_step_stride;
@@ -196,6 +210,7 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
             float u = 0.f;
 #pragma unroll
             for (int i = 0; i < WAVES; ++i) u += red[i][mt][(idx + 8) & 255];
+            if (W8) u *= a.wscale[tile * 16 + ((n_local + 8) & 15)];
             if (n_local < 8 && ok) out[(size_t)m * a.ldo + tile * 8 + n_local] = fromf<T>(swiglu<T>(v, u));
         } else if (EPI == EPI_LOGITS) {
             float lv = rnd<T>(v);

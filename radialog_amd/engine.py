@@ -25,7 +25,8 @@ def _ptr(t: Optional[torch.Tensor]):
 
 class RdxEngine:
     def __init__(self, cfg: RaDialogCfg, dtype: str = "bf16", device: int = 0, max_batch: int = 1, max_len: int = 512,
-                 lora: bool = True, vision: bool = True, llama: bool = True, classifier: bool = False):
+                 lora: bool = True, vision: bool = True, llama: bool = True, classifier: bool = False,
+                 weights_fp8: bool = False):
         if dtype not in _RDX_DT:
             raise ValueError(f"dtype must be 'f16' or 'bf16', got {dtype!r}")
         self.lib = _lib.load()                       # raises RdxLibraryError when the HIP library is absent
@@ -34,6 +35,7 @@ class RdxEngine:
         self.cfg, self.dtype, self.tdtype = cfg, dtype, _TORCH_DT[dtype]
         self.device = torch.device("cuda", device)
         self.lora = lora
+        self.weights_fp8 = weights_fp8               # decoder GEMM weights also quantised to e4m3 + per-row scale (configs[4])
         l, q, v = cfg.llama, cfg.qformer, cfg.vision
         rc = RdxConfig()
         rc.dtype = _RDX_DT[dtype]
@@ -101,7 +103,7 @@ class RdxEngine:
                 self._upload(W.vision_items(get, self.cfg.vision))
                 self._upload(W.qformer_items(get, self.cfg.qformer))
             if llama:
-                self._upload(W.llama_items(get, self.cfg.llama, self.lora))
+                self._upload(W.llama_items(get, self.cfg.llama, self.lora, fp8=self.weights_fp8))
         check(self.ctx, self.lib.rdx_finalize_weights(self.ctx), "rdx_finalize_weights")
         self._finalized = True
 

@@ -24,7 +24,7 @@ from typing import Callable, Iterator, Tuple
 import torch
 import torch.nn.functional as F
 
-from ._lib import RDX_W_F32, RDX_W_GEMM, RDX_W_TENSOR
+from ._lib import RDX_W_F32, RDX_W_GEMM, RDX_W_GEMM_FP8, RDX_W_TENSOR
 from .config import LlamaCfg, QFormerCfg, VisionCfg
 
 Getter = Callable[[str], torch.Tensor]
@@ -181,11 +181,14 @@ def rope_tables_f32(head_dim: int, max_pos: int, base: float):
     return emb.cos(), emb.sin()
 
 
-def llama_items(get: Getter, c: LlamaCfg, lora: bool) -> Iterator[Item]:
+def llama_items(get: Getter, c: LlamaCfg, lora: bool, fp8: bool = False) -> Iterator[Item]:
+    # fp8: the decoder's GEMM weights (QKV + LoRA-A rows, o_proj, gate/up, down, lm_head) are additionally quantised to e4m3
+    # with one scale per row (RDX_W_GEMM_FP8, BASELINE configs[4]); embeddings, norms, LoRA-B, img_proj keep the model dtype
+    GK = RDX_W_GEMM_FP8 if fp8 else RDX_W_GEMM
     H, I = c.hidden, c.inter
     yield "embed", get("model.embed_tokens.weight"), RDX_W_TENSOR
     yield "final_norm", get("model.norm.weight").view(1, -1), RDX_W_TENSOR
-    yield "lm_head", get("lm_head.weight"), RDX_W_GEMM
+    yield "lm_head", get("lm_head.weight"), GK
     yield "img_proj.w", get("model.img_proj_layer.weight"), RDX_W_GEMM
     yield "img_proj.b", get("model.img_proj_layer.bias").view(1, -1), RDX_W_F32
     cos, sin = rope_tables_f32(c.head_dim, c.max_pos, c.rope_base)
@@ -198,14 +201,14 @@ def llama_items(get: Getter, c: LlamaCfg, lora: bool) -> Iterator[Item]:
         parts = [get(L + f"self_attn.{n}.weight") for n in ("q_proj", "k_proj", "v_proj")]
         if lora:
             parts += [get(L + "self_attn.q_proj.lora_A.weight"), get(L + "self_attn.v_proj.lora_A.weight")]
-        yield o + "wqkv", torch.cat(parts, 0).contiguous(), RDX_W_GEMM
+        yield o + "wqkv", torch.cat(parts, 0).contiguous(), GK
         del parts
         if lora:
             yield o + "lora_bq", get(L + "self_attn.q_proj.lora_B.weight").contiguous(), RDX_W_TENSOR
             yield o + "lora_bv", get(L + "self_attn.v_proj.lora_B.weight").contiguous(), RDX_W_TENSOR
-        yield o + "wo", get(L + "self_attn.o_proj.weight"), RDX_W_GEMM
+        yield o + "wo", get(L + "self_attn.o_proj.weight"), GK
         g = get(L + "mlp.gate_proj.weight").view(I // 8, 1, 8, H)
         u = get(L + "mlp.up_proj.weight").view(I // 8, 1, 8, H)
-        yield o + "wgu", torch.cat([g, u], 1).reshape(2 * I, H).contiguous(), RDX_W_GEMM
+        yield o + "wgu", torch.cat([g, u], 1).reshape(2 * I, H).contiguous(), GK
         del g, u
-        yield o + "wdown", get(L + "mlp.down_proj.weight"), RDX_W_GEMM
+        yield o + "wdown", get(L + "mlp.down_proj.weight"), GK

@@ -17,12 +17,12 @@ def eng(request):
     e.close()
 
 
-def _ref(x, w, bias, resid, epi, norm_w, eps, dt):
+def _ref(x, w, bias, resid, epi, norm_w, eps, dt, wdt=None):
     xf = x.float()
     if norm_w is not None:
         var = xf.pow(2).mean(-1, keepdim=True)
         xf = (norm_w.to(dt) * (xf * torch.rsqrt(var + eps)).to(dt)).float()
-    y = xf.double() @ w.to(dt).double().t()
+    y = xf.double() @ w.to(wdt or dt).double().t()
     if bias is not None:
         y = y + bias.double()
     if epi == 1:
@@ -70,6 +70,39 @@ def test_gemm_matches_fp32(eng, M, N, K, epi, norm, force):
     nw = synth.synth(f"g.n{K}", (K,), 0.8, 1.2).to(dt) if norm else None
     out = eng.gemm_test(x, w, bias, resid, epi, nw, 1e-6, force).float().cpu()
     ref = _ref(x, w, bias, resid, epi, nw, 1e-6, dt).float()
+    tol = {"f16": 2e-3, "bf16": 1.6e-2}[eng.dtype] * max(1.0, float(ref.abs().max()))
+    err = float((out - ref).abs().max())
+    assert err < tol, f"max abs err {err} (tol {tol})"
+
+
+def _fake_quant_e4m3(w):
+    """The library's per-row quantisation (gemm.hip pack_weight_fp8_k): scale = absmax / 448, q = RNE(w * (448 / absmax))."""
+    absmax = w.abs().amax(dim=1, keepdim=True).float()
+    inv = torch.where(absmax > 0, 448.0 / absmax, torch.ones_like(absmax))
+    sc = torch.where(absmax > 0, absmax / 448.0, torch.ones_like(absmax))
+    q = (w.float() * inv).to(torch.float8_e4m3fn)
+    return q.float() * sc
+
+
+FP8_CASES = [
+    # M, N, K, epi, norm     (K % 64 == 0; M*K*2 <= 32 KiB streams the fp8 bytes, larger M falls back to the dequantised copy)
+    (1, 256, 4096, 0, True), (1, 64, 11008, 3, False), (3, 128, 512, 4, True), (1, 2064, 4096, 0, True),
+    (2, 4096, 4096, 3, False), (4, 16400, 4096, 4, True), (8, 64, 4096, 0, False), (1, 48, 704, 0, False),
+]
+
+
+@pytest.mark.parametrize("M,N,K,epi,norm", FP8_CASES)
+def test_fp8_weight_gemv_matches_fake_quantised_fp32(eng, M, N, K, epi, norm):
+    """BASELINE configs[4]: e4m3 weights + per-row scale through the weight-streaming kernels. Reference = the same
+    math with the fake-quantised weights q * scale in fp32."""
+    dt = DT[eng.dtype]
+    x = synth.synth(f"g8.x{M}.{K}", (M, K), -1.0, 1.0).to(dt)
+    w = synth.synth(f"g8.w{N}.{K}", (N, K), -0.05, 0.05)
+    resid = synth.synth(f"g8.r{M}.{N}", (M, N), -1.0, 1.0).to(dt) if epi == 3 else None
+    nw = synth.synth(f"g8.n{K}", (K,), 0.8, 1.2).to(dt) if norm else None
+    out = eng.gemm_test(x, w, None, resid, epi, nw, 1e-6, 4).float().cpu()
+    wq = _fake_quant_e4m3(w)
+    ref = _ref(x, wq, None, resid, epi, nw, 1e-6, dt, wdt=torch.float32).float()
     tol = {"f16": 2e-3, "bf16": 1.6e-2}[eng.dtype] * max(1.0, float(ref.abs().max()))
     err = float((out - ref).abs().max())
     assert err < tol, f"max abs err {err} (tol {tol})"

@@ -313,3 +313,43 @@ def test_long_context_decode_streams_past_the_register_window(cfg, cpu_w, B, tp,
                 err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
                 assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
         eng.close()
+
+
+def _fake_quant_rows(w):
+    absmax = w.abs().amax(dim=1, keepdim=True).float()
+    inv = torch.where(absmax > 0, 448.0 / absmax, torch.ones_like(absmax))
+    sc = torch.where(absmax > 0, absmax / 448.0, torch.ones_like(absmax))
+    return (w.float() * inv).to(torch.float8_e4m3fn).float() * sc
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_fp8_weight_decode_matches_fake_quantised_oracle(cfg, cpu_w, B):
+    """BASELINE configs[4]: decoder GEMM weights in e4m3 with one scale per output row (LoRA-A rows included), streamed as
+    fp8 by the decode kernels and used as the dequantised copy by prefill. Oracle = the reference math on the same
+    fake-quantised weights (q * scale)."""
+    from oracle import ref_cpu
+    from radialog_amd.engine import RdxEngine, synth_getter
+    Wq = dict(cpu_w)
+    for k, v in cpu_w.items():
+        if k == "lm_head.weight" or (k.startswith("model.layers.") and v.dim() == 2 and
+                                     (k.endswith("_proj.weight") or k.endswith("lora_A.weight"))):
+            Wq[k] = _fake_quant_rows(v)
+    T, N = 72, 12
+    ids = _prompt(cfg, B, T, seed=33)
+    qf = synth.synth("t.qf2", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    for dtype in ("f16", "bf16"):
+        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=4, max_len=256, lora=True, vision=False, weights_fp8=True)
+        eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+        with torch.no_grad():
+            ref = ref_cpu.LlamaOracle(Wq, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
+        toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
+        toks = toks.cpu().long()
+        tol = LOGIT_TOL[dtype]
+        for b in range(B):
+            for s in range(N):
+                if toks[b, s] != ref["tokens"][b, s]:
+                    assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
+                    break
+                err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
+                assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
+        eng.close()
