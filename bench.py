@@ -210,7 +210,13 @@ def main():
         # dominant kernel: gate/up SwiGLU GEMV, HIP events on the library's stream
         lc = cfg.llama
         gu_ms = eng.time_unit(1, 10)
-        wb = 1 if (args.fp8 and B <= 4) else 2                          # bytes per streamed weight element in the decode GEMVs
+        def wbytes(n_rows, k):        # bytes per streamed weight element of a decode projection (mirrors the library's dispatch)
+            if not args.fp8:
+                return 2
+            lds = B <= 16 and B * k * 2 <= 32 * 1024                     # batch-1..4 GEMV with LDS-staged activations
+            s32 = 16 < B <= 32 and (n_rows + 15) // 16 > 512 and k % 512 == 0    # skinny32.hip
+            return 1 if (lds or s32) else 2
+        wb = wbytes(2 * lc.inter, lc.hidden)
         gu_bytes = 2 * lc.inter * lc.hidden * wb + B * lc.hidden * 2 + lc.hidden * 2 + B * lc.inter * 2
         # whole-decode average: one report minus its encode and its prefill (+ first token), over the N-1 graph-replayed steps
         torch.cuda.synchronize()
@@ -223,7 +229,9 @@ def main():
         kv_bytes = B * (T + N / 2.0) * 524288 + B * 524288          # 2 x 32 layers x 4096 x 2 B per cached token
         step_ms = eng.time_unit(0, 20)
         L_avg = T + 64      # rdx_time(0) replays from the state left by the last generate (slot ~ T+N) -- report as measured
-        step_bytes = (32 * (4 * lc.hidden ** 2 + 3 * lc.hidden * lc.inter) + lc.vocab * lc.hidden) * wb + (32 * 2 * lc.hidden + lc.hidden) * 2
+        H_, I_ = lc.hidden, lc.inter
+        step_bytes = (32 * (3 * H_ * H_ * wbytes(3 * H_ + 16, H_) + H_ * H_ * wbytes(H_, H_) + 2 * I_ * H_ * wbytes(2 * I_, H_)
+                            + H_ * I_ * wbytes(H_, I_)) + lc.vocab * H_ * wbytes(lc.vocab, H_) + (32 * 2 * H_ + H_) * 2)
         roof = {
             "bound": "hbm", "kernel": f"skinny_gemm_k<{args.dtype},MT,EPI_SILU_MUL,NORM{',W8' if wb == 1 else ''}> (gate/up SwiGLU GEMV)",
             "achieved": gu_bytes / (gu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -18,11 +18,16 @@ namespace rdx {
 
 constexpr int S32_WAVES = 16, S32_THREADS = 1024;
 
-template <typename T, int EPI, int SUB>
+// W8: fp8 (e4m3) weights, 64-deep fragment order + per-row scale (gemm.hip pack_weight_fp8_k): a wave's stage is then CH/2
+// 16-byte loads (each feeds two MFMAs), the ring is twice as many stages deep so that 8 KiB per wave stay in flight.
+template <typename T, int EPI, int SUB, bool W8>
 __global__ __launch_bounds__(S32_THREADS, 8) void skinny32_k(GemmArgs a) {
     typedef typename Vec8<T>::type V8;
     constexpr int WPS = S32_WAVES / SUB, CH = 16 / WPS, MT = 2;   // WPS * CH = 16 chunk slots per stage: a 32 KiB stage image
-    constexpr int NWS = 8 / CH;                                    // weight ring: 8 chunks (8 KiB) per wave in flight
+    constexpr int WL = W8 ? CH / 2 : CH;                           // weight loads (16 B per lane) per wave per stage
+    constexpr int NWS = W8 ? 2 : 8 / WL;                           // weight ring: 8 loads (8 KiB) per wave in flight; fp8: 4 loads = the
+                                                                   // same K depth (the dequantisation temporaries need the registers)
+    static_assert(!W8 || CH % 2 == 0, "fp8: a stage must hold whole 64-deep chunks");
     constexpr int STAGE_U4 = WPS * CH * 32 * 4;                  // 16-byte pieces per stage buffer
     constexpr int XPT = STAGE_U4 / S32_THREADS;                  // pieces per thread per stage
     static_assert(STAGE_U4 % S32_THREADS == 0, "stage must tile over the workgroup");
@@ -36,11 +41,12 @@ __global__ __launch_bounds__(S32_THREADS, 8) void skinny32_k(GemmArgs a) {
     const int tile = blockIdx.x * SUB + sub, tile_c = min(tile, ntiles - 1);
     const int r = lane & 15, g = lane >> 4;
     const int K = a.K, KC = K >> 5;
-    const int c0 = (KC * w) / WPS, c1 = (KC * (w + 1)) / WPS;
-    const int nst = KC / (WPS * CH);                             // stages: every wave consumes CH chunks per stage
+    const int nst = KC / (WPS * CH);                             // stages: every wave consumes CH chunks of 32 per stage
+    const int WC = W8 ? (KC >> 1) : KC;                          // weight chunks per row (64-deep for fp8)
+    const int c0 = (WC * w) / WPS, c1 = (WC * (w + 1)) / WPS;    // this wave's weight-chunk range
     const T* X = reinterpret_cast<const T*>(a.X);
-    const u4* wtile = reinterpret_cast<const u4*>(a.W) + (size_t)tile_c * KC * 64;   // wave-uniform
-    const int clast = min(max(c1 - 1, c0), KC - 1);
+    const u4* wtile = reinterpret_cast<const u4*>(W8 ? a.W8 : a.W) + (size_t)tile_c * WC * 64;   // wave-uniform
+    const int clast = min(max(c1 - 1, c0), WC - 1);
 
     // activation piece idx -> (range q, chunk j, row m, piece p) of the stage image. K is a multiple of 16 chunks
     // (skinny32_supported), so every range is a whole number of stages and a piece's address advances by CH chunks per
@@ -61,23 +67,37 @@ __global__ __launch_bounds__(S32_THREADS, 8) void skinny32_k(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < XPT; ++i) xbuf[buf * STAGE_U4 + threadIdx.x + i * S32_THREADS] = src[i];
     };
-    auto load_w = [&](u4 (&dst)[CH], int s) {
+    auto load_w = [&](u4 (&dst)[WL], int s) {
 #pragma unroll
-        for (int j = 0; j < CH; ++j) dst[j] = ldg16_nt(wtile + (size_t)(unsigned)(min(c0 + s * CH + j, clast) * 64 + lane));
+        for (int j = 0; j < WL; ++j) dst[j] = ldg16_nt(wtile + (size_t)(unsigned)(min(c0 + s * WL + j, clast) * 64 + lane));
     };
 
     v4f acc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](const u4 (&wr)[CH], int s, int buf) {
+    auto compute = [&](const u4 (&wr)[WL], int s, int buf) {
         // stage image: piece index ((q*CH + j)*32 + m)*4 + p ; this wave: q = w, lane (g, r) reads row 16*mt + r, piece g
         const u4* xb = xbuf + buf * STAGE_U4 + (size_t)(w * CH) * 128;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
+        for (int j = 0; j < WL; ++j) {
+            if (W8) {
+                // 64-deep chunk j: lane (g, r) holds k = 64j + 16g .. +16; MFMA h takes k = 64j + 16g + 8h .. +8, which sits in
+                // the image's 32-deep chunk 2j + (g >> 1), piece (2g + h) & 3
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const u4 xv = xb[(j * 32 + mt * 16 + r) * 4 + g];
-                acc[mt] = mfma16(as_vec8<T>(wr[j]), as_vec8<T>(xv), acc[mt]);
+                for (int h = 0; h < 2; ++h) {
+                    const u4 wd = dequant8<T>(h ? wr[j].z : wr[j].x, h ? wr[j].w : wr[j].y);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const u4 xv = xb[((2 * j + (g >> 1)) * 32 + mt * 16 + r) * 4 + ((2 * g + h) & 3)];
+                        acc[mt] = mfma16(as_vec8<T>(wd), as_vec8<T>(xv), acc[mt]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const u4 xv = xb[(j * 32 + mt * 16 + r) * 4 + g];
+                    acc[mt] = mfma16(as_vec8<T>(wr[j]), as_vec8<T>(xv), acc[mt]);
+                }
             }
         }
     };
@@ -87,7 +107,7 @@ __global__ __launch_bounds__(S32_THREADS, 8) void skinny32_k(GemmArgs a) {
     // loads in flight (the other order drains the ring every stage). Every load is unconditional (addresses clamped) ->
     // counted waits; stages past the end compute nothing (guards in compute()). Register budget: 64 VGPRs (two workgroups
     // per CU) -- a spill reload inside the loop would force vmcnt(0).
-    u4 wr[NWS][CH], xr[XPT];
+    u4 wr[NWS][WL], xr[XPT];
 #pragma unroll
     for (int k = 0; k + 1 < NWS; ++k) load_w(wr[k], k);
     load_x(xr, 0);
@@ -120,6 +140,7 @@ __global__ __launch_bounds__(S32_THREADS, 8) void skinny32_k(GemmArgs a) {
         float v = 0.f;
 #pragma unroll
         for (int i = 0; i < WPS; ++i) v += red[((so * WPS + i) * MT + mt) * 256 + idx];
+        if (W8) v *= a.wscale[min(n, ntiles * 16 - 1)];
         if (a.bias && n < a.N) v += a.bias[n];
         const bool ok = (m < a.M) && (t_o < ntiles) && (n < a.N);
         if (EPI == EPI_NONE) {
@@ -133,6 +154,7 @@ __global__ __launch_bounds__(S32_THREADS, 8) void skinny32_k(GemmArgs a) {
             float u = 0.f;
 #pragma unroll
             for (int i = 0; i < WPS; ++i) u += red[((so * WPS + i) * MT + mt) * 256 + ((idx + 8) & 255)];
+            if (W8) u *= a.wscale[min(t_o, ntiles - 1) * 16 + ((n_local + 8) & 15)];
             if (n_local < 8 && ok) out[(size_t)m * a.ldo + t_o * 8 + n_local] = fromf<T>(swiglu<T>(v, u));
         } else if (EPI == EPI_LOGITS) {
             float lv = rnd<T>(v);
@@ -162,24 +184,25 @@ bool skinny32_supported(const GemmArgs& a, int epi) {
            (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL || epi == EPI_LOGITS);
 }
 
-template <typename T, int SUB>
+template <typename T, int SUB, bool W8>
 static void launch_skinny32_sub(const GemmArgs& a, int epi, hipStream_t s) {
     const int nt = (a.N + 15) / 16;
     dim3 grid((nt + SUB - 1) / SUB), block(S32_THREADS);
     const size_t stage = (size_t)2 * 16 * 32 * 4 * 16, redb = (size_t)S32_WAVES * 2 * 256 * 4;   // 2 x 32 KiB stage images
     const size_t smem = stage > redb ? stage : redb;
     switch (epi) {
-        case EPI_NONE: hipLaunchKernelGGL((skinny32_k<T, EPI_NONE, SUB>), grid, block, smem, s, a); break;
-        case EPI_RESID: hipLaunchKernelGGL((skinny32_k<T, EPI_RESID, SUB>), grid, block, smem, s, a); break;
-        case EPI_SILU_MUL: hipLaunchKernelGGL((skinny32_k<T, EPI_SILU_MUL, SUB>), grid, block, smem, s, a); break;
-        case EPI_LOGITS: hipLaunchKernelGGL((skinny32_k<T, EPI_LOGITS, SUB>), grid, block, smem, s, a); break;
+        case EPI_NONE: hipLaunchKernelGGL((skinny32_k<T, EPI_NONE, SUB, W8>), grid, block, smem, s, a); break;
+        case EPI_RESID: hipLaunchKernelGGL((skinny32_k<T, EPI_RESID, SUB, W8>), grid, block, smem, s, a); break;
+        case EPI_SILU_MUL: hipLaunchKernelGGL((skinny32_k<T, EPI_SILU_MUL, SUB, W8>), grid, block, smem, s, a); break;
+        case EPI_LOGITS: hipLaunchKernelGGL((skinny32_k<T, EPI_LOGITS, SUB, W8>), grid, block, smem, s, a); break;
         default: break;
     }
 }
 
 void launch_skinny32(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
     // 4 tiles x 4 waves per workgroup (2 tiles x 8 waves measured slower at every shape of the decode step)
-    RDX_DISPATCH_T(dtype, T, launch_skinny32_sub<T, 4>(a, epi, s));
+    const bool w8 = a.W8 && a.wscale;                         // K % 512 == 0 holds (skinny32_supported): whole 64-deep chunks
+    RDX_DISPATCH_T(dtype, T, { if (w8) launch_skinny32_sub<T, 4, true>(a, epi, s); else launch_skinny32_sub<T, 4, false>(a, epi, s); });
 }
 
 }  // namespace rdx
