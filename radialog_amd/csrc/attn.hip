@@ -242,7 +242,8 @@ void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, cons
 // decode attention (body in attn_body.h)
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int DA_WAVES = 16;       // latency variant: few (head, row) pairs, each gets a whole CU
-constexpr int DA_WAVES_TP = 4;     // throughput variant: >= 256 pairs, 4 workgroups per CU share the KV stream
+constexpr int DA_WAVES_TP = 4;     // throughput variant: > 256 pairs, 4 workgroups per CU share the KV stream (8 waves with a 256-position
+                                   // register window measured 5 % slower at batch 32)
 
 template <typename T, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void decode_attention_k(DecAttnArgs a) {

@@ -227,14 +227,21 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
         for (int u = 0; u < KG; ++u)
             if (u < KG_LO || (u * CW + cw) * 16 < slot) score_group(kr[u], kmw[u], (u * CW + cw) * 16);   // wave-uniform
         if (!V_EARLY) { load_v(0, VR_LO, 0x7fffffff); load_v(VR_LO, VR, slot); }     // K registers are free now
-        for (int gi = KG * CW + cw; gi * 16 < slot; gi += CW) {                 // contexts beyond the register window
-            const int gb = gi * 16;
-            const int j = min(gb + r, d.max_len - 1);
-            u4 kf[4];
+        // contexts beyond the register window: two groups per trip, all eight fragment loads issued before the first MFMA
+        // (the register window is dead by now); a group past the context is loaded from a clamped row and stores nothing
+        for (int gi = KG * CW + cw; gi * 16 < slot; gi += 2 * CW) {
+            u4 kf[2][4];
+            unsigned mw[2];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) kf[c] = ldg16(kc + (size_t)j * D + c * 32 + g * 8);
-            const unsigned mw = *reinterpret_cast<const unsigned*>(km + min(gb + 4 * g, d.max_len - 4));
-            score_group(kf, mw, gb);
+            for (int t = 0; t < 2; ++t) {
+                const int gb = (gi + t * CW) * 16;
+                const int j = min(gb + r, d.max_len - 1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) kf[t][c] = ldg16(kc + (size_t)j * D + c * 32 + g * 8);
+                mw[t] = *reinterpret_cast<const unsigned*>(km + min(gb + 4 * g, d.max_len - 4));
+            }
+            score_group(kf[0], mw[0], gi * 16);
+            score_group(kf[1], mw[1], (gi + CW) * 16);               // positions >= slot are not stored
         }
     }
     if (w == 0) {                                                               // the new position itself
@@ -288,13 +295,28 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
                 o8[2 * e + 1] = dot2<T>(hi, pp, o8[2 * e + 1]);
             }
         }
-        for (int j0 = VR * SPAN; j0 < slot; j0 += SPAN) {                       // contexts beyond the register window
-            const int j = j0 + cw * 4 + jsub;
-            if (j < slot) {
-                const float p = rnd<T>(expf(S[j] - mx) / sum);
-                const V8 vv = as_vec8<T>(ldg16(vc + (size_t)j * D + doct * 8));
+        // contexts beyond the register window: four rows per trip, loads first (clamped rows get P = 0)
+        for (int j0 = VR * SPAN; j0 < slot; j0 += 4 * SPAN) {
+            u4 vt[4];
+            float pt[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o8[e] += p * tof<T>(vv[e]);
+            for (int t = 0; t < 4; ++t) {
+                const int j = j0 + t * SPAN + cw * 4 + jsub;
+                vt[t] = ldg16(vc + (size_t)min(j, d.max_len - 1) * D + doct * 8);
+                pt[t] = j < slot ? rnd<T>(expf(S[j] - mx) / sum) : 0.f;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; t += 2) {
+                const unsigned pp = (unsigned)bits16<T>(fromf<T>(pt[t])) | ((unsigned)bits16<T>(fromf<T>(pt[t + 1])) << 16);
+                const unsigned a0[4] = {vt[t].x, vt[t].y, vt[t].z, vt[t].w};
+                const unsigned a1[4] = {vt[t + 1].x, vt[t + 1].y, vt[t + 1].z, vt[t + 1].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned lo = __builtin_amdgcn_perm(a1[e], a0[e], 0x05040100u);
+                    const unsigned hi = __builtin_amdgcn_perm(a1[e], a0[e], 0x07060302u);
+                    o8[2 * e] = dot2<T>(lo, pp, o8[2 * e]);
+                    o8[2 * e + 1] = dot2<T>(hi, pp, o8[2 * e + 1]);
+                }
             }
         }
     }
