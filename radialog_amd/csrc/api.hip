@@ -87,9 +87,10 @@ struct rdx_ctx {
     int fuse_attn_oproj = 2;    // RDX_FUSE_AO: attention + o_proj in ONE launch with a fence-free hand-off: 2 = 16-wave kernel (mega.hip,
                                 // default where supported: batch <= 2), 1 = 8-wave kernel (fused.hip), 0 = one kernel per unit
     int use_mega = 0;                // RDX_MEGA=n: chained decode-layer kernel (mega.hip), n layers per launch (0 = off, -1 = all)
-    int chain_mlp = 0;               // RDX_CHAIN=1: gate/up -> down -> next qkv as one chained launch per layer
+    int chain_mlp = 2;               // RDX_CHAIN: 2 (default at batch <= 2) = down(l) -> qkv(l+1) as one chained launch (one workgroup per CU);
+                                     // 1 = gate/up -> down -> next qkv (measured slower); 0 = one kernel per unit
     int mega_naps = 1;               // RDX_MEGA_NAPS: poll back-off
-    int mega_occ = 8;                // RDX_MEGA_OCC: 8 = two workgroups per CU, 4 = one
+    int mega_occ = 4;                // RDX_MEGA_OCC: 8 = two workgroups per CU, 4 = one
     GemmW cls_fc1, cls_fc2; const float *cls_fc1_b = nullptr, *cls_fc2_b = nullptr;   // findings classifier head
     void *cls_pooled = nullptr, *cls_h = nullptr, *cls_out = nullptr;
     void* d_cur_rope = nullptr;      // [B][2][128] cos | sin row of each row's current position (written by greedy_step_k)
@@ -216,7 +217,7 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
     if (const char* e = getenv("RDX_MEGA")) c->use_mega = atoi(e);
     if (const char* e = getenv("RDX_CHAIN")) c->chain_mlp = atoi(e);
     if (const char* e = getenv("RDX_MEGA_NAPS")) c->mega_naps = atoi(e);
-    if (const char* e = getenv("RDX_MEGA_OCC")) c->mega_occ = atoi(e) == 4 ? 4 : 8;
+    if (const char* e = getenv("RDX_MEGA_OCC")) c->mega_occ = atoi(e) == 8 ? 8 : 4;
     if (const char* e = getenv("RDX_DMA")) c->use_dma_gemm = atoi(e) != 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
@@ -774,8 +775,10 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
     }
     // the hand-off counter shards of the fused launches are cleared by greedy_step_k at the end of the previous step
     // (and of the prefill): a memset node at the head of the step graph was observed to race with the first producers
-    // RDX_CHAIN=1: gate/up(l) -> down(l) -> qkv(l+1) as ONE chained launch per layer (mega.hip roles, <= 64 VGPRs)
-    const bool chain = c->chain_mlp && mega_supported(c->ld, f.inter, B) && attn_oproj16_supported(c->ld, f.hidden, f.hidden, B) && c->fuse_attn_oproj == 2;
+    // RDX_CHAIN: units chained inside one launch by the fence-free hand-off (mega.hip roles without attention)
+    // (the chained roles stream model-dtype weights only: with fp8 weights the stand-alone fp8 GEMVs are faster)
+    const bool chain = c->chain_mlp && mega_supported(c->ld, f.inter, B) && attn_oproj16_supported(c->ld, f.hidden, f.hidden, B) &&
+                       c->fuse_attn_oproj == 2 && !c->ll[0].wdown.w8;
     MegaArgs ma;
     if (chain) {
         memset(&ma, 0, sizeof(ma));
@@ -804,8 +807,13 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
             launch_decode_attention(dt, at, B, s);
             skinny(c, ao, EPI_RESID);
         }
-        if (chain) {
+        if (chain && c->chain_mlp == 1) {
             launch_decode_roles(dt, ma, l * 5 + 3, std::min((l + 1) * 5 + 1, f.layers * 5), c->mega_occ, s);
+            continue;
+        }
+        if (chain) {          // RDX_CHAIN=2: gate/up stand-alone, then down(l) -> qkv(l+1) chained
+            { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; skinny(c, a, EPI_SILU_MUL); }
+            launch_decode_roles(dt, ma, l * 5 + 4, std::min((l + 1) * 5 + 1, f.layers * 5), c->mega_occ, s);
             continue;
         }
         { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps;

@@ -367,7 +367,18 @@ void launch_decode_roles(int dtype, MegaArgs ma, int R0, int R1, int occ, hipStr
     const size_t smem = sm_gemm > sm_att ? sm_gemm : sm_att;
     dim3 grid((l1 - l0 + 1) * per_layer - off - tail), block(MG_THREADS);
     RDX_DISPATCH_T(dtype, T, {
-        if (!with_att) hipLaunchKernelGGL((decode_layers_k<T, 8, false>), grid, block, smem, s, ma);
+        if (!with_att && occ == 8) hipLaunchKernelGGL((decode_layers_k<T, 8, false>), grid, block, smem, s, ma);
+        else if (!with_att) {
+            // ONE workgroup per CU: two resident 1024-thread workgroups per CU measured ~25 % slower in every unit, and the
+            // register budget alone (62 VGPRs) would admit two, so reserve more than half of the LDS
+            const size_t big = smem > (size_t)84 * 1024 ? smem : (size_t)84 * 1024;
+            static bool attr_set[2] = {false, false};
+            if (!attr_set[dtype & 1]) {
+                hipFuncSetAttribute((const void*)decode_layers_k<T, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+                attr_set[dtype & 1] = true;
+            }
+            hipLaunchKernelGGL((decode_layers_k<T, 4, false>), grid, block, big, s, ma);
+        }
         else if (occ == 8) hipLaunchKernelGGL((decode_layers_k<T, 8, true>), grid, block, smem, s, ma);
         else hipLaunchKernelGGL((decode_layers_k<T, 4, true>), grid, block, smem, s, ma);
     });

@@ -212,13 +212,14 @@ def test_chained_decode_layer_kernel_matches_oracle(cfg, cpu_w, monkeypatch, lay
         eng.close()
 
 
-@pytest.mark.parametrize("B", [1, 2])
-def test_chained_mlp_qkv_launch_matches_oracle(cfg, cpu_w, monkeypatch, B):
-    """RDX_CHAIN=1: gate/up(l) -> down(l) -> qkv(l+1) as one chained launch per layer (roles of csrc/mega.hip with the
-    fence-free hand-off), attention + o_proj in the fused 16-wave launch."""
+@pytest.mark.parametrize("B,mode", [(1, 1), (2, 1), (2, 2), (1, 0)])
+def test_chained_mlp_qkv_launch_matches_oracle(cfg, cpu_w, monkeypatch, B, mode):
+    """RDX_CHAIN: 1 = gate/up(l) -> down(l) -> qkv(l+1), 2 (the default at batch <= 2) = down(l) -> qkv(l+1) as one chained
+    launch per layer (roles of csrc/mega.hip with the fence-free hand-off), 0 = one kernel per unit; attention + o_proj in
+    the fused 16-wave launch."""
     from oracle import ref_cpu
     from radialog_amd.engine import RdxEngine, synth_getter
-    monkeypatch.setenv("RDX_CHAIN", "1")
+    monkeypatch.setenv("RDX_CHAIN", str(mode))
     T, N = 72, 24
     ids = _prompt(cfg, B, T, seed=33)
     qf = synth.synth("t.qf2", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
