@@ -45,16 +45,20 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic(batch, dtype):
+def pmc_traffic(batch, dtype, fp8=False):
     """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
     passes, gfx950 read-side doubling): measured offline because counters cannot be read from inside the timed process;
     the summary lives in profiles/r01_pmc_hbm_traffic.md and its machine-readable twin profiles/r01_pmc.json.
-    Only valid for the configuration it was measured on (batch 1, bf16) -> null otherwise."""
+    Only valid for the configurations it was measured on (batch 1, bf16, with or without fp8 weights) -> null otherwise."""
     if batch != 1 or dtype != "bf16":
         return None
     try:
         with open(os.path.join(REPO, "profiles", "r01_pmc.json")) as f:
-            return next(iter(json.load(f).values()))["traffic_bytes"]
+            d = json.load(f)
+        for k, v in d.items():
+            if ("W8" in k) == bool(fp8):
+                return v["traffic_bytes"]
+        return None
     except Exception:
         return None
 
@@ -235,7 +239,7 @@ def main():
         roof = {
             "bound": "hbm", "kernel": f"skinny_gemm_k<{args.dtype},MT,EPI_SILU_MUL,NORM{',W8' if wb == 1 else ''}> (gate/up SwiGLU GEMV)",
             "achieved": gu_bytes / (gu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None if args.fp8 else pmc_traffic(B, args.dtype),      # PMC pass exists for the bf16 configuration only
+            "frac": gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(B, args.dtype, args.fp8),
             "bytes_per_launch": gu_bytes, "us_per_launch": gu_ms * 1e3,
             "decode_step_ms": step_ms, "decode_step_weight_GBs": step_bytes / (step_ms * 1e-3) / 1e9,
             "decode_step_frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
