@@ -113,6 +113,8 @@ int rdx_time(rdx_ctx* ctx, int what, int iters, float* ms_host);
 int rdx_mega_trace(rdx_ctx* ctx, long long* host, int max_wgs);
 /* debug: 8 timestamps (100 MHz ticks) of workgroup (0,0) of the stand-alone decode-attention kernel of `layer` */
 int rdx_attn_trace(rdx_ctx* ctx, int layer, long long* host);
+/* debug: per-workgroup timestamps of one stand-alone decode GEMV (what: 1 gate/up, 2 qkv, 4 down), host[tile*8 + 0..5] */
+int rdx_gemv_trace(rdx_ctx* ctx, int what, int layer, long long* host, int max_tiles);
 
 /* one bare GEMM through the production kernels: out = epilogue(X . W^T); X/resid/norm_w/out model dtype, W [N][K] and
  * bias fp32. epi: 0 none, 1 relu, 2 gelu, 3 +resid, 4 swiglu(interleaved gate/up rows), 6 relu(+resid).

@@ -67,6 +67,7 @@ SYMBOLS = {
     "rdx_time": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "rdx_mega_trace": (C.c_int, [_P, _P, C.c_int]),
     "rdx_attn_trace": (C.c_int, [_P, C.c_int, _P]),
+    "rdx_gemv_trace": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int]),
     "rdx_gemm_test": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_int]),
 }
 

@@ -863,6 +863,32 @@ extern "C" int rdx_attn_trace(rdx_ctx* c, int layer, long long* host) {
     return 0;
 }
 
+// Debug: one stand-alone decode GEMV (what = 1 gate/up, 2 qkv, 4 down, as in rdx_time) of `layer` with per-workgroup
+// timestamps: host[tile*8 + {0 entry, 1 weights issued, 2 activations staged, 3 K loop done, 4 all waves done, 5 end}].
+extern "C" int rdx_gemv_trace(rdx_ctx* c, int what, int layer, long long* host, int max_tiles) {
+    if (!c || !c->finalized || c->cur_B <= 0 || !host) return fail(c, -1, "rdx_gemv_trace: run a prefill first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const rdx_config& f = c->cfg;
+    const int H = f.hidden, B = c->cur_B;
+    const LlamaLayer& L = c->ll[layer];
+    long long* dtr = nullptr;
+    const size_t bytes = (size_t)max_tiles * 8 * sizeof(long long);
+    HIPCHK(c, hipMalloc(&dtr, bytes));
+    HIPCHK(c, hipMemsetAsync(dtr, 0, bytes, c->stream));
+    GemmArgs a;
+    if (what == 1) { a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; }
+    else if (what == 2) { a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps; }
+    else { a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); }
+    if ((a.N + 15) / 16 > max_tiles) { hipFree(dtr); return fail(c, -1, "rdx_gemv_trace: need room for %d tiles", (a.N + 15) / 16); }
+    a.trace = dtr;
+    skinny(c, a, what == 1 ? EPI_SILU_MUL : EPI_NONE);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(host, dtr, bytes, hipMemcpyDeviceToHost);
+    hipFree(dtr);
+    HIPCHK(c, e);
+    return 0;
+}
+
 extern "C" int rdx_decode_step(rdx_ctx* c, void* logits) {
     if (!c) return -1;
     if (!c->finalized || c->cur_B <= 0) return fail(c, -1, "rdx_decode_step: no prefill has run");

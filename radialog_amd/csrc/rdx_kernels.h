@@ -29,6 +29,7 @@ struct GemmArgs {
     // fp8 weights (skinny / fused decode paths only): e4m3 bytes in the 64-deep fragment order (gemm.hip) + one fp32 scale per
     // output row; `W` then holds the dequantised model-dtype copy the other kernels use
     const void* W8; const float* wscale;
+    long long* trace;                // debug: [tile][8] timestamps (100 MHz ticks) written by thread 0 of every workgroup (skinny_tile)
 };
 
 struct ConvGeom {        // mode 0: plain row-major A.  mode 1: im2col gather from NHWC, K ordered (kh, kw, c)

@@ -49,6 +49,13 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
     const u4* wbase = reinterpret_cast<const u4*>(W8 ? a.W8 : a.W) + (size_t)tile * KC * 64 + lane;
     const int clast = min(max(c1 - 1, c0), KC - 1);
 
+    long long* trc = (a.trace && threadIdx.x == 0) ? a.trace + (size_t)tile * 8 : nullptr;
+#define SK_T(i) do { if (trc) trc[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+    SK_T(0);
+    if (trc) {       // where this workgroup runs: HW_ID (wave/simd/cu/sh/se fields) and the XCC (XCD) id
+        trc[6] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     // HW_REG_HW_ID (id 4), bits 0..31
+        trc[7] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));    // HW_REG_XCC_ID (id 20)
+    }
     // two weight batches in flight before anything else (HBM latency overlaps the wait and the prologue)
     u4 wv[U], wn[U];
 #pragma unroll
@@ -60,6 +67,7 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
         for (int u = 0; u < U; ++u) wn[u] = ldg16_nt(wbase + (size_t)min(c0 + U + u, clast) * 64);
     }
 
+    SK_T(1);
     wait_inputs();          // fused launches: block until the producer workgroups have published X (and resid)
 
     // COHX (fused launches with the fence-free hand-off): X was published write-through by other workgroups of THIS
@@ -111,6 +119,7 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
         __syncthreads();
     }
 
+    SK_T(2);                // activations staged
     const T* xrow[MT];
     bool xok[MT];
 #pragma unroll
@@ -173,11 +182,13 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
             for (int u = 0; u < U; ++u) wn[u] = ldg16_nt(wbase + (size_t)min(cb + 2 * U + u, clast) * 64);
         }
     }
+    SK_T(3);                // K loop done (wave 0)
     // D[i = n_local = g*4+reg][j = m_local = r]  ->  red[w][mt][m_local*16 + n_local]
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
         *reinterpret_cast<float4*>(&red[w][mt][r * 16 + g * 4]) = make_float4(acc[mt][0], acc[mt][1], acc[mt][2], acc[mt][3]);
     __syncthreads();
+    SK_T(4);                // all waves done
 
     const int t = threadIdx.x;
     constexpr int NOUT = MT * 256;
@@ -231,6 +242,8 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
             }
         }
     }
+    SK_T(5);
+#undef SK_T
 }
 
 }  // namespace rdx

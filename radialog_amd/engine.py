@@ -222,6 +222,12 @@ class RdxEngine:
         check(self.ctx, self.lib.rdx_attn_trace(self.ctx, layer, buf.data_ptr()), "rdx_attn_trace")
         return buf
 
+    def gemv_trace(self, what: int, layer: int, max_tiles: int = 2048):
+        """Debug: per-workgroup timestamps [tiles, 8] of one stand-alone decode GEMV (1 gate/up, 2 qkv, 4 down)."""
+        buf = torch.zeros(max_tiles, 8, dtype=torch.int64)
+        check(self.ctx, self.lib.rdx_gemv_trace(self.ctx, what, layer, buf.data_ptr(), max_tiles), "rdx_gemv_trace")
+        return buf
+
     def mega_trace(self, max_wgs: int):
         """Debug: per-workgroup {start, inputs ready, end, role} of one chained decode step (RDX_MEGA), int64 [max_wgs, 4]."""
         buf = torch.zeros(max_wgs, 4, dtype=torch.int64)
