@@ -12,6 +12,7 @@
 //   * split-K over blockIdx.z for small grids (prefill at M = 160 has only 64-350 output tiles for 256 CUs): fp32
 //     partial slabs + a fixed-order reduce kernel that applies the epilogue (deterministic, no atomics).
 #include <algorithm>
+#include <stdlib.h>
 
 #include "rdx_common.h"
 #include "rdx_kernels.h"
@@ -164,6 +165,112 @@ __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// 256 x 256 x 32 variant with a 4-stage LDS ring for large M (batched prefill, batched encoder GEMMs).
+// PMC counters put gemm_dma_k at 33 % MFMA utilisation with the LDS 18 % busy and the waves resident: its single stage of
+// DMA lookahead (one 128 x 128 x 64 step = ~0.2 us of MFMA work) is far shorter than the memory latency. Here a block
+// tile of 256 x 256 halves the operand bytes per MFMA, a stage is 32 KiB (one k-chunk of 32 for 16 + 16 sub-tiles), and
+// four stages are resident (128 KiB, one workgroup of 8 waves per CU): three stages = ~1.3 us of MFMA work are always
+// in flight. Waves 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 MFMA tiles (128 accumulator registers, two waves per SIMD).
+// One barrier per stage: it publishes stage s and at the same time frees the slot that stage s+3 is then loaded into.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int G2_BM = 256, G2_BN = 256, G2_NS = 4;
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_dma256_k(GemmArgs a) {
+    typedef typename Vec8<T>::type V8;
+    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [stage 4][operand 2][block 16][lane 64]
+    const int MB = (a.M + G2_BM - 1) / G2_BM, NB = (a.N + G2_BN - 1) / G2_BN;
+    const int nwg = MB * NB;
+    int tile;
+    {   // XCD-aware order (see gemm_dma_k)
+        const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, rr = nwg & 7;
+        tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+    }
+    const int bn = tile / MB, bm = tile - bn * MB;
+    const int M0 = bm * G2_BM, N0 = bn * G2_BN;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int wm = w >> 2, wn = w & 3;
+    const int KC = a.K >> 5, NT16 = (a.N + 15) >> 4;
+    const int nsteps = KC;                                              // one k-chunk of 32 per stage
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const u4* Wp = reinterpret_cast<const u4*>(a.W) + lane;
+
+    // this wave stages sub-tiles 2w, 2w+1 of each operand; addresses: one base per block, advanced by the stage index
+    const u4* wsrc[2];
+    const T* xsrc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int st = w * 2 + j;
+        wsrc[j] = Wp + (size_t)min((N0 >> 4) + st, NT16 - 1) * KC * 64;
+        xsrc[j] = X + (size_t)min(M0 + st * 16 + r, a.M - 1) * a.ldx + g * 8;
+    }
+    auto stage = [&](int s, int slot) {                                 // s is clamped by the caller: loads are unconditional
+        u4* base = lds + (size_t)slot * 2 * 16 * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int st = w * 2 + j;
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + (size_t)s * 64), (lptr_t)(base + st * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[j] + (size_t)s * 32), (lptr_t)(base + (16 + st) * 64), 16, 0, 0);
+        }
+    };
+
+    v4f acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int p = 0; p < G2_NS - 1; ++p) stage(min(p, nsteps - 1), p);   // stages 0..2 in flight: 12 loads per wave
+    for (int s = 0; s < nsteps; ++s) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // this wave's 4 loads of stage s have landed
+        __builtin_amdgcn_s_barrier();                                   // ... everyone's have, and everyone finished stage s-1
+        stage(min(s + G2_NS - 1, nsteps - 1), (s + G2_NS - 1) % G2_NS); // into the slot stage s-1 was read from (past the end:
+                                                                        // the last stage again, harmless, keeps the wait counted)
+        const u4* base = lds + (size_t)(s % G2_NS) * 2 * 16 * 64;
+        V8 wf[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) wf[nt] = as_vec8<T>(base[(wn * 4 + nt) * 64 + lane]);
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const V8 xf = as_vec8<T>(base[(16 + wm * 8 + mt) * 64 + lane]);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma16(wf[nt], xf, acc[nt][mt]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // LDS reads of this stage are done before the next barrier
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // epilogue: lane (r = m_local, g) holds out[m][n0 + g*4 + 0..3]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = N0 + (wn * 4 + nt) * 16 + g * 4;
+        if (n >= a.N) continue;                                     // whole 16-column tile at once (N % 16 == 0)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = M0 + (wm * 8 + mt) * 16 + r;
+            float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
+            if (EPI == EPI_SILU_MUL) {
+                float u[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] = __shfl_xor(v[e], 32, 64);
+                if (g < 2 && m < a.M) {
+                    typedef T T4 __attribute__((ext_vector_type(4)));
+                    T4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fromf<T>(swiglu<T>(v[e], u[e]));
+                    const int oc = (N0 >> 1) + (wn * 4 + nt) * 8 + g * 4;
+                    *reinterpret_cast<T4*>(reinterpret_cast<T*>(a.out) + (size_t)m * a.ldo + oc) = o;
+                }
+                continue;
+            }
+            if (m < a.M) store4<T, EPI>(a, m, n, v);
+        }
+    }
+}
+
 // split-K reducer: sums the fp32 slabs in split order and applies the epilogue. One thread = 4 consecutive columns.
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void splitk_reduce_k(GemmArgs a, const float* __restrict__ partial, int splits) {
@@ -198,6 +305,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(GemmArgs a, const float* 
 
 template <typename T, int EPI>
 static void launch_dma_epi(const GemmArgs& a, float* ws, size_t ws_floats, hipStream_t s) {
+    {   // large M: the 256 x 256 tile kernel with the 4-stage ring, as long as its grid still covers the chip
+        const char* e256 = getenv("RDX_DMA256");
+        const int big = e256 ? atoi(e256) : 256;                  // minimum number of 256 x 256 tiles (0 = never)
+        const int MB2 = (a.M + G2_BM - 1) / G2_BM, NB2 = (a.N + G2_BN - 1) / G2_BN;
+        // (the short-K / narrow-N 1x1 convolutions of the encoder are memory-bound and do better with the small tile)
+        if (big && a.M >= 1024 && a.K >= 512 && a.N >= 1024 && MB2 * NB2 >= big) {
+            const size_t smem2 = (size_t)G2_NS * 2 * 16 * 64 * sizeof(u4);   // 128 KiB
+            static bool attr2 = false;
+            if (!attr2) { hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); attr2 = true; }
+            hipLaunchKernelGGL((gemm_dma256_k<T, EPI>), dim3(MB2 * NB2), dim3(512), smem2, s, a);
+            return;
+        }
+    }
     const int MB = (a.M + DG_BM - 1) / DG_BM, NB = (a.N + DG_BN - 1) / DG_BN, blocks = MB * NB;
     const int nsteps = a.K / DG_BK;
     int splits = 1;

@@ -54,6 +54,9 @@ CASES = [
     (196, 1408, 1408, 0, False, 3), (160, 4096, 4096, 3, False, 3), (160, 512, 11008, 3, False, 3), (160, 256, 4096, 4, False, 3),
     (300, 144, 512, 1, False, 3), (33, 64, 64, 2, False, 3), (1000, 272, 2048, 6, False, 3), (129, 4096, 128, 0, True, 3),
     (160, 2048, 4096, 4, True, 0),
+    # 256 x 256 x 32 four-stage LDS-DMA kernel (M >= 1024 and >= 256 tiles): ragged M and N, few and many K stages, every epilogue shape
+    (2048, 8192, 512, 4, False, 3), (1300, 16400, 576, 0, False, 3), (1024, 16384, 512, 3, False, 3), (5120, 4096, 640, 6, False, 3),
+    (4096, 4096, 1024, 1, False, 3),
     # 16 < M <= 32 with LDS-staged activations (skinny32.hip): 4-tile and 2-tile workgroups, ragged tile groups, ragged K ranges
     (32, 8208, 512, 3, False, 0), (19, 1040, 4096, 0, False, 0), (32, 2064, 1408, 4, False, 0), (27, 48, 11008, 3, False, 0),
     (32, 16400, 1024, 4, True, 0),
