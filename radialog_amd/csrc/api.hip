@@ -93,6 +93,7 @@ struct rdx_ctx {
     int mega_occ = 4;                // RDX_MEGA_OCC: 8 = two workgroups per CU, 4 = one
     GemmW cls_fc1, cls_fc2; const float *cls_fc1_b = nullptr, *cls_fc2_b = nullptr;   // findings classifier head
     void *cls_pooled = nullptr, *cls_h = nullptr, *cls_out = nullptr;
+    void* zero16 = nullptr;          // 16 zero bytes: source of padding taps in the DMA conv gather
     void* d_cur_rope = nullptr;      // [B][2][128] cos | sin row of each row's current position (written by greedy_step_k)
     MegaLayer* d_mlayers = nullptr; int* d_mctr = nullptr;
     long long* d_mtrace = nullptr;   // set only during rdx_mega_trace
@@ -223,6 +224,7 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
         delete c;
         return fail(nullptr, -2, "rdx_create: cannot create stream on device %d", device_id);
     }
+    if (hipMalloc(&c->zero16, 64) == hipSuccess) { hipMemset(c->zero16, 0, 64); c->allocs.push_back(c->zero16); } else c->zero16 = nullptr;
     c->gemm_ws_floats = (size_t)16 << 20;          // 64 MiB of fp32 split-K slabs
     if (hipMalloc((void**)&c->gemm_ws, c->gemm_ws_floats * sizeof(float)) != hipSuccess) { c->gemm_ws = nullptr; c->gemm_ws_floats = 0; }
     else c->allocs.push_back(c->gemm_ws);
@@ -528,6 +530,7 @@ static void conv_gemm(rdx_ctx* c, const void* X, const GemmW& W, const float* bi
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) cg.mode = 0;
     // 1x1 stride-1 convolutions are plain GEMMs; everything else needs the gather path of the tiled kernel
     if (cg.mode == 0 && c->use_dma_gemm && gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
+    else if (c->use_dma_gemm && c->zero16 && !resid && gemm_dma_conv_supported(a, cg, epi)) launch_gemm_dma_conv(c->cfg.dtype, a, cg, epi, c->zero16, c->stream);
     else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
 }
 

@@ -54,8 +54,12 @@ __device__ __forceinline__ void store4(const GemmArgs& a, int m, int n, float v[
     *reinterpret_cast<T4*>(out + (size_t)m * a.ldo + n) = o;
 }
 
-template <typename T, int EPI, bool SPLIT>
-__global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict__ partial, int steps_per_split) {
+// CONV: the activation operand is an implicit-GEMM gather from an NHWC tensor (K ordered (kh, kw, c), Cin % 8 == 0, so a lane's
+// 16-byte piece lies inside one filter tap): every lane hands global_load_lds its own source address; taps that fall
+// into the zero padding read a 16-byte zero block instead.
+template <typename T, int EPI, bool SPLIT, bool CONV = false>
+__global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict__ partial, int steps_per_split, ConvGeom cg = ConvGeom(),
+                                                  const void* zero16 = nullptr) {
     typedef typename Vec8<T>::type V8;
     extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [buf 2][operand 2][block 16][lane 64]
     const int MB = (a.M + DG_BM - 1) / DG_BM, NB = (a.N + DG_BN - 1) / DG_BN;
@@ -80,13 +84,24 @@ __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict_
     // this wave stages blocks i = w*4 .. w*4+3 of each operand per step; block i = (sub-tile i>>1, k-chunk i&1)
     const u4* wsrc[4];
     const T* xsrc[4];
+    int ih0[4], iw0[4];                              // CONV: top-left input coordinate of this lane's output pixel
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int i = w * 4 + j, st = i >> 1, kc = i & 1;
         const int t16 = min((N0 >> 4) + st, NT16 - 1);
         wsrc[j] = Wp + ((size_t)t16 * KC + kc) * 64 + lane;
         const int row = min(M0 + st * 16 + r, a.M - 1);
-        xsrc[j] = X + (size_t)row * a.ldx + kc * 32 + g * 8;
+        if (!CONV) {
+            xsrc[j] = X + (size_t)row * a.ldx + kc * 32 + g * 8;
+            ih0[j] = iw0[j] = 0;
+        } else {
+            const int hw = cg.Hout * cg.Wout;
+            const int b = row / hw, rem = row - b * hw;
+            const int oh = rem / cg.Wout, ow = rem - oh * cg.Wout;
+            xsrc[j] = X + (size_t)b * cg.Hin * cg.Win * cg.Cin;
+            ih0[j] = oh * cg.stride - cg.pad;
+            iw0[j] = ow * cg.stride - cg.pad;
+        }
     }
     auto stage = [&](int s, int buf) {
         u4* base = lds + (size_t)buf * 2 * 16 * 64;
@@ -94,7 +109,18 @@ __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict_
         for (int j = 0; j < 4; ++j) {
             const int i = w * 4 + j;
             __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + (size_t)s * 2 * 64), (lptr_t)(base + i * 64), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[j] + (size_t)s * DG_BK), (lptr_t)(base + (16 + i) * 64), 16, 0, 0);
+            const T* xp;
+            if (!CONV) {
+                xp = xsrc[j] + (size_t)s * DG_BK;
+            } else {
+                const int k = s * DG_BK + (i & 1) * 32 + g * 8;
+                const int kpos = k / cg.Cin, c0 = k - kpos * cg.Cin;
+                const int kh = kpos / cg.KW, kw = kpos - kh * cg.KW;
+                const int ih = ih0[j] + kh, iw = iw0[j] + kw;
+                const bool inb = ih >= 0 && ih < cg.Hin && iw >= 0 && iw < cg.Win;
+                xp = inb ? xsrc[j] + ((size_t)ih * cg.Win + iw) * cg.Cin + c0 : reinterpret_cast<const T*>(zero16);
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)xp, (lptr_t)(base + (16 + i) * 64), 16, 0, 0);
         }
     };
 
@@ -332,13 +358,13 @@ static void launch_dma_epi(const GemmArgs& a, float* ws, size_t ws_floats, hipSt
     if (splits > 1) {
         static bool attr = false;
         if (!attr) { hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-        hipLaunchKernelGGL((gemm_dma_k<T, EPI, true>), grid, block, smem, s, a, ws, per);
+        hipLaunchKernelGGL((gemm_dma_k<T, EPI, true>), grid, block, smem, s, a, ws, per, ConvGeom(), nullptr);
         const size_t total = (size_t)a.M * (a.N >> 2);
         hipLaunchKernelGGL((splitk_reduce_k<T, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, ws, splits);
     } else {
         static bool attr = false;
         if (!attr) { hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-        hipLaunchKernelGGL((gemm_dma_k<T, EPI, false>), grid, block, smem, s, a, nullptr, nsteps);
+        hipLaunchKernelGGL((gemm_dma_k<T, EPI, false>), grid, block, smem, s, a, nullptr, nsteps, ConvGeom(), nullptr);
     }
 }
 
@@ -353,6 +379,27 @@ static void launch_dma_T(const GemmArgs& a, int epi, float* ws, size_t ws_floats
         case EPI_SILU_MUL: launch_dma_epi<T, EPI_SILU_MUL>(a, ws, ws_floats, s); break;
         default: break;
     }
+}
+
+bool gemm_dma_conv_supported(const GemmArgs& a, const ConvGeom& cg, int epi) {
+    return cg.mode == 1 && a.K % DG_BK == 0 && a.N % 16 == 0 && cg.Cin % 8 == 0 && a.M > 32 &&
+           (epi == EPI_NONE || epi == EPI_RELU);
+}
+
+void launch_gemm_dma_conv(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, const void* zero16, hipStream_t s) {
+    const int MB = (a.M + DG_BM - 1) / DG_BM, NB = (a.N + DG_BN - 1) / DG_BN;
+    const size_t smem = (size_t)2 * 2 * 16 * 64 * sizeof(u4);       // 64 KiB
+    const int nsteps = a.K / DG_BK;
+    RDX_DISPATCH_T(dtype, T, {
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI_NONE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI_RELU, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            attr = true;
+        }
+        if (epi == EPI_RELU) hipLaunchKernelGGL((gemm_dma_k<T, EPI_RELU, false, true>), dim3(MB * NB), dim3(256), smem, s, a, nullptr, nsteps, cg, zero16);
+        else hipLaunchKernelGGL((gemm_dma_k<T, EPI_NONE, false, true>), dim3(MB * NB), dim3(256), smem, s, a, nullptr, nsteps, cg, zero16);
+    });
 }
 
 bool gemm_dma_supported(const GemmArgs& a) { return a.K % DG_BK == 0 && a.N % 16 == 0 && a.ldx % 8 == 0 && a.M > 32; }
