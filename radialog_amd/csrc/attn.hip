@@ -155,16 +155,8 @@ void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s)
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// LoRA + RoPE helpers (head_dim 128)
+// LoRA + RoPE + KV-cache write of the prompt (head_dim 128)
 // ------------------------------------------------------------------------------------------------------------------
-template <typename T>
-__device__ __forceinline__ float lora_delta(const T* Bm, int n, const T* avec, int rnk, float scale) {
-    // T( T(B . a) * scaling ):  lora_B(lora_A(x)) * scaling with each op rounded to the model dtype
-    float acc = 0.f;
-    for (int i = 0; i < rnk; ++i) acc += tof<T>(Bm[(size_t)n * rnk + i]) * tof<T>(avec[i]);
-    return rnd<T>(rnd<T>(acc) * scale);
-}
-
 // one thread = 8 contiguous dims of one (token, head): 16-byte loads/stores throughout; the rotate-half partner of q
 // (which needs the LoRA-updated value) is exchanged through LDS, the partner of k is read straight from the GEMM output.
 template <typename T>
