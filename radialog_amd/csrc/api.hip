@@ -530,7 +530,7 @@ static void conv_gemm(rdx_ctx* c, const void* X, const GemmW& W, const float* bi
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) cg.mode = 0;
     // 1x1 stride-1 convolutions are plain GEMMs; everything else needs the gather path of the tiled kernel
     if (cg.mode == 0 && c->use_dma_gemm && gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
-    else if (c->use_dma_gemm && c->zero16 && !resid && gemm_dma_conv_supported(a, cg, epi)) launch_gemm_dma_conv(c->cfg.dtype, a, cg, epi, c->zero16, c->stream);
+    else if (c->use_dma_gemm && c->zero16 && !resid && gemm_dma_conv_supported(a, cg, epi)) launch_gemm_dma_conv(c->cfg.dtype, a, cg, epi, c->zero16, c->gemm_ws, c->gemm_ws_floats, c->stream);
     else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
 }
 

@@ -386,19 +386,39 @@ bool gemm_dma_conv_supported(const GemmArgs& a, const ConvGeom& cg, int epi) {
            (epi == EPI_NONE || epi == EPI_RELU);
 }
 
-void launch_gemm_dma_conv(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, const void* zero16, hipStream_t s) {
-    const int MB = (a.M + DG_BM - 1) / DG_BM, NB = (a.N + DG_BN - 1) / DG_BN;
+template <typename T, int EPI>
+static void launch_dma_conv_epi(const GemmArgs& a, const ConvGeom& cg, const void* zero16, float* ws, size_t ws_floats, hipStream_t s) {
+    const int MB = (a.M + DG_BM - 1) / DG_BM, NB = (a.N + DG_BN - 1) / DG_BN, blocks = MB * NB;
     const size_t smem = (size_t)2 * 2 * 16 * 64 * sizeof(u4);       // 64 KiB
     const int nsteps = a.K / DG_BK;
+    // the deep layers of the trunk at batch 1 have 8-25 output tiles and K up to 4608: split K over workgroups
+    int splits = 1;
+    if (blocks < 192 && nsteps >= 16 && ws && a.N % 4 == 0) {
+        splits = std::min(std::min((256 + blocks - 1) / blocks, nsteps / 8), 8);
+        while (splits > 1 && (size_t)splits * a.M * a.N > ws_floats) --splits;
+    }
+    const int per = (nsteps + splits - 1) / splits;
+    splits = (nsteps + per - 1) / per;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        attr = true;
+    }
+    if (splits > 1) {
+        hipLaunchKernelGGL((gemm_dma_k<T, EPI, true, true>), dim3(blocks, 1, splits), dim3(256), smem, s, a, ws, per, cg, zero16);
+        const size_t total = (size_t)a.M * (a.N >> 2);
+        hipLaunchKernelGGL((splitk_reduce_k<T, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, ws, splits);
+    } else {
+        hipLaunchKernelGGL((gemm_dma_k<T, EPI, false, true>), dim3(blocks), dim3(256), smem, s, a, nullptr, nsteps, cg, zero16);
+    }
+}
+
+void launch_gemm_dma_conv(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, const void* zero16, float* ws, size_t ws_floats,
+                          hipStream_t s) {
     RDX_DISPATCH_T(dtype, T, {
-        static bool attr = false;
-        if (!attr) {
-            hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI_NONE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI_RELU, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            attr = true;
-        }
-        if (epi == EPI_RELU) hipLaunchKernelGGL((gemm_dma_k<T, EPI_RELU, false, true>), dim3(MB * NB), dim3(256), smem, s, a, nullptr, nsteps, cg, zero16);
-        else hipLaunchKernelGGL((gemm_dma_k<T, EPI_NONE, false, true>), dim3(MB * NB), dim3(256), smem, s, a, nullptr, nsteps, cg, zero16);
+        if (epi == EPI_RELU) launch_dma_conv_epi<T, EPI_RELU>(a, cg, zero16, ws, ws_floats, s);
+        else launch_dma_conv_epi<T, EPI_NONE>(a, cg, zero16, ws, ws_floats, s);
     });
 }
 

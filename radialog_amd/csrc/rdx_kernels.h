@@ -78,7 +78,8 @@ void launch_gemm_dma(int dtype, const GemmArgs& a, int epi, float* ws, size_t ws
 // the same kernel with the activation operand gathered from an NHWC tensor (3x3 / strided convolutions, Cin % 8 == 0, K % 64 == 0,
 // epilogues NONE / RELU); `zero16` = 16 zero bytes in device memory for taps that fall into the padding
 bool gemm_dma_conv_supported(const GemmArgs& a, const ConvGeom& cg, int epi);
-void launch_gemm_dma_conv(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, const void* zero16, hipStream_t s);
+void launch_gemm_dma_conv(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, const void* zero16, float* ws, size_t ws_floats,
+                          hipStream_t s);
 
 void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s);
 // prefill: LoRA add + RoPE + KV-cache write for T tokens of B rows; q -> qout [B*T][hidden]
