@@ -123,6 +123,11 @@ int rdx_gemv_trace(rdx_ctx* ctx, int what, int layer, long long* host, int max_t
 int rdx_gemm_test(rdx_ctx* ctx, const void* X, const float* W, const float* bias, const void* resid, void* out, int M, int N,
                   int K, int epi, const void* norm_w, float eps, int force);
 
+/* the lm_head epilogue of the weight-streaming kernels on a bare GEMM (M <= 32): logits model-dtype [M][N] (columns >=
+ * n_valid are not written) and the greedy choice per row (argmax over n < n_valid, ties -> lowest index). Test hook. */
+int rdx_logits_test(rdx_ctx* ctx, const void* X, const float* W, int M, int N, int n_valid, int K, void* out_logits,
+                    int32_t* argmax_host, int fp8);
+
 #ifdef __cplusplus
 }
 #endif

@@ -165,8 +165,14 @@ static GemmArgs gargs(const void* X, int ldx, const GemmW& W, const float* bias,
 // the rows are normalised once by rmsnorm_k into a scratch buffer (batch-32 decode).
 static void skinny(rdx_ctx* c, GemmArgs a, int epi) {
     if (a.norm_w && !skinny_fits_lds(a.M, a.K)) {
-        launch_rmsnorm(c->cfg.dtype, a.X, a.norm_w, c->dxn, a.M, a.K, a.eps, c->stream);
+        const void* x = a.X; const void* nw = a.norm_w;
         a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr;
+        if (xstat32_supported(a, epi)) {       // the normalised rows go straight into the consumer's register-fragment order
+            a.xpacked = (a.W8 && a.wscale) ? 2 : 1;
+            launch_rmsnorm_packed32(c->cfg.dtype, x, nw, c->dxn, a.M, a.K, a.eps, a.xpacked, c->stream);
+        } else {
+            launch_rmsnorm(c->cfg.dtype, x, nw, c->dxn, a.M, a.K, a.eps, c->stream);
+        }
     }
     launch_skinny_gemm(c->cfg.dtype, a, epi, c->stream);
 }
@@ -399,7 +405,7 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         c->n_vtiles = c->lm_head.Npad / 16;
         ALLOC(c, c->part_val, (size_t)B * c->n_vtiles * sizeof(float));
         ALLOC(c, c->part_idx, (size_t)B * c->n_vtiles * sizeof(int));
-        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)B * H * 2); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
+        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)(B > 16 ? 32 : B) * H * 2); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
         ALLOC(c, c->datt, (size_t)B * H * 2); ALLOC(c, c->dgu, (size_t)B * I * 2);
     }
     if (f.enable_vision) {
@@ -1068,12 +1074,13 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
     const bool use_skinny = force == 1 || (force == 0 && M <= 32);
     if (use_skinny) {
         if (M > 32) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: skinny path needs M <= 32"); }
+        void* keep = c->dxn;                       // skinny() pre-normalises into c->dxn when the rows do not fit the LDS
         if (a.norm_w && !skinny_fits_lds(M, K)) {
-            HIPCHK(c, hipMalloc(&xn, (size_t)M * K * 2));
-            launch_rmsnorm(c->cfg.dtype, X, norm_w, xn, M, K, eps, c->stream);
-            a.X = xn; a.norm_w = nullptr;
+            HIPCHK(c, hipMalloc(&xn, (size_t)32 * K * 2));
+            c->dxn = xn;
         }
-        launch_skinny_gemm(c->cfg.dtype, a, epi == EPI_RESID_RELU ? EPI_RESID : epi, c->stream);
+        skinny(c, a, epi == EPI_RESID_RELU ? EPI_RESID : epi);
+        c->dxn = keep;
     } else {
         if (a.norm_w) {
             HIPCHK(c, hipMalloc(&xn, (size_t)M * K * 2));
@@ -1093,5 +1100,47 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
     HIPCHK(c, hipGetLastError());
     hipFree(wp);
     if (xn) hipFree(xn);
+    return 0;
+}
+
+// the lm_head epilogue (logits + per-tile argmax partials) of the weight-streaming kernels on a bare GEMM: what the decode
+// step runs before greedy_step_k; the partials are reduced here on the host with the same tie rule (lowest index)
+extern "C" int rdx_logits_test(rdx_ctx* c, const void* X, const float* W, int M, int N, int n_valid, int K, void* out_logits,
+                               int32_t* argmax_host, int fp8) {
+    if (!c || !X || !W || !out_logits || !argmax_host) return fail(c, -1, "rdx_logits_test: null argument");
+    if (K % 32 || N % 16 || M > 32 || n_valid > N || (fp8 && K % 64)) return fail(c, -1, "rdx_logits_test: bad shape");
+    HIPCHK(c, hipSetDevice(c->device));
+    GemmW w;
+    w.N = N; w.K = K; w.Npad = N;
+    const int nt = N / 16;
+    char* wp = nullptr;
+    const size_t wb = (size_t)N * K * 2, qb = fp8 ? (size_t)N * K + (size_t)N * 4 : 0, pb = (size_t)M * nt * 4;
+    HIPCHK(c, hipMalloc((void**)&wp, wb + qb + 2 * pb + (size_t)M * K * 2));
+    w.w = wp;
+    if (fp8) {
+        w.w8 = wp + wb; w.scale = (float*)(wp + wb + (size_t)N * K);
+        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, wp, N, K, N, c->stream);
+    } else {
+        launch_pack_weight(c->cfg.dtype, W, wp, N, K, N, nullptr, c->stream);
+    }
+    GemmArgs a = gargs(X, K, w, nullptr, out_logits, N, M);
+    a.n_valid = n_valid;
+    a.part_val = (float*)(wp + wb + qb); a.part_idx = (int*)(wp + wb + qb + pb);
+    launch_skinny_gemm(c->cfg.dtype, a, EPI_LOGITS, c->stream);
+    std::vector<float> pv((size_t)M * nt);
+    std::vector<int> pi((size_t)M * nt);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(pv.data(), a.part_val, pb, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(pi.data(), a.part_idx, pb, hipMemcpyDeviceToHost));
+    hipFree(wp);
+    for (int m = 0; m < M; ++m) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int t = 0; t < nt; ++t) {
+            const float v = pv[(size_t)m * nt + t]; const int ix = pi[(size_t)m * nt + t];
+            if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+        }
+        argmax_host[m] = bi;
+    }
     return 0;
 }

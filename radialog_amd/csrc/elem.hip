@@ -6,12 +6,25 @@
 namespace rdx {
 
 // ---- LlamaRMSNorm (modeling_llama_imgemb.py:85-93): fp32 statistics, (x*rstd).to(T), then weight*h in T ---------------
-template <typename T>
+// PACK != 0 (batch-32 decode, consumer xstat32_k): the output is written in the MFMA B-operand fragment order of the 32-row
+// block, [fragment f][row tile mt][lane (g, r)][8], so that a wave's activation fragment is one contiguous KiB. A thread's 8
+// elements k = i .. i + 8 of row m are exactly one lane's piece: PACK 1 (32-deep fragments): f = i / 32, g = (i % 32) / 8;
+// PACK 2 (the fp8 weights' 64-deep chunks): f = 2 (i / 64) + (i % 16) / 8, g = (i % 64) / 16. Rows >= n_rows are zero-filled.
+template <typename T, int PACK>
 __global__ __launch_bounds__(256) void rmsnorm_k(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ out,
-                                                 int H, float eps) {
+                                                 int H, float eps, int n_rows) {
     typedef typename Vec8<T>::type V8;
     __shared__ float red[32];
     const size_t row = blockIdx.x;
+    auto dst = [&](int i) -> T* {
+        if (PACK == 0) return out + row * H + i;
+        const int f = PACK == 1 ? (i >> 5) : (2 * (i >> 6) + ((i & 15) >> 3)), g = PACK == 1 ? ((i & 31) >> 3) : ((i & 63) >> 4);
+        return out + ((size_t)((f * 2 + (int)(row >> 4)) * 64 + g * 16 + (int)(row & 15)) << 3);
+    };
+    if (PACK && (int)row >= n_rows) {
+        for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) stg16(dst(i), (u4){0u, 0u, 0u, 0u});
+        return;
+    }
     const T* xr = x + row * H;
     float ss = 0.f;
     for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {
@@ -27,13 +40,20 @@ __global__ __launch_bounds__(256) void rmsnorm_k(const T* __restrict__ x, const 
         V8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof<T>(wv[j]) * rnd<T>(tof<T>(v[j]) * rs));
-        stg16(out + row * H + i, as_u4<T>(o));
+        stg16(dst(i), as_u4<T>(o));
     }
 }
 
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s) {
-    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T>), dim3(rows), dim3(256), 0, s, (const T*)x, (const T*)w,
-                                                (T*)out, H, eps));
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T, 0>), dim3(rows), dim3(256), 0, s, (const T*)x, (const T*)w,
+                                                (T*)out, H, eps, rows));
+}
+
+void launch_rmsnorm_packed32(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, int pack, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, {
+        if (pack == 2) hipLaunchKernelGGL((rmsnorm_k<T, 2>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, H, eps, rows);
+        else hipLaunchKernelGGL((rmsnorm_k<T, 1>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, H, eps, rows);
+    });
 }
 
 // ---- LayerNorm over the last dim (Q-Former post-LN, eps 1e-12; fp32 statistics, two-pass variance) -------------------

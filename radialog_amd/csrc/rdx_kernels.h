@@ -29,6 +29,7 @@ struct GemmArgs {
     // fp8 weights (skinny / fused decode paths only): e4m3 bytes in the 64-deep fragment order (gemm.hip) + one fp32 scale per
     // output row; `W` then holds the dequantised model-dtype copy the other kernels use
     const void* W8; const float* wscale;
+    int xpacked;                     // xstat32_k: X is the fragment-packed 32-row block written by launch_rmsnorm_packed32 (1 / 2)
     long long* trace;                // debug: [tile][8] timestamps (100 MHz ticks) written by thread 0 of every workgroup (skinny_tile)
 };
 
@@ -71,6 +72,8 @@ void launch_skinny_gemm(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 // no fused RMSNorm (a.norm_w must be null)
 bool skinny32_supported(const GemmArgs& a, int epi);
 void launch_skinny32(int dtype, const GemmArgs& a, int epi, hipStream_t s);
+bool xstat32_supported(const GemmArgs& a, int epi);
+void launch_xstat32(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 void launch_tiled_gemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s);
 // LDS-DMA GEMM for plain row-major activations (M > 32, K % 64 == 0); `ws` = fp32 split-K workspace (nullable)
 bool gemm_dma_supported(const GemmArgs& a);
@@ -135,6 +138,8 @@ void launch_decode_layers(int dtype, MegaArgs ma, int nlayers, int occ, hipStrea
 void launch_decode_roles(int dtype, MegaArgs ma, int R0, int R1, int occ, hipStream_t s);
 
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s);
+// rows <= 32 normalised into the 32-row fragment-packed block xstat32_k reads (pack 1: 32-deep fragments, 2: fp8 64-deep order)
+void launch_rmsnorm_packed32(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, int pack, hipStream_t s);
 void launch_layernorm(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* out_f32,
                       int rows, int H, float eps, hipStream_t s);
 void launch_layernorm_ex(int dtype, const void* x, long ldx, const float* gamma, const float* beta, const void* emb, int emb_rows,

@@ -1,0 +1,211 @@
+// Activation-stationary weight-streaming GEMM for 16 < M <= 32 rows and K = 4096 (batch-32 decode: QKV, gate/up, lm_head), gfx950.
+//
+// skinny32_k re-stages the [32][K] activation block through LDS for every group of four output tiles, one workgroup
+// barrier per 512-deep stage, and its weight stream ran at ~3.9 TB/s. Here the activations never move after start-up:
+// 256 persistent 8-wave workgroups (one per CU), wave w owns the K range [512 w, 512 w + 512) and keeps the MFMA B-operand
+// fragments of all 32 rows for that range in registers (2 x 16 fragments = 128 VGPRs, read once per workgroup = 256 KiB
+// per CU from L2). The workgroup then walks output tiles t = blockIdx, blockIdx + grid, ...: per tile every wave streams its 16
+// weight fragments (16 KiB contiguous, fragment-packed, non-temporal), does 32 MFMAs, and drops a 16 x 32 fp32 partial in LDS;
+// one barrier per tile, after which all 512 threads reduce the 8 partials in a fixed order and run the epilogue while the
+// next tile's fragments are already landing (the ring is refilled fragment by fragment as the MFMAs consume it: 16 KiB
+// per wave = 128 KiB per CU in flight, no load ever waits for a barrier). fp8 weights (W8): 8 loads of 64-deep fragments per
+// tile, two tiles per trip so the same 16 KiB stay in flight. Same rounding points / epilogues as skinny32_k.
+#include <type_traits>
+#include "rdx_common.h"
+#include "rdx_kernels.h"
+#include "skinny_body.h"   // swiglu()
+
+namespace rdx {
+
+constexpr int XS_WAVES = 8, XS_THREADS = 512, XS_K = 4096, XS_CPW = XS_K / 32 / XS_WAVES;   // 16 chunks of 32 per wave
+
+template <typename T, int EPI, bool W8>
+__global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
+    constexpr int TPI = W8 ? 2 : 1;                   // tiles per trip
+    constexpr int LPT = W8 ? XS_CPW / 2 : XS_CPW;     // 16-byte weight loads per wave per tile
+    constexpr int RING = TPI * LPT;                   // 16
+    extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+    float* red = reinterpret_cast<float*>(smx);       // [2 bufs][TPI][8 waves][2 mt][256]
+
+    const int lane = threadIdx.x & 63, wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int ntiles = (a.N + 15) >> 4;
+    const int G = gridDim.x;
+    const int ngroups = (ntiles + TPI - 1) / TPI;     // trips in total; this workgroup takes blockIdx, blockIdx + G, ...
+    const int nit = (ngroups - (int)blockIdx.x + G - 1) / G;
+    if (nit <= 0) return;
+    // debug timeline (rdx_gemv_trace): 0 entry, 1 first trip's K loop done, 2 first trip done, 3 last trip begins, 4 its K loop done, 5 end
+    long long* trc = (a.trace && threadIdx.x == 0) ? a.trace + (size_t)blockIdx.x * 8 : nullptr;
+#define XS_T(i) do { if (trc) trc[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+    XS_T(0);
+
+    const int WC = W8 ? XS_K / 64 : XS_K / 32;                       // weight chunks per tile row block
+    const u4* wbase = reinterpret_cast<const u4*>(W8 ? a.W8 : a.W) + (size_t)(wa * LPT) * 64;   // wave-uniform
+    auto tile_ptr = [&](int t) { return wbase + (size_t)min(t, ntiles - 1) * WC * 64; };
+
+    u4 ring[RING];
+    {
+        const int t0 = (int)blockIdx.x * TPI;
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) {
+            const u4* wp = tile_ptr(t0 + q);
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                ring[q * LPT + j] = ldg16_nt(wp + (unsigned)(j * 64 + lane));
+                __builtin_amdgcn_sched_barrier(0);               // issue order = consume order (the loop's counted waits rely on it)
+            }
+        }
+    }
+
+    // ---- activations -> registers, requested AFTER the first ring of weights: the 256 workgroups read the same 256 KiB from L2
+    // at once (~6 us of L2 hot-spotting), and weight requests queued behind them would leave HBM idle meanwhile. xf[mt][c] is the B fragment (column = row 16 mt + r of X, k = 8 g .. + 8 within the chunk)
+    const T* X = reinterpret_cast<const T*>(a.X);
+    u4 xf[2][XS_CPW];
+    const bool xp = a.xpacked != 0;          // fragment-packed by rmsnorm_k<T, PACK>: fragment (f, mt) is one contiguous KiB
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const T* xr = xp ? X + (size_t)(((wa * XS_CPW) * 2 + mt) * 64 + lane) * 8
+                         : X + (size_t)min(mt * 16 + r, a.M - 1) * a.ldx + wa * (XS_CPW * 32);
+#pragma unroll
+        for (int c = 0; c < XS_CPW; ++c) {
+            // row-major X, bf16/f16 weights: chunk c covers k = 32 c + 8 g .. + 8. fp8: load j = c / 2 covers k = 64 j + 16 g .. + 16
+            // and MFMA h = c & 1 takes k = 64 j + 16 g + 8 h .. + 8  (16 rows x 16 B per quarter wave: slow, tests only)
+            const int koff = W8 ? ((c >> 1) * 64 + g * 16 + (c & 1) * 8) : (c * 32 + g * 8);
+            xf[mt][c] = ldg16(xr + (xp ? c * 1024 : koff));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    T* out = reinterpret_cast<T*>(a.out);
+    if (a.out_step && out) out += (size_t)(*a.out_step) * a.out_step_stride;
+
+    // epilogue coordinates of this thread: one output per tile of the trip; idx = m_local * 16 + n_local
+    const int e_mt = threadIdx.x >> 8, e_idx = threadIdx.x & 255, e_m = e_mt * 16 + (e_idx >> 4), e_nl = e_idx & 15;
+
+    auto trip = [&](int it, auto pf_tag) {
+        constexpr bool PF = decltype(pf_tag)::value;
+        const int grp = (int)blockIdx.x + it * G, t0 = grp * TPI;
+        // operands the epilogue needs come first in the (in-order) load queue, ahead of the ring refills
+        float e_res[TPI], e_sc[TPI], e_bias[TPI];
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) {
+            const int n = min((t0 + q) * 16 + e_nl, ntiles * 16 - 1);
+            e_res[q] = 0.f; e_sc[q] = 1.f; e_bias[q] = 0.f;
+            if (EPI == EPI_RESID) e_res[q] = tof<T>(reinterpret_cast<const T*>(a.resid)[(size_t)min(e_m, a.M - 1) * a.ldr + min(n, a.N - 1)]);
+            if (W8) e_sc[q] = a.wscale[n];
+            if (a.bias) e_bias[q] = a.bias[min(n, a.N - 1)];
+        }
+        v4f acc[TPI][2];
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) {
+            acc[q][0] = (v4f){0.f, 0.f, 0.f, 0.f};
+            acc[q][1] = (v4f){0.f, 0.f, 0.f, 0.f};
+            const u4* wn = tile_ptr(t0 + G * TPI + q);
+#pragma unroll
+            for (int j = 0; j < LPT; ++j) {
+                const u4 wv = ring[q * LPT + j];
+                if (W8) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u4 wd = dequant8<T>(h ? wv.z : wv.x, h ? wv.w : wv.y);
+                        acc[q][0] = mfma16(as_vec8<T>(wd), as_vec8<T>(xf[0][2 * j + h]), acc[q][0]);
+                        acc[q][1] = mfma16(as_vec8<T>(wd), as_vec8<T>(xf[1][2 * j + h]), acc[q][1]);
+                    }
+                } else {
+                    acc[q][0] = mfma16(as_vec8<T>(wv), as_vec8<T>(xf[0][j]), acc[q][0]);
+                    acc[q][1] = mfma16(as_vec8<T>(wv), as_vec8<T>(xf[1][j]), acc[q][1]);
+                }
+                if (PF) ring[q * LPT + j] = ldg16_nt(wn + (unsigned)(j * 64 + lane));
+                __builtin_amdgcn_sched_barrier(0);           // keep consume-j / refill-j order: the waits stay vmcnt(RING - 1)
+            }
+        }
+        if (it == 0) XS_T(1);
+        if (!PF) XS_T(4);
+        // D[n_local = 4 g + reg][m_local = r] -> red[buf][q][wave][mt][m_local * 16 + n_local]
+        float* rb = red + (size_t)(it & 1) * (TPI * XS_WAVES * 2 * 256);
+#pragma unroll
+        for (int q = 0; q < TPI; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                *reinterpret_cast<float4*>(&rb[((q * XS_WAVES + wa) * 2 + mt) * 256 + r * 16 + g * 4]) =
+                    make_float4(acc[q][mt][0], acc[q][mt][1], acc[q][mt][2], acc[q][mt][3]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) {
+            const int t_o = t0 + q, n = t_o * 16 + e_nl;
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < XS_WAVES; ++i) v += rb[((q * XS_WAVES + i) * 2 + e_mt) * 256 + e_idx];
+            if (W8) v *= e_sc[q];
+            v += e_bias[q];
+            const bool ok = (e_m < a.M) && (t_o < ntiles) && (n < a.N);
+            if (EPI == EPI_NONE) {
+                if (ok) out[(size_t)e_m * a.ldo + n] = fromf<T>(v);
+            } else if (EPI == EPI_RESID) {
+                if (ok) out[(size_t)e_m * a.ldo + n] = fromf<T>(e_res[q] + rnd<T>(v));
+            } else if (EPI == EPI_SILU_MUL) {
+                // rows 0-7 of a tile are gate, 8-15 the matching up rows: the partner sits 8 lanes away in the same DPP row
+                const float u = dpp_mov<DPP_ROR8>(v);
+                if (e_nl < 8 && ok) out[(size_t)e_m * a.ldo + t_o * 8 + e_nl] = fromf<T>(swiglu<T>(v, u));
+            } else if (EPI == EPI_LOGITS) {
+                float lv = rnd<T>(v);
+                int li = n;
+                const bool valid = n < a.n_valid && t_o < ntiles;
+                if (valid && e_m < a.M && out) out[(size_t)e_m * a.ldo + n] = fromf<T>(lv);
+                if (!valid) { lv = -INFINITY; li = 0x7fffffff; }
+                // argmax over the tile's 16 columns (16 consecutive lanes share m); ties -> lowest index (torch.argmax)
+#pragma unroll
+                for (int sh = 8; sh > 0; sh >>= 1) {
+                    const float ov = __shfl_xor(lv, sh, 64);
+                    const int oi = __shfl_xor(li, sh, 64);
+                    if (ov > lv || (ov == lv && oi < li)) { lv = ov; li = oi; }
+                }
+                if (e_nl == 0 && e_m < a.M && t_o < ntiles) {
+                    a.part_val[(size_t)e_m * ntiles + t_o] = lv;
+                    a.part_idx[(size_t)e_m * ntiles + t_o] = li;
+                }
+            }
+        }
+    };
+
+    // the first trip is peeled: its waits cover the activation loads (newest in the queue), the loop's stay counted
+    if (nit > 1) {
+        trip(0, std::true_type{});
+        XS_T(2);
+        for (int it = 1; it + 1 < nit; ++it) trip(it, std::true_type{});
+    }
+    XS_T(3);
+    trip(nit - 1, std::false_type{});
+    XS_T(5);
+    if (trc) { trc[6] = nit; trc[7] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }    // HW_REG_XCC_ID
+#undef XS_T
+}
+
+bool xstat32_supported(const GemmArgs& a, int epi) {
+    const char* e = getenv("RDX_XS32");                       // minimum tile count (0 = off); read per launch (tests toggle it)
+    const int min_tiles = e ? atoi(e) : 512;
+    return min_tiles > 0 && a.M > 16 && a.M <= 32 && a.K == XS_K && !a.norm_w && (a.N + 15) / 16 >= min_tiles &&
+           (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL || epi == EPI_LOGITS);
+}
+
+template <typename T, bool W8>
+static void launch_xstat32_t(const GemmArgs& a, int epi, hipStream_t s) {
+    constexpr int TPI = W8 ? 2 : 1;
+    const int nt = (a.N + 15) / 16, groups = (nt + TPI - 1) / TPI;
+    dim3 grid(groups < 256 ? groups : 256), block(XS_THREADS);
+    const size_t smem = (size_t)2 * TPI * XS_WAVES * 2 * 256 * 4;
+    switch (epi) {
+        case EPI_NONE: hipLaunchKernelGGL((xstat32_k<T, EPI_NONE, W8>), grid, block, smem, s, a); break;
+        case EPI_RESID: hipLaunchKernelGGL((xstat32_k<T, EPI_RESID, W8>), grid, block, smem, s, a); break;
+        case EPI_SILU_MUL: hipLaunchKernelGGL((xstat32_k<T, EPI_SILU_MUL, W8>), grid, block, smem, s, a); break;
+        case EPI_LOGITS: hipLaunchKernelGGL((xstat32_k<T, EPI_LOGITS, W8>), grid, block, smem, s, a); break;
+        default: break;
+    }
+}
+
+void launch_xstat32(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
+    const bool w8 = a.W8 && a.wscale;
+    RDX_DISPATCH_T(dtype, T, { if (w8) launch_xstat32_t<T, true>(a, epi, s); else launch_xstat32_t<T, false>(a, epi, s); });
+}
+
+}  // namespace rdx

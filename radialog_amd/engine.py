@@ -201,6 +201,20 @@ class RdxEngine:
                                                eps, force), "rdx_gemm_test")
         return out
 
+    def logits_test(self, x, w, n_valid=None, fp8=False):
+        """(logits [M,N] model dtype, argmax int32[M]) of x @ w.T through the lm_head epilogue of the weight-streaming kernels."""
+        import ctypes
+        M, K = x.shape
+        N = w.shape[0]
+        x = x.to(self.device, self.tdtype).contiguous()
+        w = w.to(self.device, torch.float32).contiguous()
+        out = torch.zeros(M, N, dtype=self.tdtype, device=self.device)
+        am = (ctypes.c_int32 * M)()
+        torch.cuda.synchronize(self.device)
+        check(self.ctx, self.lib.rdx_logits_test(self.ctx, _ptr(x), _ptr(w), M, N, N if n_valid is None else n_valid, K, _ptr(out),
+                                                 ctypes.cast(am, ctypes.c_void_p), int(fp8)), "rdx_logits_test")
+        return out, torch.tensor(list(am), dtype=torch.int32)
+
     def classify_findings(self, image: torch.Tensor) -> torch.Tensor:
         """ChexpertClassifier.forward: float32[B,3,S,S] on the device -> float32[B,classes] logits."""
         image = image.to(self.device, torch.float32).contiguous()

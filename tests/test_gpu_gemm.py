@@ -60,6 +60,10 @@ CASES = [
     # 16 < M <= 32 with LDS-staged activations (skinny32.hip): 4-tile and 2-tile workgroups, ragged tile groups, ragged K ranges
     (32, 8208, 512, 3, False, 0), (19, 1040, 4096, 0, False, 0), (32, 2064, 1408, 4, False, 0), (27, 48, 11008, 3, False, 0),
     (32, 16400, 1024, 4, True, 0),
+    # 16 < M <= 32, K = 4096, >= 512 tiles: activation-stationary persistent kernel (xstat32.hip): whole and ragged trips per
+    # workgroup, ragged N, every epilogue
+    (32, 8192, 4096, 0, False, 0), (19, 8208, 4096, 3, False, 0), (32, 22016, 4096, 4, True, 0), (27, 12304, 4096, 0, True, 0),
+    (32, 4096, 4096, 3, False, 0),
 ]
 
 
@@ -111,9 +115,10 @@ def test_fp8_weight_gemv_matches_fake_quantised_fp32(eng, M, N, K, epi, norm):
     assert err < tol, f"max abs err {err} (tol {tol})"
 
 
-@pytest.mark.parametrize("M,N,K,epi,norm", [(32, 8208, 512, 3, False), (20, 16400, 1024, 4, True), (32, 8224, 4096, 0, False)])
+@pytest.mark.parametrize("M,N,K,epi,norm", [(32, 8208, 512, 3, False), (20, 16400, 1024, 4, True), (32, 8224, 4096, 0, False),
+                                            (25, 8208, 4096, 4, False), (32, 12304, 4096, 3, True)])
 def test_fp8_weight_batch32_gemm_matches_fake_quantised_fp32(eng, M, N, K, epi, norm):
-    """fp8 weights through the LDS-staged 16 < M <= 32 kernel (skinny32.hip, W8)."""
+    """fp8 weights through the 16 < M <= 32 kernels (skinny32.hip LDS-staged, xstat32.hip activation-stationary at K = 4096)."""
     dt = DT[eng.dtype]
     x = synth.synth(f"g8.x{M}.{K}", (M, K), -1.0, 1.0).to(dt)
     w = synth.synth(f"g8.w{N}.{K}", (N, K), -0.05, 0.05)
@@ -124,3 +129,28 @@ def test_fp8_weight_batch32_gemm_matches_fake_quantised_fp32(eng, M, N, K, epi, 
     tol = {"f16": 2e-3, "bf16": 1.6e-2}[eng.dtype] * max(1.0, float(ref.abs().max()))
     err = float((out - ref).abs().max())
     assert err < tol, f"max abs err {err} (tol {tol})"
+
+
+@pytest.mark.parametrize("M,N,K,n_valid,fp8", [(1, 2064, 4096, 2049, False), (12, 1040, 512, 1033, False), (32, 8208, 512, 8201, False),
+                                               (32, 8208, 4096, 8201, False), (21, 32016, 4096, 32001, False), (32, 8208, 4096, 8195, True),
+                                               (3, 4112, 4096, 4100, True)])
+def test_lm_head_epilogue_logits_and_greedy_choice(eng, M, N, K, n_valid, fp8):
+    """EPI_LOGITS of every weight-streaming kernel (skinny M <= 16, skinny32, xstat32; bf16/f16 and fp8 weights): logits rounded
+    to the model dtype and argmax over n < n_valid taken ON the rounded values with ties to the lowest index (torch.argmax of
+    the fp16 logits row, GenerationMixin.greedy_search)."""
+    dt = DT[eng.dtype]
+    x = synth.synth(f"lg.x{M}.{K}", (M, K), -1.0, 1.0).to(dt)
+    w = synth.synth(f"lg.w{N}.{K}", (N, K), -0.05, 0.05)
+    out, am = eng.logits_test(x, w, n_valid, fp8)
+    out = out.float().cpu()
+    wr = _fake_quant_e4m3(w) if fp8 else w.to(dt).float()
+    ref = (x.double() @ wr.double().T).float()
+    tol = {"f16": 2e-3, "bf16": 1.6e-2}[eng.dtype] * max(1.0, float(ref.abs().max()))
+    assert float((out[:, :n_valid] - ref[:, :n_valid]).abs().max()) < tol
+    assert float(out[:, n_valid:].abs().max()) == 0.0                      # padded vocab columns are never written
+    # the greedy choice is exactly the argmax of the kernel's own rounded logits (first index on ties) ...
+    assert torch.equal(am.long(), out[:, :n_valid].argmax(dim=1))
+    # ... and equals the fp32 reference's choice whenever that one is decided by more than the tolerance
+    top2 = ref[:, :n_valid].topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 2 * tol
+    assert torch.equal(am.long()[clear], ref[:, :n_valid].argmax(dim=1)[clear])
