@@ -79,6 +79,8 @@ struct rdx_ctx {
     float* part_val = nullptr; int* part_idx = nullptr; int n_vtiles = 0;
     // decode-step activations ([max_batch] rows) and prefill activations (grown on demand)
     void *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dgu = nullptr;
+    float* kslab = nullptr;          // batch 17-32 decode: fp32 partial slabs [<= 4 groups][32][hidden] of a K-split projection
+    int pend_groups = 0;             // launch-time state: slabs written by the last xsplit32 launch, not yet added into dx
     void *px = nullptr, *pxn = nullptr, *pqkv = nullptr, *pq = nullptr, *patt = nullptr, *pgu = nullptr, *pqe = nullptr, *pimg = nullptr;
     size_t prefill_rows = 0;
     int cur_B = 0, cur_T = 0, cur_max_new = 0, cur_eos = -1, cur_pad = 0;
@@ -167,14 +169,43 @@ static void skinny(rdx_ctx* c, GemmArgs a, int epi) {
     if (a.norm_w && !skinny_fits_lds(a.M, a.K)) {
         const void* x = a.X; const void* nw = a.norm_w;
         a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr;
+        // a K-split projection before this one left its residual epilogue to this RMSNorm (xsplit32_k): x += T(sum of slabs)
+        const int pend = (x == c->dx) ? c->pend_groups : 0;
+        if (pend) c->pend_groups = 0;
         if (xstat32_supported(a, epi)) {       // the normalised rows go straight into the consumer's register-fragment order
             a.xpacked = (a.W8 && a.wscale) ? 2 : 1;
-            launch_rmsnorm_packed32(c->cfg.dtype, x, nw, c->dxn, a.M, a.K, a.eps, a.xpacked, c->stream);
+            launch_rmsnorm_packed32(c->cfg.dtype, const_cast<void*>(x), nw, c->dxn, a.M, a.K, a.eps, a.xpacked, pend ? c->kslab : nullptr, pend, c->stream);
+        } else if (pend) {
+            launch_rmsnorm_packed32(c->cfg.dtype, const_cast<void*>(x), nw, c->dxn, a.M, a.K, a.eps, 0, c->kslab, pend, c->stream);
         } else {
             launch_rmsnorm(c->cfg.dtype, x, nw, c->dxn, a.M, a.K, a.eps, c->stream);
         }
     }
     launch_skinny_gemm(c->cfg.dtype, a, epi, c->stream);
+}
+
+// batch 17-32 decode: gate/up (xstat32_k) can hand its SwiGLU output to down_proj fragment-packed, and down_proj then runs
+// K-split over 4 workgroups per tile (xsplit32_k), its residual epilogue deferred to the next RMSNorm
+static bool down_split_ok(rdx_ctx* c, const LlamaLayer& L, int B) {
+    if (B <= 16 || !c->kslab) return false;
+    GemmArgs gu = gargs(c->dxn, c->cfg.hidden, L.wgu, nullptr, c->dgu, c->cfg.inter, B);
+    if ((gu.W8 && gu.wscale) || !xstat32_supported(gu, EPI_SILU_MUL)) return false;
+    GemmArgs dn = gargs(c->dgu, c->cfg.inter, L.wdown, nullptr, c->dx, c->cfg.hidden, B);
+    dn.xpacked = 1;
+    return !(dn.W8 && dn.wscale) && xsplit32_groups(dn) > 0;
+}
+
+static void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split) {
+    const rdx_config& f = c->cfg;
+    GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, f.hidden, B);
+    a.resid = c->dx; a.ldr = f.hidden;
+    if (split) {
+        a.xpacked = 1;
+        launch_xsplit32(f.dtype, a, c->kslab, c->stream);
+        c->pend_groups = xsplit32_groups(a);
+    } else {
+        skinny(c, a, EPI_RESID);
+    }
 }
 
 static void run_gemm(rdx_ctx* c, GemmArgs a, int epi) {
@@ -405,8 +436,9 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         c->n_vtiles = c->lm_head.Npad / 16;
         ALLOC(c, c->part_val, (size_t)B * c->n_vtiles * sizeof(float));
         ALLOC(c, c->part_idx, (size_t)B * c->n_vtiles * sizeof(int));
-        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)(B > 16 ? 32 : B) * H * 2); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
-        ALLOC(c, c->datt, (size_t)B * H * 2); ALLOC(c, c->dgu, (size_t)B * I * 2);
+        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)(B > 16 ? 32 : B) * H * 2);
+        if (B > 16) ALLOC(c, c->kslab, (size_t)4 * 32 * H * sizeof(float)); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
+        ALLOC(c, c->datt, (size_t)B * H * 2); ALLOC(c, c->dgu, (size_t)(B > 16 ? 32 : B) * I * 2);
     }
     if (f.enable_vision) {
         const int H = f.q_hidden, I = f.q_inter;
@@ -825,9 +857,10 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
             launch_decode_roles(dt, ma, l * 5 + 4, std::min((l + 1) * 5 + 1, f.layers * 5), c->mega_occ, s);
             continue;
         }
-        { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps;
+        const bool split = down_split_ok(c, L, B);
+        { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; a.out_packed = split;
           skinny(c, a, EPI_SILU_MUL); }
-        { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; skinny(c, a, EPI_RESID); }
+        launch_down(c, L, B, split);
     }
     lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
 }
@@ -1025,7 +1058,10 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
                 if (what == 1) { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; skinny(c, a, EPI_SILU_MUL); }
                 else if (what == 2) { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps; skinny(c, a, EPI_NONE); }
                 else if (what == 3) { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dqkv, H, B); skinny(c, a, EPI_NONE); }
-                else if (what == 4) { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); skinny(c, a, EPI_NONE); }
+                else if (what == 4) {
+                    if (down_split_ok(c, L, B)) { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); a.xpacked = 1; launch_xsplit32(f.dtype, a, c->kslab, c->stream); }
+                    else { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); skinny(c, a, EPI_NONE); }
+                }
                 else if (what == 6) {   // decode attention at the current slot (re-appends the same KV row: idempotent)
                     DecAttnArgs at;
                     at.d = c->ld; at.qkv = c->dqkv; at.lbq = L.lora_bq; at.lbv = L.lora_bv; at.cos_t = c->rope_cos; at.sin_t = c->rope_sin;
@@ -1071,6 +1107,23 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
     a.resid = resid; a.ldr = N;
     a.norm_w = norm_w; a.eps = eps;
     void* xn = nullptr;
+    if (force == 5) {       // K-split slab path: pack X -> xsplit32_k -> slab combine (+ residual) at the launch boundary; out = resid + T(X W^T)
+        if (epi != EPI_RESID || !resid || M <= 16 || M > 32) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: force 5 needs epi 3 and 16 < M <= 32"); }
+        char* tmp = nullptr;
+        const size_t xb = (size_t)32 * K * 2, sb = (size_t)4 * 32 * N * 4;
+        HIPCHK(c, hipMalloc((void**)&tmp, 2 * xb + sb));
+        launch_rmsnorm_packed32(c->cfg.dtype, const_cast<void*>(X), nullptr, tmp, M, K, eps, 1, nullptr, 0, c->stream);   // w = null: re-layout only
+        a.X = tmp; a.xpacked = 1; a.norm_w = nullptr;
+        const int kg = xsplit32_groups(a);
+        if (!kg) { hipFree(wp); hipFree(tmp); return fail(c, -1, "rdx_gemm_test: shape not supported by xsplit32_k"); }
+        launch_xsplit32(c->cfg.dtype, a, (float*)(tmp + 2 * xb), c->stream);
+        HIPCHK(c, hipMemcpyAsync(out, resid, (size_t)M * N * 2, hipMemcpyDeviceToDevice, c->stream));
+        launch_rmsnorm_packed32(c->cfg.dtype, out, nullptr, tmp + xb, M, N, eps, 0, (const float*)(tmp + 2 * xb), kg, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        hipFree(wp); hipFree(tmp);
+        return 0;
+    }
     const bool use_skinny = force == 1 || (force == 0 && M <= 32);
     if (use_skinny) {
         if (M > 32) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: skinny path needs M <= 32"); }

@@ -103,7 +103,9 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
     auto load_v = [&](int u0, int u1, int limit) {
 #pragma unroll
         for (int u = 0; u < VR; ++u) {
-            if (u >= u0 && u < u1 && u * SPAN + cw * 4 < limit) {
+            // pair granularity: P.V consumes rows (u, u + 1) together whenever row u is inside the context, so the odd row of
+            // a pair is loaded with its even partner (clamped address, P = 0) -- an unloaded register may hold a NaN pattern
+            if (u >= u0 && u < u1 && (u & ~1) * SPAN + cw * 4 < limit) {
                 const int j = min(u * SPAN + cw * 4 + jsub, d.max_len - 1);
                 vr[u] = ldg16(vc + (size_t)j * D + doct * 8);
             }

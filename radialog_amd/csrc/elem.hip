@@ -11,8 +11,8 @@ namespace rdx {
 // elements k = i .. i + 8 of row m are exactly one lane's piece: PACK 1 (32-deep fragments): f = i / 32, g = (i % 32) / 8;
 // PACK 2 (the fp8 weights' 64-deep chunks): f = 2 (i / 64) + (i % 16) / 8, g = (i % 64) / 16. Rows >= n_rows are zero-filled.
 template <typename T, int PACK>
-__global__ __launch_bounds__(256) void rmsnorm_k(const T* __restrict__ x, const T* __restrict__ w, T* __restrict__ out,
-                                                 int H, float eps, int n_rows) {
+__global__ __launch_bounds__(256) void rmsnorm_k(const T* x, const T* __restrict__ w, T* __restrict__ out,
+                                                 int H, float eps, int n_rows, const float* __restrict__ slab, int groups, T* xw) {
     typedef typename Vec8<T>::type V8;
     __shared__ float red[32];
     const size_t row = blockIdx.x;
@@ -29,6 +29,21 @@ __global__ __launch_bounds__(256) void rmsnorm_k(const T* __restrict__ x, const 
     float ss = 0.f;
     for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {
         V8 v = as_vec8<T>(ldg16(xr + i));
+        if (slab) {
+            // pending K-split projection (xsplit32_k): x[row] += T(sum of the groups' fp32 partials, fixed order) -- the residual
+            // epilogue of o_proj / down_proj, done here at the launch boundary; the completed row is written back (same thread
+            // re-reads it below)
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int gq = 0; gq < groups; ++gq) {
+                const float* sp = slab + ((size_t)gq * 32 + row) * H + i;
+                const float4 s0 = *reinterpret_cast<const float4*>(sp), s1 = *reinterpret_cast<const float4*>(sp + 4);
+                acc[0] += s0.x; acc[1] += s0.y; acc[2] += s0.z; acc[3] += s0.w;
+                acc[4] += s1.x; acc[5] += s1.y; acc[6] += s1.z; acc[7] += s1.w;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = fromf<T>(tof<T>(v[j]) + rnd<T>(acc[j]));
+            stg16(xw + row * H + i, as_u4<T>(v));
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float f = tof<T>(v[j]); ss += f * f; }
     }
@@ -36,23 +51,29 @@ __global__ __launch_bounds__(256) void rmsnorm_k(const T* __restrict__ x, const 
     const float rs = rsqrtf(ss / (float)H + eps);
     for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {
         V8 v = as_vec8<T>(ldg16(xr + i));
-        V8 wv = as_vec8<T>(ldg16(w + i));
         V8 o;
+        if (w) {
+            V8 wv = as_vec8<T>(ldg16(w + i));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof<T>(wv[j]) * rnd<T>(tof<T>(v[j]) * rs));
+            for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof<T>(wv[j]) * rnd<T>(tof<T>(v[j]) * rs));
+        } else {
+            o = v;                                  // w == null: re-layout only (test hook)
+        }
         stg16(dst(i), as_u4<T>(o));
     }
 }
 
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s) {
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T, 0>), dim3(rows), dim3(256), 0, s, (const T*)x, (const T*)w,
-                                                (T*)out, H, eps, rows));
+                                                (T*)out, H, eps, rows, (const float*)nullptr, 0, (T*)nullptr));
 }
 
-void launch_rmsnorm_packed32(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, int pack, hipStream_t s) {
+void launch_rmsnorm_packed32(int dtype, void* x, const void* w, void* out, int rows, int H, float eps, int pack, const float* slab,
+                             int groups, hipStream_t s) {
     RDX_DISPATCH_T(dtype, T, {
-        if (pack == 2) hipLaunchKernelGGL((rmsnorm_k<T, 2>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, H, eps, rows);
-        else hipLaunchKernelGGL((rmsnorm_k<T, 1>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, H, eps, rows);
+        if (pack == 2) hipLaunchKernelGGL((rmsnorm_k<T, 2>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, H, eps, rows, slab, groups, (T*)x);
+        else if (pack == 1) hipLaunchKernelGGL((rmsnorm_k<T, 1>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, H, eps, rows, slab, groups, (T*)x);
+        else hipLaunchKernelGGL((rmsnorm_k<T, 0>), dim3(rows), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, H, eps, rows, slab, groups, (T*)x);
     });
 }
 

@@ -29,6 +29,7 @@ struct GemmArgs {
     // fp8 weights (skinny / fused decode paths only): e4m3 bytes in the 64-deep fragment order (gemm.hip) + one fp32 scale per
     // output row; `W` then holds the dequantised model-dtype copy the other kernels use
     const void* W8; const float* wscale;
+    int out_packed;                  // xstat32_k, EPI_SILU_MUL: write the output fragment-packed (input of xsplit32_k)
     int xpacked;                     // xstat32_k: X is the fragment-packed 32-row block written by launch_rmsnorm_packed32 (1 / 2)
     long long* trace;                // debug: [tile][8] timestamps (100 MHz ticks) written by thread 0 of every workgroup (skinny_tile)
 };
@@ -74,6 +75,10 @@ bool skinny32_supported(const GemmArgs& a, int epi);
 void launch_skinny32(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 bool xstat32_supported(const GemmArgs& a, int epi);
 void launch_xstat32(int dtype, const GemmArgs& a, int epi, hipStream_t s);
+// K-split activation-stationary GEMM for the 256-tile projections at 16 < M <= 32: fp32 partial slabs [groups][32][N], combined
+// (+ residual, rounding) by the following RMSNorm (launch_rmsnorm_packed32 with `slab`). groups = 0: shape not supported
+int xsplit32_groups(const GemmArgs& a);
+void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s);
 void launch_tiled_gemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s);
 // LDS-DMA GEMM for plain row-major activations (M > 32, K % 64 == 0); `ws` = fp32 split-K workspace (nullable)
 bool gemm_dma_supported(const GemmArgs& a);
@@ -139,7 +144,9 @@ void launch_decode_roles(int dtype, MegaArgs ma, int R0, int R1, int occ, hipStr
 
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s);
 // rows <= 32 normalised into the 32-row fragment-packed block xstat32_k reads (pack 1: 32-deep fragments, 2: fp8 64-deep order)
-void launch_rmsnorm_packed32(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, int pack, hipStream_t s);
+// slab != null: the rows are first completed as x[row] = x[row] + T(sum over g < groups of slab[g][row][:]) (written back to x)
+void launch_rmsnorm_packed32(int dtype, void* x, const void* w, void* out, int rows, int H, float eps, int pack, const float* slab,
+                             int groups, hipStream_t s);
 void launch_layernorm(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* out_f32,
                       int rows, int H, float eps, hipStream_t s);
 void launch_layernorm_ex(int dtype, const void* x, long ldx, const float* gamma, const float* beta, const void* emb, int emb_rows,

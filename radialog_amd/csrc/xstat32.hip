@@ -11,6 +11,7 @@
 // per wave = 128 KiB per CU in flight, no load ever waits for a barrier). fp8 weights (W8): 8 loads of 64-deep fragments per
 // tile, two tiles per trip so the same 16 KiB stay in flight. Same rounding points / epilogues as skinny32_k.
 #include <type_traits>
+#include <algorithm>
 #include "rdx_common.h"
 #include "rdx_kernels.h"
 #include "skinny_body.h"   // swiglu()
@@ -146,7 +147,13 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
             } else if (EPI == EPI_SILU_MUL) {
                 // rows 0-7 of a tile are gate, 8-15 the matching up rows: the partner sits 8 lanes away in the same DPP row
                 const float u = dpp_mov<DPP_ROR8>(v);
-                if (e_nl < 8 && ok) out[(size_t)e_m * a.ldo + t_o * 8 + e_nl] = fromf<T>(swiglu<T>(v, u));
+                if (a.out_packed) {
+                    // fragment-packed [f = k / 32][mt][lane (g = (k % 32) / 8, r = m % 16)][8] for the K-split consumer (xsplit32_k):
+                    // this tile's 8 outputs k = 8 t_o .. + 8 of row m are one lane's 16-byte piece; rows >= M are zero-filled
+                    if (e_nl < 8 && t_o < ntiles)
+                        out[((size_t)(((t_o >> 2) * 2 + e_mt) * 64 + (t_o & 3) * 16 + (e_idx >> 4)) << 3) + e_nl] =
+                            e_m < a.M ? fromf<T>(swiglu<T>(v, u)) : fromf<T>(0.f);
+                } else if (e_nl < 8 && ok) out[(size_t)e_m * a.ldo + t_o * 8 + e_nl] = fromf<T>(swiglu<T>(v, u));
             } else if (EPI == EPI_LOGITS) {
                 float lv = rnd<T>(v);
                 int li = n;
@@ -179,6 +186,119 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
     XS_T(5);
     if (trc) { trc[6] = nit; trc[7] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }    // HW_REG_XCC_ID
 #undef XS_T
+}
+
+// ---- K-split variant for the 256-tile projections (down: K = 11008, o_proj: K = 4096) ------------------------------------------
+// With N = 4096 there is one tile per CU, and [32][11008] activations do not fit one workgroup's registers. KGN workgroups share
+// a tile: workgroup b is K group kg = b % KGN of tile slot b / KGN, its 8 waves hold the fragments of chunk range
+// [KC s / S, KC (s + 1) / S), s = 8 kg + wave, S = 8 KGN (<= CPW chunks: 10-11 for K = 11008, KGN = 4), and it walks the tiles
+// slot, slot + G / KGN, ... (4 trips of 88 KiB at G = 256). The activations must be fragment-packed (written by the producer's
+// epilogue: xstat32_k's SwiGLU, or rmsnorm_k<T, 1>). Output: the fp32 partial of every K group in its own slab [kg][32][N],
+// plain stores, no in-launch reduction -- the next kernel on the stream is always the RMSNorm of the following projection, and
+// its prologue adds the slabs in kg order, rounds, adds the residual (rmsnorm_k with `slab`): the launch boundary is the sync.
+template <typename T, int KC, int KGN>
+__global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __restrict__ slab) {
+    constexpr int SLOTS = XS_WAVES * KGN, CPW = (KC + SLOTS - 1) / SLOTS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
+    float* red = reinterpret_cast<float*>(smx);       // [2 bufs][8 waves][2 mt][256]
+
+    const int lane = threadIdx.x & 63, wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int ntiles = (a.N + 15) >> 4;
+    const int nts = (int)gridDim.x / KGN, kg = (int)blockIdx.x % KGN, ts = (int)blockIdx.x / KGN;
+    if (ts >= nts) return;
+    const int nit = (ntiles - ts + nts - 1) / nts;
+    if (nit <= 0) return;
+    long long* trc = (a.trace && threadIdx.x == 0) ? a.trace + (size_t)blockIdx.x * 8 : nullptr;
+#define XS_T(i) do { if (trc) trc[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+    XS_T(0);
+    const int slot = kg * XS_WAVES + wa;
+    const int c0 = (KC * slot) / SLOTS, cnt = (KC * (slot + 1)) / SLOTS - c0;      // wave-uniform
+    const u4* wbase = reinterpret_cast<const u4*>(a.W) + (size_t)c0 * 64;
+    auto tile_ptr = [&](int t) { return wbase + (size_t)min(t, ntiles - 1) * KC * 64; };
+
+    u4 ring[CPW];
+    {
+        const u4* wp = tile_ptr(ts);
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            ring[j] = ldg16_nt(wp + (unsigned)(min(j, cnt - 1) * 64 + lane));     // j >= cnt: re-read, multiplied by a zero fragment
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const T* X = reinterpret_cast<const T*>(a.X);
+    u4 xf[2][CPW];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            const u4 v = ldg16(X + ((size_t)(((c0 + min(j, cnt - 1)) * 2 + mt) * 64 + lane) << 3));
+            xf[mt][j] = j < cnt ? v : (u4){0u, 0u, 0u, 0u};
+        }
+    __builtin_amdgcn_sched_barrier(0);
+
+    const int e_mt = threadIdx.x >> 8, e_idx = threadIdx.x & 255, e_m = e_mt * 16 + (e_idx >> 4), e_nl = e_idx & 15;
+    float* sl = slab + ((size_t)kg * 32 + e_m) * a.N;
+
+    auto trip = [&](int it, auto pf_tag) {
+        constexpr bool PF = decltype(pf_tag)::value;
+        const int t_o = ts + it * nts;
+        v4f acc0 = (v4f){0.f, 0.f, 0.f, 0.f}, acc1 = (v4f){0.f, 0.f, 0.f, 0.f};
+        const u4* wn = tile_ptr(t_o + nts);
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+            acc0 = mfma16(as_vec8<T>(ring[j]), as_vec8<T>(xf[0][j]), acc0);
+            acc1 = mfma16(as_vec8<T>(ring[j]), as_vec8<T>(xf[1][j]), acc1);
+            if (PF) ring[j] = ldg16_nt(wn + (unsigned)(min(j, cnt - 1) * 64 + lane));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (it == 0) XS_T(1);
+        if (!PF) XS_T(4);
+        float* rb = red + (size_t)(it & 1) * (XS_WAVES * 2 * 256);
+        *reinterpret_cast<float4*>(&rb[(wa * 2 + 0) * 256 + r * 16 + g * 4]) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
+        *reinterpret_cast<float4*>(&rb[(wa * 2 + 1) * 256 + r * 16 + g * 4]) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
+        __syncthreads();
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < XS_WAVES; ++i) v += rb[(i * 2 + e_mt) * 256 + e_idx];
+        const int n = t_o * 16 + e_nl;
+        if (e_m < a.M && n < a.N) sl[n] = v;
+    };
+    if (nit > 1) {
+        trip(0, std::true_type{});
+        XS_T(2);
+        for (int it = 1; it + 1 < nit; ++it) trip(it, std::true_type{});
+    }
+    XS_T(3);
+    trip(nit - 1, std::false_type{});
+    XS_T(5);
+    if (trc) { trc[6] = nit; trc[7] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
+#undef XS_T
+}
+
+// K groups for this shape (0 = not supported): needs fragment-packed activations and model-dtype weights
+int xsplit32_groups(const GemmArgs& a) {
+    const char* e = getenv("RDX_XSPLIT");                     // 0 = off
+    if (e && atoi(e) == 0) return 0;
+    if (!(a.M > 16 && a.M <= 32) || a.xpacked != 1 || a.norm_w || a.bias || (a.N + 15) / 16 < 128 || (a.N + 15) / 16 > 512) return 0;
+    if (a.K == 11008) return 4;
+    if (a.K == 4096) return 2;
+    return 0;
+}
+
+void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
+    const int kgn = xsplit32_groups(a);
+    const int nt = (a.N + 15) / 16;
+    const size_t smem = (size_t)2 * XS_WAVES * 2 * 256 * 4;
+    RDX_DISPATCH_T(dtype, T, {
+        if (kgn == 4) {
+            const int nts = std::min(nt, 256 / 4);
+            hipLaunchKernelGGL((xsplit32_k<T, 344, 4>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
+        } else if (kgn == 2) {
+            const int nts = std::min(nt, 256 / 2);
+            hipLaunchKernelGGL((xsplit32_k<T, 128, 2>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
+        }
+    });
 }
 
 bool xstat32_supported(const GemmArgs& a, int epi) {

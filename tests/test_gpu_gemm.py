@@ -64,6 +64,10 @@ CASES = [
     # workgroup, ragged N, every epilogue
     (32, 8192, 4096, 0, False, 0), (19, 8208, 4096, 3, False, 0), (32, 22016, 4096, 4, True, 0), (27, 12304, 4096, 0, True, 0),
     (32, 4096, 4096, 3, False, 0),
+    # K-split slab path (xsplit32.hip via force=5): down_proj (K = 11008, 4 groups, ragged chunk ranges) and o_proj (K = 4096, 2 groups)
+    # shapes, ragged M, fewer tiles than tile slots
+    (32, 4096, 11008, 3, False, 5), (21, 4096, 11008, 3, False, 5), (32, 4096, 4096, 3, False, 5), (17, 2048, 4096, 3, False, 5),
+    (32, 8192, 11008, 3, False, 5),
 ]
 
 
