@@ -438,7 +438,7 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         ALLOC(c, c->part_idx, (size_t)B * c->n_vtiles * sizeof(int));
         ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)(B > 16 ? 32 : B) * H * 2);
         if (B > 16) ALLOC(c, c->kslab, (size_t)4 * 32 * H * sizeof(float)); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
-        ALLOC(c, c->datt, (size_t)B * H * 2); ALLOC(c, c->dgu, (size_t)(B > 16 ? 32 : B) * I * 2);
+        ALLOC(c, c->datt, (size_t)(B > 16 ? 32 : B) * H * 2); ALLOC(c, c->dgu, (size_t)(B > 16 ? 32 : B) * I * 2);
     }
     if (f.enable_vision) {
         const int H = f.q_hidden, I = f.q_inter;
@@ -845,8 +845,14 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         } else if (c->fuse_attn_oproj == 1 && (L.wo.N + 15) / 16 <= 256) {
             launch_attn_oproj(dt, at, ao, B, c->d_ctr + (size_t)l * 128, c->d_err, s);
         } else {
+            // batch 17-32: attention writes its output fragment-packed and o_proj runs K-split over two workgroups per tile,
+            // its residual epilogue folded into the RMSNorm in front of gate/up (xsplit32_k)
+            GemmArgs ap = ao; ap.xpacked = 1;
+            const int kg = (B > 16 && c->kslab && !(ao.W8 && ao.wscale)) ? xsplit32_groups(ap) : 0;
+            at.out_packed = kg > 0;
             launch_decode_attention(dt, at, B, s);
-            skinny(c, ao, EPI_RESID);
+            if (kg) { launch_xsplit32(dt, ap, c->kslab, s); c->pend_groups = kg; }
+            else skinny(c, ao, EPI_RESID);
         }
         if (chain && c->chain_mlp == 1) {
             launch_decode_roles(dt, ma, l * 5 + 3, std::min((l + 1) * 5 + 1, f.layers * 5), c->mega_occ, s);
@@ -1057,7 +1063,12 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
                 const LlamaLayer& L = c->ll[same_layer ? 0 : l];
                 if (what == 1) { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; skinny(c, a, EPI_SILU_MUL); }
                 else if (what == 2) { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps; skinny(c, a, EPI_NONE); }
-                else if (what == 3) { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dqkv, H, B); skinny(c, a, EPI_NONE); }
+                else if (what == 3) {
+                    GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dqkv, H, B);
+                    GemmArgs ap = a; ap.xpacked = 1;
+                    if (B > 16 && c->kslab && !(a.W8 && a.wscale) && xsplit32_groups(ap)) launch_xsplit32(f.dtype, ap, c->kslab, c->stream);
+                    else skinny(c, a, EPI_NONE);
+                }
                 else if (what == 4) {
                     if (down_split_ok(c, L, B)) { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); a.xpacked = 1; launch_xsplit32(f.dtype, a, c->kslab, c->stream); }
                     else { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); skinny(c, a, EPI_NONE); }

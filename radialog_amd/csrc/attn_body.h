@@ -340,7 +340,11 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
             float v = 0.f;
 #pragma unroll
             for (int i = 0; i < WAVES; ++i) v += part[i * D + tid];
-            reinterpret_cast<T*>(a.out)[(size_t)b * H + h * D + tid] = fromf<T>(v);
+            const int k = h * D + tid;
+            // out_packed: the 32-row fragment-packed block the K-split o_proj reads (xsplit32_k): [k / 32][b / 16][(k % 32) / 8][b % 16][8]
+            const size_t o = a.out_packed ? ((size_t)((((k >> 5) * 2 + (b >> 4)) * 64 + ((k & 31) >> 3) * 16 + (b & 15))) << 3) + (k & 7)
+                                          : (size_t)b * H + k;
+            reinterpret_cast<T*>(a.out)[o] = fromf<T>(v);
         }
     } else if (tid < D / 4) {                                  // write-through 8-byte stores (4 dims per lane)
         unsigned long long pk = 0ull;

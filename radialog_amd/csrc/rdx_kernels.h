@@ -103,6 +103,7 @@ struct DecAttnArgs {
     const uint8_t* key_mask;
     void *kcache, *vcache, *out;
     long long* trace = nullptr;      // debug: 8 timestamps (100 MHz ticks) of workgroup (b=0,h=0)
+    int out_packed = 0;              // stand-alone launches, batch 17-32: write `out` fragment-packed for xsplit32_k (attn_body.h)
 };
 void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s);
 // decode attention + o_proj(+residual) in ONE launch: the o_proj tile workgroups put their weights in flight
