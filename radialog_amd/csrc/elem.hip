@@ -68,8 +68,80 @@ void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows
                                                 (T*)out, H, eps, rows, (const float*)nullptr, 0, (T*)nullptr));
 }
 
+// One-round-trip version for H = 4096 (decode at batch 17-32: two of these per layer sit on the step's critical path): a
+// thread owns 2 x 8 elements, every load (row, slabs, norm weight) is issued up front, the row stays in registers between the
+// statistics and the scaling. Same arithmetic and rounding points as rmsnorm_k.
+template <typename T, int PACK>
+__global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __restrict__ w, T* __restrict__ out, float eps, int n_rows,
+                                                     const float* __restrict__ slab, int groups, T* xw) {
+    typedef typename Vec8<T>::type V8;
+    constexpr int H = 4096;
+    __shared__ float red[32];
+    const size_t row = blockIdx.x;
+    auto dst = [&](int i) -> T* {
+        if (PACK == 0) return out + row * H + i;
+        const int f = PACK == 1 ? (i >> 5) : (2 * (i >> 6) + ((i & 15) >> 3)), g = PACK == 1 ? ((i & 31) >> 3) : ((i & 63) >> 4);
+        return out + ((size_t)((f * 2 + (int)(row >> 4)) * 64 + g * 16 + (int)(row & 15)) << 3);
+    };
+    const int i0 = threadIdx.x * 8, i1 = i0 + 2048;
+    if (PACK && (int)row >= n_rows) {
+        stg16(dst(i0), (u4){0u, 0u, 0u, 0u});
+        stg16(dst(i1), (u4){0u, 0u, 0u, 0u});
+        return;
+    }
+    const T* xr = x + row * H;
+    V8 v[2] = {as_vec8<T>(ldg16(xr + i0)), as_vec8<T>(ldg16(xr + i1))};
+    const V8 wv[2] = {as_vec8<T>(ldg16(w + i0)), as_vec8<T>(ldg16(w + i1))};
+    if (slab) {
+        float4 sp[4][2][2];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float* p = slab + ((size_t)min(gq, groups - 1) * 32 + row) * H + (k ? i1 : i0);
+                sp[gq][k][0] = *reinterpret_cast<const float4*>(p);
+                sp[gq][k][1] = *reinterpret_cast<const float4*>(p + 4);
+            }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq)
+                if (gq < groups) {
+                    acc[0] += sp[gq][k][0].x; acc[1] += sp[gq][k][0].y; acc[2] += sp[gq][k][0].z; acc[3] += sp[gq][k][0].w;
+                    acc[4] += sp[gq][k][1].x; acc[5] += sp[gq][k][1].y; acc[6] += sp[gq][k][1].z; acc[7] += sp[gq][k][1].w;
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[k][j] = fromf<T>(tof<T>(v[k][j]) + rnd<T>(acc[j]));
+            stg16(xw + row * H + (k ? i1 : i0), as_u4<T>(v[k]));
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float f = tof<T>(v[k][j]); ss += f * f; }
+    ss = block_sum(ss, red);
+    const float rs = rsqrtf(ss / (float)H + eps);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        V8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof<T>(wv[k][j]) * rnd<T>(tof<T>(v[k][j]) * rs));
+        stg16(dst(k ? i1 : i0), as_u4<T>(o));
+    }
+}
+
 void launch_rmsnorm_packed32(int dtype, void* x, const void* w, void* out, int rows, int H, float eps, int pack, const float* slab,
                              int groups, hipStream_t s) {
+    if (H == 4096 && w && groups <= 4) {
+        RDX_DISPATCH_T(dtype, T, {
+            if (pack == 2) hipLaunchKernelGGL((rmsnorm4096_k<T, 2>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, eps, rows, slab, groups, (T*)x);
+            else if (pack == 1) hipLaunchKernelGGL((rmsnorm4096_k<T, 1>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, eps, rows, slab, groups, (T*)x);
+            else hipLaunchKernelGGL((rmsnorm4096_k<T, 0>), dim3(rows), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, eps, rows, slab, groups, (T*)x);
+        });
+        return;
+    }
     RDX_DISPATCH_T(dtype, T, {
         if (pack == 2) hipLaunchKernelGGL((rmsnorm_k<T, 2>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, H, eps, rows, slab, groups, (T*)x);
         else if (pack == 1) hipLaunchKernelGGL((rmsnorm_k<T, 1>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, H, eps, rows, slab, groups, (T*)x);
