@@ -189,10 +189,10 @@ static void skinny(rdx_ctx* c, GemmArgs a, int epi) {
 static bool down_split_ok(rdx_ctx* c, const LlamaLayer& L, int B) {
     if (B <= 16 || !c->kslab) return false;
     GemmArgs gu = gargs(c->dxn, c->cfg.hidden, L.wgu, nullptr, c->dgu, c->cfg.inter, B);
-    if ((gu.W8 && gu.wscale) || !xstat32_supported(gu, EPI_SILU_MUL)) return false;
+    if (!xstat32_supported(gu, EPI_SILU_MUL)) return false;
     GemmArgs dn = gargs(c->dgu, c->cfg.inter, L.wdown, nullptr, c->dx, c->cfg.hidden, B);
-    dn.xpacked = 1;
-    return !(dn.W8 && dn.wscale) && xsplit32_groups(dn) > 0;
+    dn.xpacked = (dn.W8 && dn.wscale) ? 2 : 1;       // fp8 weights: the 64-deep fragment order
+    return xsplit32_groups(dn) > 0;
 }
 
 static void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split) {
@@ -200,7 +200,7 @@ static void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split) {
     GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, f.hidden, B);
     a.resid = c->dx; a.ldr = f.hidden;
     if (split) {
-        a.xpacked = 1;
+        a.xpacked = (a.W8 && a.wscale) ? 2 : 1;
         launch_xsplit32(f.dtype, a, c->kslab, c->stream);
         c->pend_groups = xsplit32_groups(a);
     } else {
@@ -847,9 +847,9 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         } else {
             // batch 17-32: attention writes its output fragment-packed and o_proj runs K-split over two workgroups per tile,
             // its residual epilogue folded into the RMSNorm in front of gate/up (xsplit32_k)
-            GemmArgs ap = ao; ap.xpacked = 1;
-            const int kg = (B > 16 && c->kslab && !(ao.W8 && ao.wscale)) ? xsplit32_groups(ap) : 0;
-            at.out_packed = kg > 0;
+            GemmArgs ap = ao; ap.xpacked = (ao.W8 && ao.wscale) ? 2 : 1;
+            const int kg = (B > 16 && c->kslab) ? xsplit32_groups(ap) : 0;
+            at.out_packed = kg > 0 ? ap.xpacked : 0;
             launch_decode_attention(dt, at, B, s);
             if (kg) { launch_xsplit32(dt, ap, c->kslab, s); c->pend_groups = kg; }
             else skinny(c, ao, EPI_RESID);
@@ -864,7 +864,8 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
             continue;
         }
         const bool split = down_split_ok(c, L, B);
-        { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; a.out_packed = split;
+        { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps;
+          a.out_packed = split ? ((L.wdown.w8 && L.wdown.scale) ? 2 : 1) : 0;
           skinny(c, a, EPI_SILU_MUL); }
         launch_down(c, L, B, split);
     }
@@ -1065,12 +1066,12 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
                 else if (what == 2) { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps; skinny(c, a, EPI_NONE); }
                 else if (what == 3) {
                     GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dqkv, H, B);
-                    GemmArgs ap = a; ap.xpacked = 1;
-                    if (B > 16 && c->kslab && !(a.W8 && a.wscale) && xsplit32_groups(ap)) launch_xsplit32(f.dtype, ap, c->kslab, c->stream);
+                    GemmArgs ap = a; ap.xpacked = (a.W8 && a.wscale) ? 2 : 1;
+                    if (B > 16 && c->kslab && xsplit32_groups(ap)) launch_xsplit32(f.dtype, ap, c->kslab, c->stream);
                     else skinny(c, a, EPI_NONE);
                 }
                 else if (what == 4) {
-                    if (down_split_ok(c, L, B)) { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); a.xpacked = 1; launch_xsplit32(f.dtype, a, c->kslab, c->stream); }
+                    if (down_split_ok(c, L, B)) { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); a.xpacked = (a.W8 && a.wscale) ? 2 : 1; launch_xsplit32(f.dtype, a, c->kslab, c->stream); }
                     else { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); skinny(c, a, EPI_NONE); }
                 }
                 else if (what == 6) {   // decode attention at the current slot (re-appends the same KV row: idempotent)
@@ -1118,13 +1119,24 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
     a.resid = resid; a.ldr = N;
     a.norm_w = norm_w; a.eps = eps;
     void* xn = nullptr;
+    bool split8 = false;
+    if (force == 6) {       // force 5 with fp8 weights
+        if (K % 64) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: fp8 needs K %% 64 == 0"); }
+        hipFree(wp);
+        HIPCHK(c, hipMalloc(&wp, (size_t)N * K * 3 + (size_t)N * 4));
+        w.w = wp; w.w8 = (char*)wp + (size_t)N * K * 2; w.scale = (float*)((char*)wp + (size_t)N * K * 3);
+        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, wp, N, K, N, c->stream);
+        a = gargs(X, K, w, bias, out, N, M);
+        a.resid = resid; a.ldr = N; a.eps = eps;
+        split8 = true; force = 5;
+    }
     if (force == 5) {       // K-split slab path: pack X -> xsplit32_k -> slab combine (+ residual) at the launch boundary; out = resid + T(X W^T)
         if (epi != EPI_RESID || !resid || M <= 16 || M > 32) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: force 5 needs epi 3 and 16 < M <= 32"); }
         char* tmp = nullptr;
         const size_t xb = (size_t)32 * K * 2, sb = (size_t)4 * 32 * N * 4;
         HIPCHK(c, hipMalloc((void**)&tmp, 2 * xb + sb));
-        launch_rmsnorm_packed32(c->cfg.dtype, const_cast<void*>(X), nullptr, tmp, M, K, eps, 1, nullptr, 0, c->stream);   // w = null: re-layout only
-        a.X = tmp; a.xpacked = 1; a.norm_w = nullptr;
+        launch_rmsnorm_packed32(c->cfg.dtype, const_cast<void*>(X), nullptr, tmp, M, K, eps, split8 ? 2 : 1, nullptr, 0, c->stream);   // w = null: re-layout only
+        a.X = tmp; a.xpacked = split8 ? 2 : 1; a.norm_w = nullptr;
         const int kg = xsplit32_groups(a);
         if (!kg) { hipFree(wp); hipFree(tmp); return fail(c, -1, "rdx_gemm_test: shape not supported by xsplit32_k"); }
         launch_xsplit32(c->cfg.dtype, a, (float*)(tmp + 2 * xb), c->stream);

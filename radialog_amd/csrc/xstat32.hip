@@ -150,8 +150,10 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
                 if (a.out_packed) {
                     // fragment-packed [f = k / 32][mt][lane (g = (k % 32) / 8, r = m % 16)][8] for the K-split consumer (xsplit32_k):
                     // this tile's 8 outputs k = 8 t_o .. + 8 of row m are one lane's 16-byte piece; rows >= M are zero-filled
+                    // (out_packed 2, fp8 consumer: the 64-deep order -- piece t_o is fragment 2 (t_o / 8) + (t_o & 1), g = (t_o & 7) / 2)
+                    const int pf = a.out_packed == 2 ? 2 * (t_o >> 3) + (t_o & 1) : (t_o >> 2), pg = a.out_packed == 2 ? ((t_o & 7) >> 1) : (t_o & 3);
                     if (e_nl < 8 && t_o < ntiles)
-                        out[((size_t)(((t_o >> 2) * 2 + e_mt) * 64 + (t_o & 3) * 16 + (e_idx >> 4)) << 3) + e_nl] =
+                        out[((size_t)((pf * 2 + e_mt) * 64 + pg * 16 + (e_idx >> 4)) << 3) + e_nl] =
                             e_m < a.M ? fromf<T>(swiglu<T>(v, u)) : fromf<T>(0.f);
                 } else if (e_nl < 8 && ok) out[(size_t)e_m * a.ldo + t_o * 8 + e_nl] = fromf<T>(swiglu<T>(v, u));
             } else if (EPI == EPI_LOGITS) {
@@ -196,44 +198,49 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
 // epilogue: xstat32_k's SwiGLU, or rmsnorm_k<T, 1>). Output: the fp32 partial of every K group in its own slab [kg][32][N],
 // plain stores, no in-launch reduction -- the next kernel on the stream is always the RMSNorm of the following projection, and
 // its prologue adds the slabs in kg order, rounds, adds the residual (rmsnorm_k with `slab`): the launch boundary is the sync.
-template <typename T, int KC, int KGN>
+// fp8 weights (W8): KC counts 64-deep chunks, one 16-byte load feeds two MFMAs per row tile, the activations are packed in the
+// 64-deep order (PACK 2), the per-row scale is applied to the partial; two tiles per trip (TPI) keep 8-12 KiB per wave in flight.
+template <typename T, int KC, int KGN, bool W8, int TPI>
 __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __restrict__ slab) {
-    constexpr int SLOTS = XS_WAVES * KGN, CPW = (KC + SLOTS - 1) / SLOTS;
+    constexpr int SLOTS = XS_WAVES * KGN, CPW = (KC + SLOTS - 1) / SLOTS, FPL = W8 ? 2 : 1;   // fragments (MFMAs per row tile) per load
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
-    float* red = reinterpret_cast<float*>(smx);       // [2 bufs][8 waves][2 mt][256]
+    float* red = reinterpret_cast<float*>(smx);       // [2 bufs][TPI][8 waves][2 mt][256]
 
     const int lane = threadIdx.x & 63, wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int ntiles = (a.N + 15) >> 4;
     const int nts = (int)gridDim.x / KGN, kg = (int)blockIdx.x % KGN, ts = (int)blockIdx.x / KGN;
     if (ts >= nts) return;
-    const int nit = (ntiles - ts + nts - 1) / nts;
+    const int ntl = (ntiles - ts + nts - 1) / nts;    // tiles of this workgroup: ts, ts + nts, ...
+    const int nit = (ntl + TPI - 1) / TPI;
     if (nit <= 0) return;
     long long* trc = (a.trace && threadIdx.x == 0) ? a.trace + (size_t)blockIdx.x * 8 : nullptr;
 #define XS_T(i) do { if (trc) trc[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
     XS_T(0);
     const int slot = kg * XS_WAVES + wa;
     const int c0 = (KC * slot) / SLOTS, cnt = (KC * (slot + 1)) / SLOTS - c0;      // wave-uniform
-    const u4* wbase = reinterpret_cast<const u4*>(a.W) + (size_t)c0 * 64;
+    const u4* wbase = reinterpret_cast<const u4*>(W8 ? a.W8 : a.W) + (size_t)c0 * 64;
     auto tile_ptr = [&](int t) { return wbase + (size_t)min(t, ntiles - 1) * KC * 64; };
 
-    u4 ring[CPW];
-    {
-        const u4* wp = tile_ptr(ts);
+    u4 ring[TPI][CPW];
+#pragma unroll
+    for (int q = 0; q < TPI; ++q) {
+        const u4* wp = tile_ptr(ts + q * nts);
 #pragma unroll
         for (int j = 0; j < CPW; ++j) {
-            ring[j] = ldg16_nt(wp + (unsigned)(min(j, cnt - 1) * 64 + lane));     // j >= cnt: re-read, multiplied by a zero fragment
+            ring[q][j] = ldg16_nt(wp + (unsigned)(min(j, cnt - 1) * 64 + lane));     // j >= cnt: re-read, multiplied by a zero fragment
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     const T* X = reinterpret_cast<const T*>(a.X);
-    u4 xf[2][CPW];
+    u4 xf[2][CPW * FPL];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            const u4 v = ldg16(X + ((size_t)(((c0 + min(j, cnt - 1)) * 2 + mt) * 64 + lane) << 3));
-            xf[mt][j] = j < cnt ? v : (u4){0u, 0u, 0u, 0u};
+        for (int j = 0; j < CPW * FPL; ++j) {
+            const int f = (c0 + min(j / FPL, cnt - 1)) * FPL + (j % FPL);          // packed fragment index (32-deep, or 2 per 64-deep chunk)
+            const u4 v = ldg16(X + ((size_t)((f * 2 + mt) * 64 + lane) << 3));
+            xf[mt][j] = (j / FPL) < cnt ? v : (u4){0u, 0u, 0u, 0u};
         }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -242,27 +249,51 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 
     auto trip = [&](int it, auto pf_tag) {
         constexpr bool PF = decltype(pf_tag)::value;
-        const int t_o = ts + it * nts;
-        v4f acc0 = (v4f){0.f, 0.f, 0.f, 0.f}, acc1 = (v4f){0.f, 0.f, 0.f, 0.f};
-        const u4* wn = tile_ptr(t_o + nts);
+        float e_sc[TPI];
 #pragma unroll
-        for (int j = 0; j < CPW; ++j) {
-            acc0 = mfma16(as_vec8<T>(ring[j]), as_vec8<T>(xf[0][j]), acc0);
-            acc1 = mfma16(as_vec8<T>(ring[j]), as_vec8<T>(xf[1][j]), acc1);
-            if (PF) ring[j] = ldg16_nt(wn + (unsigned)(min(j, cnt - 1) * 64 + lane));
-            __builtin_amdgcn_sched_barrier(0);
+        for (int q = 0; q < TPI; ++q) e_sc[q] = W8 ? a.wscale[min((ts + (it * TPI + q) * nts) * 16 + e_nl, ntiles * 16 - 1)] : 1.f;
+        v4f acc[TPI][2];
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) {
+            acc[q][0] = (v4f){0.f, 0.f, 0.f, 0.f};
+            acc[q][1] = (v4f){0.f, 0.f, 0.f, 0.f};
+            const u4* wn = tile_ptr(ts + ((it + 1) * TPI + q) * nts);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                const u4 wv = ring[q][j];
+                if (W8) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const u4 wd = dequant8<T>(h ? wv.z : wv.x, h ? wv.w : wv.y);
+                        acc[q][0] = mfma16(as_vec8<T>(wd), as_vec8<T>(xf[0][2 * j + h]), acc[q][0]);
+                        acc[q][1] = mfma16(as_vec8<T>(wd), as_vec8<T>(xf[1][2 * j + h]), acc[q][1]);
+                    }
+                } else {
+                    acc[q][0] = mfma16(as_vec8<T>(wv), as_vec8<T>(xf[0][j]), acc[q][0]);
+                    acc[q][1] = mfma16(as_vec8<T>(wv), as_vec8<T>(xf[1][j]), acc[q][1]);
+                }
+                if (PF) ring[q][j] = ldg16_nt(wn + (unsigned)(min(j, cnt - 1) * 64 + lane));
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         if (it == 0) XS_T(1);
         if (!PF) XS_T(4);
-        float* rb = red + (size_t)(it & 1) * (XS_WAVES * 2 * 256);
-        *reinterpret_cast<float4*>(&rb[(wa * 2 + 0) * 256 + r * 16 + g * 4]) = make_float4(acc0[0], acc0[1], acc0[2], acc0[3]);
-        *reinterpret_cast<float4*>(&rb[(wa * 2 + 1) * 256 + r * 16 + g * 4]) = make_float4(acc1[0], acc1[1], acc1[2], acc1[3]);
-        __syncthreads();
-        float v = 0.f;
+        float* rb = red + (size_t)(it & 1) * (TPI * XS_WAVES * 2 * 256);
 #pragma unroll
-        for (int i = 0; i < XS_WAVES; ++i) v += rb[(i * 2 + e_mt) * 256 + e_idx];
-        const int n = t_o * 16 + e_nl;
-        if (e_m < a.M && n < a.N) sl[n] = v;
+        for (int q = 0; q < TPI; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                *reinterpret_cast<float4*>(&rb[((q * XS_WAVES + wa) * 2 + mt) * 256 + r * 16 + g * 4]) =
+                    make_float4(acc[q][mt][0], acc[q][mt][1], acc[q][mt][2], acc[q][mt][3]);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < TPI; ++q) {
+            float v = 0.f;
+#pragma unroll
+            for (int i = 0; i < XS_WAVES; ++i) v += rb[((q * XS_WAVES + i) * 2 + e_mt) * 256 + e_idx];
+            const int tl = it * TPI + q, n = (ts + tl * nts) * 16 + e_nl;
+            if (tl < ntl && e_m < a.M && n < a.N) sl[n] = v * e_sc[q];
+        }
     };
     if (nit > 1) {
         trip(0, std::true_type{});
@@ -276,11 +307,12 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 #undef XS_T
 }
 
-// K groups for this shape (0 = not supported): needs fragment-packed activations and model-dtype weights
+// K groups for this shape (0 = not supported): needs fragment-packed activations (xpacked 1; 2 = the fp8 64-deep order)
 int xsplit32_groups(const GemmArgs& a) {
     const char* e = getenv("RDX_XSPLIT");                     // 0 = off
     if (e && atoi(e) == 0) return 0;
-    if (!(a.M > 16 && a.M <= 32) || a.xpacked != 1 || a.norm_w || a.bias || (a.N + 15) / 16 < 128 || (a.N + 15) / 16 > 512) return 0;
+    const bool w8 = a.W8 && a.wscale;
+    if (!(a.M > 16 && a.M <= 32) || a.xpacked != (w8 ? 2 : 1) || a.norm_w || a.bias || (a.N + 15) / 16 < 128 || (a.N + 15) / 16 > 512) return 0;
     if (a.K == 11008) return 4;
     if (a.K == 4096) return 2;
     return 0;
@@ -289,14 +321,17 @@ int xsplit32_groups(const GemmArgs& a) {
 void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
     const int kgn = xsplit32_groups(a);
     const int nt = (a.N + 15) / 16;
-    const size_t smem = (size_t)2 * XS_WAVES * 2 * 256 * 4;
+    const bool w8 = a.W8 && a.wscale;
+    const size_t smem = (size_t)2 * (w8 ? 2 : 1) * XS_WAVES * 2 * 256 * 4;
     RDX_DISPATCH_T(dtype, T, {
         if (kgn == 4) {
             const int nts = std::min(nt, 256 / 4);
-            hipLaunchKernelGGL((xsplit32_k<T, 344, 4>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
+            if (w8) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
+            else hipLaunchKernelGGL((xsplit32_k<T, 344, 4, false, 1>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
         } else if (kgn == 2) {
             const int nts = std::min(nt, 256 / 2);
-            hipLaunchKernelGGL((xsplit32_k<T, 128, 2>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
+            if (w8) hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
+            else hipLaunchKernelGGL((xsplit32_k<T, 128, 2, false, 1>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
         }
     });
 }

@@ -119,16 +119,19 @@ def test_fp8_weight_gemv_matches_fake_quantised_fp32(eng, M, N, K, epi, norm):
     assert err < tol, f"max abs err {err} (tol {tol})"
 
 
-@pytest.mark.parametrize("M,N,K,epi,norm", [(32, 8208, 512, 3, False), (20, 16400, 1024, 4, True), (32, 8224, 4096, 0, False),
-                                            (25, 8208, 4096, 4, False), (32, 12304, 4096, 3, True)])
-def test_fp8_weight_batch32_gemm_matches_fake_quantised_fp32(eng, M, N, K, epi, norm):
-    """fp8 weights through the 16 < M <= 32 kernels (skinny32.hip LDS-staged, xstat32.hip activation-stationary at K = 4096)."""
+@pytest.mark.parametrize("M,N,K,epi,norm,force", [(32, 8208, 512, 3, False, 4), (20, 16400, 1024, 4, True, 4), (32, 8224, 4096, 0, False, 4),
+                                                  (25, 8208, 4096, 4, False, 4), (32, 12304, 4096, 3, True, 4),
+                                                  # K-split slab path with fp8 weights (force 6): down_proj and o_proj shapes
+                                                  (32, 4096, 11008, 3, False, 6), (19, 4096, 4096, 3, False, 6), (32, 2048, 11008, 3, False, 6)])
+def test_fp8_weight_batch32_gemm_matches_fake_quantised_fp32(eng, M, N, K, epi, norm, force):
+    """fp8 weights through the 16 < M <= 32 kernels (skinny32.hip LDS-staged, xstat32.hip activation-stationary at K = 4096,
+    xsplit32_k K-split with the slab combine)."""
     dt = DT[eng.dtype]
     x = synth.synth(f"g8.x{M}.{K}", (M, K), -1.0, 1.0).to(dt)
     w = synth.synth(f"g8.w{N}.{K}", (N, K), -0.05, 0.05)
     resid = synth.synth(f"g8.r{M}.{N}", (M, N), -1.0, 1.0).to(dt) if epi == 3 else None
     nw = synth.synth(f"g8.n{K}", (K,), 0.8, 1.2).to(dt) if norm else None
-    out = eng.gemm_test(x, w, None, resid, epi, nw, 1e-6, 4).float().cpu()
+    out = eng.gemm_test(x, w, None, resid, epi, nw, 1e-6, force).float().cpu()
     ref = _ref(x, _fake_quant_e4m3(w), None, resid, epi, nw, 1e-6, dt, wdt=torch.float32).float()
     tol = {"f16": 2e-3, "bf16": 1.6e-2}[eng.dtype] * max(1.0, float(ref.abs().max()))
     err = float((out - ref).abs().max())
