@@ -49,14 +49,14 @@ def pmc_traffic(batch, dtype, fp8=False):
     """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
     passes, gfx950 read-side doubling): measured offline because counters cannot be read from inside the timed process;
     the summary lives in profiles/r01_pmc_hbm_traffic.md and its machine-readable twin profiles/r01_pmc.json.
-    Only valid for the configurations it was measured on (batch 1, bf16, with or without fp8 weights) -> null otherwise."""
-    if batch != 1 or dtype != "bf16":
+    Only valid for the configurations it was measured on (bf16: batch 1 with or without fp8 weights, batch 32) -> null otherwise."""
+    if batch not in (1, 32) or dtype != "bf16" or (batch == 32 and fp8):
         return None
     try:
         with open(os.path.join(REPO, "profiles", "r01_pmc.json")) as f:
             d = json.load(f)
         for k, v in d.items():
-            if ("W8" in k) == bool(fp8):
+            if ("W8" in k) == bool(fp8) and (f"B={batch}," in k):
                 return v["traffic_bytes"]
         return None
     except Exception:
@@ -217,9 +217,11 @@ def main():
         def wbytes(n_rows, k):        # bytes per streamed weight element of a decode projection (mirrors the library's dispatch)
             if not args.fp8:
                 return 2
+            tiles = (n_rows + 15) // 16
             lds = B <= 16 and B * k * 2 <= 32 * 1024                     # batch-1..4 GEMV with LDS-staged activations
-            s32 = 16 < B <= 32 and (n_rows + 15) // 16 > 512 and k % 512 == 0    # skinny32.hip
-            return 1 if (lds or s32) else 2
+            s32 = 16 < B <= 32 and tiles > 512 and k % 512 == 0          # skinny32.hip
+            xs = 16 < B <= 32 and ((tiles >= 512 and k == 4096) or (128 <= tiles <= 512 and k in (4096, 11008)))   # xstat32.hip
+            return 1 if (lds or s32 or xs) else 2
         wb = wbytes(2 * lc.inter, lc.hidden)
         gu_bytes = 2 * lc.inter * lc.hidden * wb + B * lc.hidden * 2 + lc.hidden * 2 + B * lc.inter * 2
         # whole-decode average: one report minus its encode and its prefill (+ first token), over the N-1 graph-replayed steps
@@ -237,7 +239,8 @@ def main():
         step_bytes = (32 * (3 * H_ * H_ * wbytes(3 * H_ + 16, H_) + H_ * H_ * wbytes(H_, H_) + 2 * I_ * H_ * wbytes(2 * I_, H_)
                             + H_ * I_ * wbytes(H_, I_)) + lc.vocab * H_ * wbytes(lc.vocab, H_) + (32 * 2 * H_ + H_) * 2)
         roof = {
-            "bound": "hbm", "kernel": f"skinny_gemm_k<{args.dtype},MT,EPI_SILU_MUL,NORM{',W8' if wb == 1 else ''}> (gate/up SwiGLU GEMV)",
+            "bound": "hbm", "kernel": (f"xstat32_k<{args.dtype},EPI_SILU_MUL{',W8' if wb == 1 else ''}> (gate/up SwiGLU, activation-stationary batch-32 GEMM)" if B > 16 else
+                                       f"skinny_gemm_k<{args.dtype},MT,EPI_SILU_MUL,NORM{',W8' if wb == 1 else ''}> (gate/up SwiGLU GEMV)"),
             "achieved": gu_bytes / (gu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(B, args.dtype, args.fp8),
             "bytes_per_launch": gu_bytes, "us_per_launch": gu_ms * 1e3,
