@@ -359,6 +359,41 @@ def test_long_context_decode_streams_past_the_register_window(cfg, cpu_w, B, tp,
         eng.close()
 
 
+@pytest.mark.parametrize("tp,lens", [(1, (47, 48, 49, 64, 65, 96, 97, 112, 113, 128, 129)),
+                                     (0, (60, 61, 120, 121, 240, 241, 300, 301, 420, 421, 480, 481))])
+def test_decode_attention_context_lengths_around_the_register_window_edges(cfg, cpu_w, tp, lens, monkeypatch):
+    """Context lengths on either side of every boundary of the register window: the halves (loaded unconditionally / once
+    `slot` is known), the V row pairs P.V consumes together (16 positions apart in the 4-wave variant, 60 in the 16-wave
+    one -- an unloaded odd row of a pair once produced NaN x 0), the window end where the tail loops take over. Three
+    decode steps from each prompt length, both attention variants, logits and tokens against the oracle."""
+    from oracle import ref_cpu
+    if tp:
+        monkeypatch.setenv("RDX_ATT_TP", "1")
+    from radialog_amd.engine import RdxEngine, synth_getter
+    B, N = 2, 4
+    for dtype in ("f16", "bf16"):
+        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=512, lora=True, vision=False)
+        eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+        oracle = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True)
+        tol = LOGIT_TOL[dtype]
+        for T in lens:
+            ids = _prompt(cfg, B, T, seed=100 + T)
+            qf = synth.synth(f"t.qfw{T}", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+            with torch.no_grad():
+                ref = oracle.generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
+            toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=False)
+            assert not torch.isnan(scores.float()).any(), f"{dtype} T={T}: NaN logits"
+            toks = toks.cpu().long()
+            for b in range(B):
+                for s in range(N):
+                    if toks[b, s] != ref["tokens"][b, s]:
+                        assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} T={T} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
+                        break
+                    err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
+                    assert float(err) < tol, f"{dtype} T={T} row {b} step {s}: logits differ by {float(err)}"
+        eng.close()
+
+
 def _fake_quant_rows(w):
     absmax = w.abs().amax(dim=1, keepdim=True).float()
     inv = torch.where(absmax > 0, 448.0 / absmax, torch.ones_like(absmax))
