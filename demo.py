@@ -67,6 +67,7 @@ def init_vicuna(args):
                                                   device_map="auto", max_batch=1, max_len=1024)
     if args.lora_model:
         lang_model.load_adapter(args.lora_model)
+    lang_model.reuse_prefix_kv = True       # chat turns re-send the whole conversation: keep the KV rows of the shared token prefix
     return lang_model.eval(), tok
 
 

@@ -99,6 +99,17 @@ int rdx_prefill(rdx_ctx* ctx, const int32_t* ids, const int32_t* mask, int batch
                 int max_new, int eos_id, int pad_id, int32_t* out_tokens, void* logits);
 int rdx_decode_step(rdx_ctx* ctx, void* logits);
 
+/* Multi-turn re-prompting (test.py:440-674, demo.py:277-305: the reference re-runs the whole conversation each turn). The
+ * next turn's prompt usually starts with the previous prompt + answer; its KV rows are still in the cache. These calls keep the
+ * first keep_len cache slots of every row (keep_len <= cached positions = previous T + tokens consumed; the caller compares
+ * token ids: radialog_amd LlamaForCausalLM.generate does) and run only ids_tail int32[B,T_tail] (no padding, no <IMG>
+ * splice) behind them: positions, causal mask and logits are those of the full sequence. Same outputs as rdx_prefill /
+ * rdx_generate. */
+int rdx_prefill_append(rdx_ctx* ctx, const int32_t* ids_tail, int batch, int T_tail, int keep_len, int max_new, int eos_id,
+                       int pad_id, int32_t* out_tokens, void* logits);
+int rdx_generate_append(rdx_ctx* ctx, const int32_t* ids_tail, int batch, int T_tail, int keep_len, int max_new, int eos_id,
+                        int pad_id, int32_t* out_tokens, void* scores, int* n_steps_host, int use_graph);
+
 /* introspection for tests / benchmarks */
 int rdx_kv_read(rdx_ctx* ctx, int layer, int which /*0=K,1=V*/, void* dst /*model dtype [B][heads][max_len][D]*/);
 int rdx_hidden_read(rdx_ctx* ctx, void* dst /*model dtype [B][hidden]: decoder output rows of the last call*/);

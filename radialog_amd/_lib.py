@@ -62,6 +62,9 @@ SYMBOLS = {
                                C.POINTER(C.c_int), C.c_int]),
     "rdx_prefill": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rdx_decode_step": (C.c_int, [_P, _P]),
+    "rdx_prefill_append": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "rdx_generate_append": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,
+                                      C.POINTER(C.c_int), C.c_int]),
     "rdx_kv_read": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "rdx_hidden_read": (C.c_int, [_P, _P]),
     "rdx_time": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),

@@ -750,25 +750,40 @@ static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, c
                        f.layers * 128 + ((c->use_mega || c->chain_mlp) ? (int)mega_ctr_ints(f.layers) : 0), c->stream);
 }
 
-extern "C" int rdx_prefill(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int T, const float* qformer_embs,
-                           int max_new, int eos_id, int pad_id, int32_t* out_tokens, void* logits) {
+// keep == 0: a fresh prompt. keep > 0: `T` further prompt tokens behind the first `keep` cache slots of the previous call(s)
+// (the shared prefix of a multi-turn conversation is not recomputed; no image splice in the continuation).
+static int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int T, const float* qformer_embs, int keep,
+                        int max_new, int eos_id, int pad_id, int32_t* out_tokens, void* logits) {
     if (!c) return -1;
     if (!c->finalized || !c->cfg.enable_llama) return fail(c, -1, "rdx_prefill: llama weights not finalized");
     const rdx_config& f = c->cfg;
     if (!ids || !out_tokens || B <= 0 || B > f.max_batch) return fail(c, -1, "rdx_prefill: batch %d outside [1, %d]", B, f.max_batch);
-    if (T <= 0 || T + max_new > f.max_len) return fail(c, -1, "rdx_prefill: T (%d) + max_new (%d) exceeds max_len %d", T, max_new, f.max_len);
-    if (T + max_new > f.max_pos) return fail(c, -1, "rdx_prefill: sequence exceeds max_position_embeddings %d", f.max_pos);
+    if (T <= 0 || keep + T + max_new > f.max_len) return fail(c, -1, "rdx_prefill: T (%d) + max_new (%d) exceeds max_len %d", keep + T, max_new, f.max_len);
+    if (keep + T + max_new > f.max_pos) return fail(c, -1, "rdx_prefill: sequence exceeds max_position_embeddings %d", f.max_pos);
     if (qformer_embs && T < 32) return fail(c, -1, "rdx_prefill: image splice needs T >= 32");
     HIPCHK(c, hipSetDevice(c->device));
+    if (keep > 0) {
+        if (B != c->cur_B) return fail(c, -1, "rdx_prefill_append: batch %d differs from the cached conversation's %d", B, c->cur_B);
+        std::vector<int> slot(B);
+        HIPCHK(c, hipMemcpyAsync(slot.data(), c->d_slot, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int b = 0; b < B; ++b)
+            if (keep > slot[b]) return fail(c, -1, "rdx_prefill_append: keep_len %d exceeds the %d cached positions of row %d", keep, slot[b], b);
+    }
     const size_t M = (size_t)B * T;
     int rc = ensure_prefill_ws(c, M);
     if (rc) return rc;
     const int dt = f.dtype, H = f.hidden;
     hipStream_t s = c->stream;
-    c->cur_B = B; c->cur_T = T; c->cur_max_new = max_new; c->cur_eos = eos_id; c->cur_pad = pad_id; c->cur_tokens = out_tokens;
+    c->cur_B = B; c->cur_T = keep + T; c->cur_max_new = max_new; c->cur_eos = eos_id; c->cur_pad = pad_id; c->cur_tokens = out_tokens;
 
-    launch_prep_prompt(ids, mask, B, T, 32000, pad_id, c->d_img_pos, c->d_pos_ids, c->key_mask, f.max_len, c->d_pos, c->d_slot,
-                       c->d_step, c->d_unf, s);
+    if (keep > 0) {
+        launch_prep_append(B, T, keep, c->d_img_pos, c->d_pos_ids, c->d_pos, c->d_slot, c->d_step, c->d_unf, s);
+        qformer_embs = nullptr;
+    } else {
+        launch_prep_prompt(ids, mask, B, T, 32000, pad_id, c->d_img_pos, c->d_pos_ids, c->key_mask, f.max_len, c->d_pos, c->d_slot,
+                           c->d_step, c->d_unf, s);
+    }
     if (qformer_embs) {
         // a8: img_proj_layer on the model-dtype copy of the Q-Former output (".half()", modeling_llama_imgemb.py:576-579)
         launch_from_f32(dt, qformer_embs, c->pqe, (size_t)B * 32 * f.qformer_dim, s);
@@ -783,13 +798,15 @@ extern "C" int rdx_prefill(rdx_ctx* c, const int32_t* ids, const int32_t* mask, 
         void* vc = kv_ptr(c, c->vcache, l);
         launch_rmsnorm(dt, c->px, L.attn_norm, c->pxn, (int)M, H, f.rms_eps, s);
         { GemmArgs a = gargs(c->pxn, H, L.wqkv, nullptr, c->pqkv, c->ld.qkv_ld, (int)M); a.N = L.wqkv.Npad; run_gemm(c, a, EPI_NONE); }
-        launch_rope_kv_prefill(dt, c->ld, c->pqkv, L.lora_bq, L.lora_bv, c->rope_cos, c->rope_sin, c->d_pos_ids, c->pq, kc, vc, B, T, s);
+        // new K/V rows land behind the kept slots (row stride unchanged: shifting the base shifts every (row, head) slab)
+        launch_rope_kv_prefill(dt, c->ld, c->pqkv, L.lora_bq, L.lora_bv, c->rope_cos, c->rope_sin, c->d_pos_ids, c->pq,
+                               (char*)kc + (size_t)keep * 128 * 2, (char*)vc + (size_t)keep * 128 * 2, B, T, s);
         AttnArgs at;
         memset(&at, 0, sizeof(at));
         at.Q = c->pq; at.q_bs = (long)T * H; at.q_ts = H; at.q_hs = 128;
         at.K = kc; at.V = vc; at.k_bs = at.v_bs = (long)f.heads * f.max_len * 128; at.k_ts = at.v_ts = 128; at.k_hs = at.v_hs = (long)f.max_len * 128;
         at.O = c->patt; at.o_bs = (long)T * H; at.o_ts = H; at.o_hs = 128;
-        at.B = B; at.H = f.heads; at.Tq = T; at.Tk = T; at.causal = 1; at.key_mask = c->key_mask; at.km_bs = f.max_len;
+        at.B = B; at.H = f.heads; at.Tq = T; at.Tk = keep + T; at.causal = 1; at.key_mask = c->key_mask; at.km_bs = f.max_len;
         launch_attention(dt, 128, at, s);
         { GemmArgs a = gargs(c->patt, H, L.wo, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H; run_gemm(c, a, EPI_RESID); }
         launch_rmsnorm(dt, c->px, L.mlp_norm, c->pxn, (int)M, H, f.rms_eps, s);
@@ -801,6 +818,20 @@ extern "C" int rdx_prefill(rdx_ctx* c, const int32_t* ids, const int32_t* mask, 
     HIPCHK(c, hipGetLastError());
     return 0;
 }
+
+extern "C" int rdx_prefill(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int T, const float* qformer_embs,
+                           int max_new, int eos_id, int pad_id, int32_t* out_tokens, void* logits) {
+    return prefill_impl(c, ids, mask, B, T, qformer_embs, 0, max_new, eos_id, pad_id, out_tokens, logits);
+}
+
+extern "C" int rdx_prefill_append(rdx_ctx* c, const int32_t* ids_tail, int B, int T_tail, int keep_len, int max_new, int eos_id,
+                                  int pad_id, int32_t* out_tokens, void* logits) {
+    if (!c) return -1;
+    if (keep_len <= 0 || c->cur_B <= 0) return fail(c, -1, "rdx_prefill_append: no cached conversation to continue (keep_len %d)", keep_len);
+    return prefill_impl(c, ids_tail, nullptr, B, T_tail, nullptr, keep_len, max_new, eos_id, pad_id, out_tokens, logits);
+}
+
+static int decode_loop(rdx_ctx* c, int B, int max_new, int eos_id, void* scores, int* n_steps_host, int use_graph);
 
 static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, long step_stride) {
     const rdx_config& f = c->cfg;
@@ -976,6 +1007,20 @@ extern "C" int rdx_generate(rdx_ctx* c, const int32_t* ids, const int32_t* mask,
     if (max_new <= 0) return fail(c, -1, "rdx_generate: max_new must be positive");
     int rc = rdx_prefill(c, ids, mask, B, T, qformer_embs, max_new, eos_id, pad_id, out_tokens, scores);
     if (rc) return rc;
+    return decode_loop(c, B, max_new, eos_id, scores, n_steps_host, use_graph);
+}
+
+extern "C" int rdx_generate_append(rdx_ctx* c, const int32_t* ids_tail, int B, int T_tail, int keep_len, int max_new, int eos_id,
+                                   int pad_id, int32_t* out_tokens, void* scores, int* n_steps_host, int use_graph) {
+    if (!c) return -1;
+    if (max_new <= 0) return fail(c, -1, "rdx_generate_append: max_new must be positive");
+    int rc = rdx_prefill_append(c, ids_tail, B, T_tail, keep_len, max_new, eos_id, pad_id, out_tokens, scores);
+    if (rc) return rc;
+    return decode_loop(c, B, max_new, eos_id, scores, n_steps_host, use_graph);
+}
+
+static int decode_loop(rdx_ctx* c, int B, int max_new, int eos_id, void* scores, int* n_steps_host, int use_graph) {
+    int rc = 0;
     const rdx_config& f = c->cfg;
     int done = 1;
     std::vector<int> unf(B, 1);

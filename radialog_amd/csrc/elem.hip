@@ -396,6 +396,29 @@ void launch_prep_prompt(const int* ids, const int* mask_in, int B, int T_, int i
                        km_bs, (int)km_bs, pos_next, slot_b, step_b, unfinished);
 }
 
+// ---- continuation of a cached conversation: `T_` new prompt tokens go behind the first `keep_len` cache slots of every row
+// (multi-turn re-prompting, test.py:440-674 / demo.py:277-305, without recomputing the shared prefix). A row's pad count is
+// slot - next position, constant since its first prefill; the key mask of the kept slots stays, later slots are already 1.
+__global__ void prep_append_k(int T_, int keep_len, int* __restrict__ img_pos, int* __restrict__ pos_ids, int* __restrict__ pos_next,
+                              int* __restrict__ slot_b, int* __restrict__ step_b, int* __restrict__ unfinished) {
+    const int b = blockIdx.x;
+    const int pads = slot_b[b] - pos_next[b];
+    const int base = keep_len - pads;
+    for (int t = threadIdx.x; t < T_; t += blockDim.x) pos_ids[(size_t)b * T_ + t] = base + t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        img_pos[b] = 0;
+        pos_next[b] = base + T_;
+        slot_b[b] = keep_len + T_;
+        step_b[b] = 0;
+        unfinished[b] = 1;
+    }
+}
+void launch_prep_append(int B, int T_, int keep_len, int* img_pos, int* pos_ids, int* pos_next, int* slot_b, int* step_b,
+                        int* unfinished, hipStream_t s) {
+    hipLaunchKernelGGL(prep_append_k, dim3(B), dim3(256), 0, s, T_, keep_len, img_pos, pos_ids, pos_next, slot_b, step_b, unfinished);
+}
+
 // ---- embedding gather + image splice (:571-594): rows [p, p+32) take the projected image embedding ----------------------
 template <typename T>
 __global__ __launch_bounds__(256) void embed_splice_k(const int* __restrict__ ids, const int* __restrict__ img_pos,

@@ -166,6 +166,8 @@ void launch_from_f32(int dtype, const float* src, void* dst, size_t n, hipStream
 void launch_prep_prompt(const int* ids, const int* mask_in, int B, int T, int img_id, int pad_id, int* img_pos,
                         int* pos_ids, uint8_t* key_mask, long km_bs, int* pos_next, int* slot_b, int* step_b,
                         int* unfinished, hipStream_t s);
+void launch_prep_append(int B, int T_, int keep_len, int* img_pos, int* pos_ids, int* pos_next, int* slot_b, int* step_b,
+                        int* unfinished, hipStream_t s);
 void launch_embed_splice(int dtype, const int* ids, const int* img_pos, const void* embed, int vocab, const void* img_emb,
                          int n_img, void* out, int B, int T, int H, int use_img, hipStream_t s);
 void launch_gather_last(int dtype, const void* x, void* out, int B, int T, int H, hipStream_t s);

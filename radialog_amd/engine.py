@@ -131,9 +131,32 @@ class RdxEngine:
         self.sync()
         return out, emb
 
+    def _reusable_prefix(self, ids: torch.Tensor, qf, pad_id: int) -> int:
+        """Number of leading cache slots of the previous generate(reuse_prefix=True) call that this prompt can keep: the
+        longest token prefix all rows share with what was fed then (prompt + consumed answer tokens), provided the image
+        embeddings are the same, the whole <IMG> block lies inside it and the rest holds neither padding nor <IMG>."""
+        conv = getattr(self, "_conv", None)
+        if conv is None or conv["seq"].shape[0] != ids.shape[0]:
+            return 0
+        if (qf is None) != (conv["qf"] is None) or (qf is not None and not torch.equal(qf, conv["qf"])):
+            return 0
+        seq, new = conv["seq"], ids.cpu().to(torch.int64)
+        m = min(seq.shape[1], new.shape[1] - 1)                  # at least one token must be run to get logits
+        if m <= 0:
+            return 0
+        same = (seq[:, :m] == new[:, :m]).all(dim=0).to(torch.int64)
+        p = int(same.cumprod(0).sum())
+        tail = new[:, p:]
+        if p <= 0 or bool((tail == pad_id).any()) or bool((tail == 32000).any()):
+            return 0
+        return p
+
     def generate(self, ids: torch.Tensor, qformer_embs: Optional[torch.Tensor], max_new: int, eos_id: int = 2,
-                 pad_id: int = 0, mask: Optional[torch.Tensor] = None, output_scores: bool = False, use_graph: bool = True):
-        """Greedy generation. Returns (tokens int32[B,n_steps], scores [n_steps,B,V] model dtype or None, n_steps)."""
+                 pad_id: int = 0, mask: Optional[torch.Tensor] = None, output_scores: bool = False, use_graph: bool = True,
+                 reuse_prefix: bool = False):
+        """Greedy generation. Returns (tokens int32[B,n_steps], scores [n_steps,B,V] model dtype or None, n_steps).
+        reuse_prefix: multi-turn conversations -- keep the KV rows of the token prefix this prompt shares with the previous
+        reuse_prefix call and prefill only the rest (rdx_generate_append); outputs are those of the full prompt."""
         B, T = ids.shape
         ids32 = ids.to(device=self.device, dtype=torch.int32).contiguous()
         m32 = None if mask is None else mask.to(device=self.device, dtype=torch.int32).contiguous()
@@ -153,8 +176,21 @@ class RdxEngine:
                 self._keep[skey] = scores
         n = C.c_int(0)
         torch.cuda.synchronize(self.device)
-        check(self.ctx, self.lib.rdx_generate(self.ctx, _ptr(ids32), _ptr(m32), B, T, _ptr(qf), max_new, eos_id, pad_id,
-                                              _ptr(toks), _ptr(scores), C.byref(n), int(use_graph)), "rdx_generate")
+        keep = self._reusable_prefix(ids, qf, pad_id) if (reuse_prefix and mask is None) else 0
+        self.last_kept_prefix = keep
+        if keep:
+            tail = ids32[:, keep:].contiguous()
+            check(self.ctx, self.lib.rdx_generate_append(self.ctx, _ptr(tail), B, T - keep, keep, max_new, eos_id, pad_id, _ptr(toks),
+                                                         _ptr(scores), C.byref(n), int(use_graph)), "rdx_generate_append")
+        else:
+            check(self.ctx, self.lib.rdx_generate(self.ctx, _ptr(ids32), _ptr(m32), B, T, _ptr(qf), max_new, eos_id, pad_id,
+                                                  _ptr(toks), _ptr(scores), C.byref(n), int(use_graph)), "rdx_generate")
+        if reuse_prefix and mask is None:
+            # what the cache now holds: the prompt and every answer token that was fed back (all but the last one selected)
+            self._conv = {"seq": torch.cat([ids.cpu().to(torch.int64), toks[:, :max(n.value - 1, 0)].cpu().to(torch.int64)], dim=1),
+                          "qf": None if qf is None else qf.clone()}
+        else:
+            self._conv = None
         return toks, scores, n.value
 
     def prefill(self, ids, qformer_embs, max_new, eos_id=2, pad_id=0, mask=None, want_logits=True):

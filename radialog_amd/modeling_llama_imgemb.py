@@ -153,8 +153,11 @@ class LlamaForCausalLM:
         if embs is not None and tuple(embs.shape) != (B, 32, self.lcfg.qformer_dim):
             raise ValueError(f"image embeddings should be of size {(B, 32, self.lcfg.qformer_dim)}, but are {tuple(embs.shape)}")
         self._ensure_engine()
+        # multi-turn chats (demo.py:277-305 re-sends the whole conversation every turn): with `reuse_prefix_kv` set on the model
+        # the KV rows of the token prefix shared with the previous call are kept and only the new turn is prefilled
         toks, scores, n = self._engine.generate(input_ids, embs, max_new=max_new_tokens, eos_id=eos, pad_id=pad,
-                                                mask=attention_mask, output_scores=output_scores)
+                                                mask=attention_mask, output_scores=output_scores,
+                                                reuse_prefix=bool(getattr(self, "reuse_prefix_kv", False)) and attention_mask is None)
         toks = toks[:, :n].to(torch.int64)
         # HF stops as soon as every row has emitted EOS; the engine checks every 16 steps, so trim the all-pad tail
         if eos >= 0 and n > 0:

@@ -394,6 +394,74 @@ def test_decode_attention_context_lengths_around_the_register_window_edges(cfg, 
         eng.close()
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_multi_turn_prefix_kv_reuse_matches_full_recompute_and_oracle(cfg, cpu_w, B):
+    """Multi-turn re-prompting (test.py:440-674, demo.py:277-305): turn 2's prompt = turn 1's prompt + its answer + a
+    follow-up question. With reuse_prefix the engine keeps the KV rows of the shared token prefix (rdx_generate_append) and
+    prefills only the rest; tokens and logits must be those of the full prompt (oracle on the whole sequence), and the kept
+    length must be everything the cache held (prompt + consumed answer tokens)."""
+    from oracle import ref_cpu
+    from radialog_amd.engine import RdxEngine, synth_getter
+    T1, N1, TQ, N2 = 72, 9, 21, 8
+    ids1 = _prompt(cfg, B, T1, seed=41)
+    if B > 1:
+        ids1[1] = _prompt(cfg, 2, T1, seed=43)[1]            # row 1 left-padded (pads sit inside the shared prefix)
+    qf = synth.synth("t.qfmt", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    question = torch.randint(3, 31999, (B, TQ), generator=torch.Generator().manual_seed(5))
+    for dtype in ("f16", "bf16"):
+        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=256, lora=True, vision=False)
+        eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+        t1, _, n1 = eng.generate(ids1, qf, max_new=N1, eos_id=-1, pad_id=0, reuse_prefix=True)
+        assert eng.last_kept_prefix == 0 and n1 == N1
+        ids2 = torch.cat([ids1, t1.cpu().long(), question], dim=1)
+        t2, s2, n2 = eng.generate(ids2, qf, max_new=N2, eos_id=-1, pad_id=0, output_scores=True, reuse_prefix=True)
+        assert eng.last_kept_prefix == T1 + N1 - 1          # the last selected token of turn 1 was never fed: it is prefilled now
+        t2, s2 = t2.cpu().long().clone(), s2.float().cpu().clone()
+        # the same prompt from scratch on the same engine
+        t2f, s2f, _ = eng.generate(ids2, qf, max_new=N2, eos_id=-1, pad_id=0, output_scores=True)
+        assert eng.last_kept_prefix == 0
+        with torch.no_grad():
+            ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids2, qf, max_new=N2, eos_id=-1, pad_id=0)
+        tol = LOGIT_TOL[dtype]
+        for b in range(B):
+            for s in range(N2):
+                if t2[b, s] != ref["tokens"][b, s]:
+                    assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
+                    break
+                assert float((s2[s, b] - ref["scores"][s][b].float()).abs().max()) < tol, f"{dtype} row {b} step {s}: reuse path vs oracle"
+                assert float((s2[s, b] - s2f[s, b].float().cpu()).abs().max()) < tol, f"{dtype} row {b} step {s}: reuse path vs full prefill"
+        # a third turn whose prompt diverges inside the cached part keeps only the common prefix
+        ids3 = ids2.clone()
+        ids3[:, T1 + 3] = (ids3[:, T1 + 3] + 7) % 31000 + 3
+        eng.generate(ids2, qf, max_new=2, eos_id=-1, pad_id=0, reuse_prefix=True)
+        eng.generate(ids3, qf, max_new=2, eos_id=-1, pad_id=0, reuse_prefix=True)
+        assert eng.last_kept_prefix == T1 + 3
+        # other image -> nothing is reused
+        eng.generate(ids3, qf + 0.5, max_new=2, eos_id=-1, pad_id=0, reuse_prefix=True)
+        assert eng.last_kept_prefix == 0
+        eng.close()
+
+
+def test_prefill_append_rejects_what_the_cache_does_not_hold(cfg):
+    from radialog_amd.engine import RdxEngine, synth_getter
+    from radialog_amd._lib import RdxError
+    import ctypes as C
+    eng = RdxEngine(cfg, dtype="bf16", device=0, max_batch=2, max_len=128, lora=True, vision=False)
+    eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+    tail = torch.full((1, 4), 17, dtype=torch.int32, device=eng.device)
+    toks = torch.zeros(1, 4, dtype=torch.int32, device=eng.device)
+    n = C.c_int(0)
+    call = lambda B, keep: eng.lib.rdx_generate_append(eng.ctx, tail.data_ptr(), B, 4, keep, 4, -1, 0, toks.data_ptr(), None, C.byref(n), 0)
+    assert call(1, 10) != 0                                  # nothing cached yet
+    ids = _prompt(cfg, 1, 48, seed=9)
+    eng.generate(ids, None, max_new=4, eos_id=-1, pad_id=0)
+    assert call(1, 52) != 0                                  # 48 + 3 consumed tokens are cached, not 52
+    assert call(2, 40) != 0                                  # batch differs from the cached conversation
+    assert call(1, 120) != 0                                 # would overflow max_len
+    assert call(1, 51) == 0
+    eng.close()
+
+
 def _fake_quant_rows(w):
     absmax = w.abs().amax(dim=1, keepdim=True).float()
     inv = torch.where(absmax > 0, 448.0 / absmax, torch.ones_like(absmax))
