@@ -81,6 +81,7 @@ struct rdx_ctx {
     void *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dgu = nullptr;
     float* kslab = nullptr;          // batch 17-32 decode: fp32 partial slabs [<= 4 groups][32][hidden] of a K-split projection
     int pend_groups = 0;             // launch-time state: slabs written by the last xsplit32 launch, not yet added into dx
+    int prenorm_pack = -1;           // launch-time state: >= 0 -> that launch also ran the next RMSNorm (norm tail): dxn holds the rows in this layout
     void *px = nullptr, *pxn = nullptr, *pqkv = nullptr, *pq = nullptr, *patt = nullptr, *pgu = nullptr, *pqe = nullptr, *pimg = nullptr;
     size_t prefill_rows = 0;
     int cur_B = 0, cur_T = 0, cur_max_new = 0, cur_eos = -1, cur_pad = 0;
@@ -168,6 +169,12 @@ static GemmArgs gargs(const void* X, int ldx, const GemmW& W, const float* bias,
 // The RMSNorm of a projection whose rows do not fit the GEMV's LDS stage runs as its own launch in front of it; returns the
 // arguments of the GEMM proper (activations = c->dxn)
 static GemmArgs skinny_prenorm(rdx_ctx* c, GemmArgs a, int epi) {
+    if (a.norm_w && !skinny_fits_lds(a.M, a.K) && a.X == c->dx && c->prenorm_pack >= 0) {
+        // the K-split projection in front already ran this RMSNorm as its tail (xsplit32_k, XsTail), in the layout asked for
+        a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr; a.xpacked = c->prenorm_pack;
+        c->prenorm_pack = -1; c->pend_groups = 0;
+        return a;
+    }
     if (a.norm_w && !skinny_fits_lds(a.M, a.K)) {
         const void* x = a.X; const void* nw = a.norm_w;
         a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr;
@@ -201,14 +208,31 @@ static bool down_split_ok(rdx_ctx* c, const LlamaLayer& L, int B) {
     return xsplit32_groups(dn) > 0;
 }
 
-static void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split) {
+// A K-split projection (o_proj, down_proj at batch 17-32) followed by the RMSNorm + projection `next` (norm weight, epilogue):
+// the norm runs as a tail of the K-split launch when the shapes allow (xsplit32_tail_ok), writing c->dxn in the layout `next`
+// reads; otherwise the slabs stay pending for the stand-alone RMSNorm (skinny_prenorm).
+static void launch_ksplit(rdx_ctx* c, const GemmArgs& a, int* ctr, const GemmW* next_w, const void* next_norm, int next_epi) {
+    const rdx_config& f = c->cfg;
+    const int kg = xsplit32_groups(a);
+    if (next_w && next_norm && ctr && xsplit32_tail_ok(a)) {
+        GemmArgs nx = gargs(c->dxn, f.hidden, *next_w, nullptr, nullptr, 0, a.M);
+        const int pack = xstat32_supported(nx, next_epi) ? ((nx.W8 && nx.wscale) ? 2 : 1) : 0;
+        launch_xsplit32(f.dtype, a, c->kslab, c->stream, ctr, c->d_err, next_norm, c->dx, c->dxn, f.rms_eps, pack);
+        c->prenorm_pack = pack; c->pend_groups = 0;
+    } else {
+        launch_xsplit32(f.dtype, a, c->kslab, c->stream);
+        c->pend_groups = kg;
+    }
+}
+
+static void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split, int* ctr = nullptr, const GemmW* next_w = nullptr,
+                        const void* next_norm = nullptr, int next_epi = 0) {
     const rdx_config& f = c->cfg;
     GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, f.hidden, B);
     a.resid = c->dx; a.ldr = f.hidden;
     if (split) {
         a.xpacked = (a.W8 && a.wscale) ? 2 : 1;
-        launch_xsplit32(f.dtype, a, c->kslab, c->stream);
-        c->pend_groups = xsplit32_groups(a);
+        launch_ksplit(c, a, ctr, next_w, next_norm, next_epi);
     } else {
         skinny(c, a, EPI_RESID);
     }
@@ -423,9 +447,11 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         ALLOC(c, c->d_img_pos, B * sizeof(int)); ALLOC(c, c->d_pos, B * sizeof(int)); ALLOC(c, c->d_slot, B * sizeof(int));
         ALLOC(c, c->d_step, B * sizeof(int)); ALLOC(c, c->d_unf, B * sizeof(int));
         // hand-off counters: fused attention+o_proj (8 shards x 64 B per layer), then the chained kernel's (mega_ctr_ints)
-        ALLOC(c, c->d_ctr, ((size_t)f.layers * 128 + mega_ctr_ints(f.layers)) * sizeof(int)); ALLOC(c, c->d_err, sizeof(int));
-        HIPCHK(c, hipMemset(c->d_ctr, 0, ((size_t)f.layers * 128 + mega_ctr_ints(f.layers)) * sizeof(int)));
-        c->d_mctr = c->d_ctr + (size_t)f.layers * 128;
+        // per layer two sharded hand-off counters of 128 ints (fused attention + o_proj at batch <= 2; o_proj / down_proj norm tails
+        // at batch 17-32), then the chained kernels' block
+        ALLOC(c, c->d_ctr, ((size_t)f.layers * 256 + mega_ctr_ints(f.layers)) * sizeof(int)); ALLOC(c, c->d_err, sizeof(int));
+        HIPCHK(c, hipMemset(c->d_ctr, 0, ((size_t)f.layers * 256 + mega_ctr_ints(f.layers)) * sizeof(int)));
+        c->d_mctr = c->d_ctr + (size_t)f.layers * 256;
         HIPCHK(c, hipMemset(c->d_err, 0, sizeof(int)));
         {
             std::vector<MegaLayer> ml(f.layers);
@@ -747,7 +773,7 @@ static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, c
                        c->cur_tokens, c->d_unf, advance ? c->d_pos : nullptr, advance ? c->d_slot : nullptr, c->d_step,
                        c->embed, f.vocab, c->dx, f.hidden, c->d_pos, c->rope_cos, c->rope_sin, c->d_cur_rope,
                        (c->fuse_attn_oproj || c->use_mega || c->chain_mlp) ? c->d_ctr : nullptr,
-                       f.layers * 128 + ((c->use_mega || c->chain_mlp) ? (int)mega_ctr_ints(f.layers) : 0), c->stream);
+                       f.layers * 256 + ((c->use_mega || c->chain_mlp) ? (int)mega_ctr_ints(f.layers) : 0), c->stream);
 }
 
 // keep == 0: a fresh prompt. keep > 0: `T` further prompt tokens behind the first `keep` cache slots of the previous call(s)
@@ -878,9 +904,9 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         GemmArgs ao = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B);
         ao.resid = c->dx; ao.ldr = H;
         if (c->fuse_attn_oproj == 2 && attn_oproj16_supported(c->ld, L.wo.N, L.wo.K, B)) {
-            launch_attn_oproj16(dt, at, ao, B, c->d_ctr + (size_t)l * 128, c->d_err, s);
+            launch_attn_oproj16(dt, at, ao, B, c->d_ctr + (size_t)l * 256, c->d_err, s);
         } else if (c->fuse_attn_oproj == 1 && (L.wo.N + 15) / 16 <= 256) {
-            launch_attn_oproj(dt, at, ao, B, c->d_ctr + (size_t)l * 128, c->d_err, s);
+            launch_attn_oproj(dt, at, ao, B, c->d_ctr + (size_t)l * 256, c->d_err, s);
         } else {
             // batch 17-32: attention writes its output fragment-packed and o_proj runs K-split over two workgroups per tile,
             // its residual epilogue folded into the RMSNorm in front of gate/up (xsplit32_k)
@@ -888,7 +914,7 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
             const int kg = (B > 16 && c->kslab) ? xsplit32_groups(ap) : 0;
             at.out_packed = kg > 0 ? ap.xpacked : 0;
             launch_decode_attention(dt, at, B, s);
-            if (kg) { launch_xsplit32(dt, ap, c->kslab, s); c->pend_groups = kg; }
+            if (kg) launch_ksplit(c, ap, c->d_ctr + (size_t)l * 256, &L.wgu, L.mlp_norm, EPI_SILU_MUL);     // tail: the RMSNorm of gate/up
             else skinny(c, ao, EPI_RESID);
         }
         if (chain && c->chain_mlp == 1) {
@@ -904,7 +930,9 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps;
           a.out_packed = split ? ((L.wdown.w8 && L.wdown.scale) ? 2 : 1) : 0;
           skinny(c, a, EPI_SILU_MUL); }
-        launch_down(c, L, B, split);
+        // tail: the RMSNorm of the next layer's QKV, or the final norm in front of lm_head
+        if (l + 1 < f.layers) launch_down(c, L, B, split, c->d_ctr + (size_t)l * 256 + 128, &c->ll[l + 1].wqkv, c->ll[l + 1].attn_norm, EPI_NONE);
+        else launch_down(c, L, B, split, c->d_ctr + (size_t)l * 256 + 128, &c->lm_head, c->final_norm, EPI_LOGITS);
     }
     lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
 }

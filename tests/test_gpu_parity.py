@@ -286,18 +286,20 @@ def test_batch18_greedy_tokens_match_oracle(cfg, cpu_w):
         eng.close()
 
 
-@pytest.mark.parametrize("fp8", [False, True])
-def test_batch20_production_width_layer_matches_oracle(fp8):
+@pytest.mark.parametrize("fp8,layers,tail", [(False, 1, 0), (True, 1, 0), (False, 2, 0), (False, 2, 1)])
+def test_batch20_production_width_layer_matches_oracle(fp8, layers, tail, monkeypatch):
     """Batch 17-32 at the production widths (hidden 4096, inter 11008, vocab 32001; one decoder layer so that the oracle
     finishes in seconds): QKV / gate-up / lm_head go through the activation-stationary kernel (xstat32.hip) fed by the
     fragment-packed RMSNorm, gate/up hands its SwiGLU output to down_proj fragment-packed, down_proj runs K-split
-    (xsplit32_k) and its residual epilogue happens in the next RMSNorm; attention hands its output to the K-split o_proj the
-    same way. Tokens and per-step logits against the oracle. fp8 = the same path on e4m3 weights (oracle on the fake-quantised
+    (xsplit32_k) and its residual epilogue + the next RMSNorm run as a tail of the same launch; attention hands its output to the
+    K-split o_proj the same way. Tokens and per-step logits against the oracle. fp8 = the same path on e4m3 weights (oracle on the fake-quantised
     weights, bf16 only)."""
     from oracle import ref_cpu
     from radialog_amd.config import LlamaCfg, RaDialogCfg
     from radialog_amd.engine import RdxEngine, synth_getter
-    cfg = RaDialogCfg(llama=LlamaCfg(layers=1, qformer_dim=192))
+    if tail:        # the in-launch norm tail of the K-split kernels (RDX_XSTAIL, off by default)
+        monkeypatch.setenv("RDX_XSTAIL", "1")
+    cfg = RaDialogCfg(llama=LlamaCfg(layers=layers, qformer_dim=192))     # 2 layers: the down_proj -> next layer's QKV seam as well
     cpu_w = synth.make_weights(synth.llama_specs(cfg.llama, lora=True))
     if fp8:
         cpu_w = {k: (_fake_quant_rows(v) if k == "lm_head.weight" or (k.startswith("model.layers.") and v.dim() == 2 and
@@ -306,7 +308,7 @@ def test_batch20_production_width_layer_matches_oracle(fp8):
     B, T, N = 20, 96, 5
     ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, pad_rows=True, seed=5)
     qf = synth.synth("t.qf20", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
-    for dtype in (("bf16",) if fp8 else ("bf16", "f16")):
+    for dtype in (("bf16",) if (fp8 or layers > 1) else ("bf16", "f16")):
         eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=128, lora=True, vision=False, weights_fp8=fp8)
         eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
         with torch.no_grad():
@@ -315,7 +317,7 @@ def test_batch20_production_width_layer_matches_oracle(fp8):
         toks = toks.cpu().long()
         # 4096- and 11008-deep fp32 accumulations in another order than torch's, rounded to the model dtype at every op of the
         # layer: the worst of 20 x 32001 logits sits 3 ulp off at |logit| ~ 6 (ulp 2^-8 fp16, 2^-5 bf16; mean error 1/3 ulp)
-        tol = {"f16": 2e-2, "bf16": 0.125}[dtype]
+        tol = {"f16": 2e-2, "bf16": 0.125}[dtype] * (layers ** 0.5)       # the rounding noise adds up layer by layer
         if fp8:     # the streaming kernels scale the fp32 sum of e4m3 products; the oracle's weights are T(q * scale), each rounded to bf16
             tol *= 1.5
         assert not torch.isnan(scores.float()).any()
