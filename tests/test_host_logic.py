@@ -106,3 +106,33 @@ def test_generate_wrapper_argument_errors():
         lm.generate(input_ids=ids, qformer_embs=torch.zeros(1, 31, 768), max_new_tokens=4)
     with pytest.raises(ValueError):
         lm.generate(input_ids=ids[0], max_new_tokens=4)
+
+
+def test_reusable_prefix_rules_for_multi_turn_kv_reuse():
+    """RdxEngine._reusable_prefix (host side of rdx_generate_append): the kept length is the longest token prefix ALL rows share
+    with what the cache holds, at least one token is left to run, and nothing is reused across images, batch sizes, or when
+    the remainder holds padding or <IMG> tokens."""
+    import types
+    import torch
+    from radialog_amd.engine import RdxEngine
+    seq = torch.tensor([[0, 0, 1, 5, 32000, 32000, 7, 8, 9, 11], [1, 4, 32000, 32000, 6, 7, 8, 9, 10, 12]])
+    qf = torch.ones(2, 32, 4)
+    eng = types.SimpleNamespace(_conv={"seq": seq, "qf": qf.clone()})
+    f = lambda ids, q=qf, pad=0: RdxEngine._reusable_prefix(eng, ids, q, pad)
+    tail = torch.tensor([[21, 22, 23], [24, 25, 26]])
+    assert f(torch.cat([seq, tail], 1)) == 10                    # whole cached sequence kept, the new turn is the tail
+    assert f(seq) == 9                                           # identical prompt: one token must still be run
+    d = torch.cat([seq, tail], 1)
+    d[1, 7] = 99
+    assert f(d) == 7                                             # rows must agree: the shortest common prefix over the batch
+    assert f(torch.cat([seq, tail], 1), q=qf + 1) == 0           # another image
+    assert f(torch.cat([seq, tail], 1), q=None) == 0
+    assert f(torch.cat([seq[:1], tail[:1]], 1), q=qf[:1]) == 0   # another batch size
+    p = torch.cat([seq, tail], 1)
+    p[0, 11] = 0
+    assert f(p) == 0                                             # padding behind the kept part
+    g = torch.cat([seq, tail], 1)
+    g[:, 3] = 77
+    assert f(g) == 0                                             # diverges before the <IMG> block ends -> <IMG> in the remainder
+    eng._conv = None
+    assert f(torch.cat([seq, tail], 1)) == 0
