@@ -468,9 +468,9 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         c->n_vtiles = c->lm_head.Npad / 16;
         ALLOC(c, c->part_val, (size_t)B * c->n_vtiles * sizeof(float));
         ALLOC(c, c->part_idx, (size_t)B * c->n_vtiles * sizeof(int));
-        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)(B > 16 ? 32 : B) * H * 2);
+        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)(B > 16 ? std::max(B, 32) : B) * H * 2);
         if (B > 16) ALLOC(c, c->kslab, (size_t)4 * 32 * H * sizeof(float)); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
-        ALLOC(c, c->datt, (size_t)(B > 16 ? 32 : B) * H * 2); ALLOC(c, c->dgu, (size_t)(B > 16 ? 32 : B) * I * 2);
+        ALLOC(c, c->datt, (size_t)(B > 16 ? std::max(B, 32) : B) * H * 2); ALLOC(c, c->dgu, (size_t)(B > 16 ? std::max(B, 32) : B) * I * 2);
     }
     if (f.enable_vision) {
         const int H = f.q_hidden, I = f.q_inter;
