@@ -1,4 +1,4 @@
-// Activation-stationary weight-streaming GEMM for 16 < M <= 32 rows and K = 4096 (batch-32 decode: QKV, gate/up, lm_head), gfx950.
+// Activation-stationary weight-streaming GEMM for 4 < M <= 32 rows and K = 4096 (batch 5-32 decode: QKV, gate/up, lm_head), gfx950.
 //
 // skinny32_k re-stages the [32][K] activation block through LDS for every group of four output tiles, one workgroup
 // barrier per 512-deep stage, and its weight stream ran at ~3.9 TB/s. Here the activations never move after start-up:
@@ -376,12 +376,20 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
     stg16(dst, as_u4<T>(o));
 }
 
+// smallest row count (batch) that takes the activation-stationary / K-split kernels; below it the GEMV family of skinny_body.h
+// (whose LDS stage holds up to 4 rows of 4096). Measured step times, default GEMV path -> these kernels: batch 5 3.31 -> 3.25 ms,
+// batch 8 3.53 -> 3.29, batch 16 4.23 -> 3.53 (rows beyond the batch ride along as zero columns of the 32-row block).
+int xs_min_rows() {
+    const char* e = getenv("RDX_XS_MINM");
+    return e ? atoi(e) : 5;
+}
+
 // K groups for this shape (0 = not supported): needs fragment-packed activations (xpacked 1; 2 = the fp8 64-deep order)
 int xsplit32_groups(const GemmArgs& a) {
     const char* e = getenv("RDX_XSPLIT");                     // 0 = off
     if (e && atoi(e) == 0) return 0;
     const bool w8 = a.W8 && a.wscale;
-    if (!(a.M > 16 && a.M <= 32) || a.xpacked != (w8 ? 2 : 1) || a.norm_w || a.bias || (a.N + 15) / 16 < 128 || (a.N + 15) / 16 > 512) return 0;
+    if (!(a.M >= xs_min_rows() && a.M <= 32) || a.xpacked != (w8 ? 2 : 1) || a.norm_w || a.bias || (a.N + 15) / 16 < 128 || (a.N + 15) / 16 > 512) return 0;
     if (a.K == 11008) return 4;
     if (a.K == 4096) return 2;
     return 0;
@@ -418,7 +426,7 @@ void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s, i
 bool xstat32_supported(const GemmArgs& a, int epi) {
     const char* e = getenv("RDX_XS32");                       // minimum tile count (0 = off); read per launch (tests toggle it)
     const int min_tiles = e ? atoi(e) : 512;
-    return min_tiles > 0 && a.M > 16 && a.M <= 32 && a.K == XS_K && !a.norm_w && (a.N + 15) / 16 >= min_tiles &&
+    return min_tiles > 0 && a.M >= xs_min_rows() && a.M <= 32 && a.K == XS_K && !a.norm_w && (a.N + 15) / 16 >= min_tiles &&
            (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL || epi == EPI_LOGITS);
 }
 
