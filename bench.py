@@ -220,7 +220,7 @@ def main():
             tiles = (n_rows + 15) // 16
             lds = B <= 16 and B * k * 2 <= 32 * 1024                     # batch-1..4 GEMV with LDS-staged activations
             s32 = 16 < B <= 32 and tiles > 512 and k % 512 == 0          # skinny32.hip
-            xs = 5 <= B <= 32 and ((tiles >= 512 and k == 4096) or (128 <= tiles <= 512 and k in (4096, 11008)))   # xstat32.hip
+            xs = 3 <= B <= 32 and ((tiles >= 512 and k == 4096) or (128 <= tiles <= 512 and k in (4096, 11008)))   # xstat32.hip
             return 1 if (lds or s32 or xs) else 2
         wb = wbytes(2 * lc.inter, lc.hidden)
         gu_bytes = 2 * lc.inter * lc.hidden * wb + B * lc.hidden * 2 + lc.hidden * 2 + B * lc.inter * 2
@@ -239,7 +239,7 @@ def main():
         step_bytes = (32 * (3 * H_ * H_ * wbytes(3 * H_ + 16, H_) + H_ * H_ * wbytes(H_, H_) + 2 * I_ * H_ * wbytes(2 * I_, H_)
                             + H_ * I_ * wbytes(H_, I_)) + lc.vocab * H_ * wbytes(lc.vocab, H_) + (32 * 2 * H_ + H_) * 2)
         roof = {
-            "bound": "hbm", "kernel": (f"xstat32_k<{args.dtype},EPI_SILU_MUL{',W8' if wb == 1 else ''}> (gate/up SwiGLU, activation-stationary batch 5-32 GEMM)" if B > 4 else
+            "bound": "hbm", "kernel": (f"xstat32_k<{args.dtype},EPI_SILU_MUL{',W8' if wb == 1 else ''}> (gate/up SwiGLU, activation-stationary batch 3-32 GEMM)" if B > 2 else
                                        f"skinny_gemm_k<{args.dtype},MT,EPI_SILU_MUL,NORM{',W8' if wb == 1 else ''}> (gate/up SwiGLU GEMV)"),
             "achieved": gu_bytes / (gu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(B, args.dtype, args.fp8),

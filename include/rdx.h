@@ -130,7 +130,7 @@ int rdx_gemv_trace(rdx_ctx* ctx, int what, int layer, long long* host, int max_t
 /* one bare GEMM through the production kernels: out = epilogue(X . W^T); X/resid/norm_w/out model dtype, W [N][K] and
  * bias fp32. epi: 0 none, 1 relu, 2 gelu, 3 +resid, 4 swiglu(interleaved gate/up rows), 6 relu(+resid).
  * force: 0 = production dispatch (M <= 32 -> skinny, else LDS-DMA GEMM when K % 64 == 0, else tiled), 1 = skinny,
- * 2 = tiled_gemm_k, 3 = gemm_dma_k, 4 = skinny with fp8 (e4m3 + per-row scale) weights, 5 = the batch 5-32 K-split path (epi 3 only:
+ * 2 = tiled_gemm_k, 3 = gemm_dma_k, 4 = skinny with fp8 (e4m3 + per-row scale) weights, 5 = the batch 3-32 K-split path (epi 3 only:
  * pack X, xsplit32_k, slab combine + residual), 6 = 5 with fp8 weights. Test / benchmark hook. */
 int rdx_gemm_test(rdx_ctx* ctx, const void* X, const float* W, const float* bias, const void* resid, void* out, int M, int N,
                   int K, int epi, const void* norm_w, float eps, int force);

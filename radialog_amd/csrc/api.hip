@@ -79,7 +79,7 @@ struct rdx_ctx {
     float* part_val = nullptr; int* part_idx = nullptr; int n_vtiles = 0;
     // decode-step activations ([max_batch] rows) and prefill activations (grown on demand)
     void *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dgu = nullptr;
-    float* kslab = nullptr;          // batch 5-32 decode: fp32 partial slabs [<= 4 groups][32][hidden] of a K-split projection
+    float* kslab = nullptr;          // batch 3-32 decode: fp32 partial slabs [<= 4 groups][32][hidden] of a K-split projection
     int pend_groups = 0;             // launch-time state: slabs written by the last xsplit32 launch, not yet added into dx
     int prenorm_pack = -1;           // launch-time state: >= 0 -> that launch also ran the next RMSNorm (norm tail): dxn holds the rows in this layout
     void *px = nullptr, *pxn = nullptr, *pqkv = nullptr, *pq = nullptr, *patt = nullptr, *pgu = nullptr, *pqe = nullptr, *pimg = nullptr;
@@ -169,13 +169,21 @@ static GemmArgs gargs(const void* X, int ldx, const GemmW& W, const float* bias,
 // The RMSNorm of a projection whose rows do not fit the GEMV's LDS stage runs as its own launch in front of it; returns the
 // arguments of the GEMM proper (activations = c->dxn)
 static GemmArgs skinny_prenorm(rdx_ctx* c, GemmArgs a, int epi) {
-    if (a.norm_w && !skinny_fits_lds(a.M, a.K) && a.X == c->dx && c->prenorm_pack >= 0) {
+    if (a.norm_w && a.X == c->dx && c->prenorm_pack >= 0) {
         // the K-split projection in front already ran this RMSNorm as its tail (xsplit32_k, XsTail), in the layout asked for
         a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr; a.xpacked = c->prenorm_pack;
         c->prenorm_pack = -1; c->pend_groups = 0;
         return a;
     }
-    if (a.norm_w && !skinny_fits_lds(a.M, a.K)) {
+    // (batch 3-4 rows would fit the GEMV's LDS stage with the norm fused, but the activation-stationary kernel behind a
+    // stand-alone RMSNorm is faster there too: gate/up 41.7 -> 31 + 5 us at batch 4)
+    bool standalone = a.norm_w && !skinny_fits_lds(a.M, a.K);
+    if (a.norm_w && !standalone && a.M >= xs_min_rows() && c->kslab) {
+        GemmArgs t = a;
+        t.X = c->dxn; t.ldx = a.K; t.norm_w = nullptr;
+        standalone = xstat32_supported(t, epi);
+    }
+    if (standalone) {
         const void* x = a.X; const void* nw = a.norm_w;
         a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr;
         // a K-split projection before this one left its residual epilogue to this RMSNorm (xsplit32_k): x += T(sum of slabs)
@@ -197,7 +205,7 @@ static void skinny(rdx_ctx* c, GemmArgs a, int epi) {
     launch_skinny_gemm(c->cfg.dtype, skinny_prenorm(c, a, epi), epi, c->stream);
 }
 
-// batch 5-32 decode: gate/up (xstat32_k) can hand its SwiGLU output to down_proj fragment-packed, and down_proj then runs
+// batch 3-32 decode: gate/up (xstat32_k) can hand its SwiGLU output to down_proj fragment-packed, and down_proj then runs
 // K-split over 4 workgroups per tile (xsplit32_k), its residual epilogue deferred to the next RMSNorm
 static bool down_split_ok(rdx_ctx* c, const LlamaLayer& L, int B) {
     if (B < xs_min_rows() || !c->kslab) return false;
@@ -208,7 +216,7 @@ static bool down_split_ok(rdx_ctx* c, const LlamaLayer& L, int B) {
     return xsplit32_groups(dn) > 0;
 }
 
-// A K-split projection (o_proj, down_proj at batch 5-32) followed by the RMSNorm + projection `next` (norm weight, epilogue):
+// A K-split projection (o_proj, down_proj at batch 3-32) followed by the RMSNorm + projection `next` (norm weight, epilogue):
 // the norm runs as a tail of the K-split launch when the shapes allow (xsplit32_tail_ok), writing c->dxn in the layout `next`
 // reads; otherwise the slabs stay pending for the stand-alone RMSNorm (skinny_prenorm).
 static void launch_ksplit(rdx_ctx* c, const GemmArgs& a, int* ctr, const GemmW* next_w, const void* next_norm, int next_epi) {
@@ -448,7 +456,7 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         ALLOC(c, c->d_step, B * sizeof(int)); ALLOC(c, c->d_unf, B * sizeof(int));
         // hand-off counters: fused attention+o_proj (8 shards x 64 B per layer), then the chained kernel's (mega_ctr_ints)
         // per layer two sharded hand-off counters of 128 ints (fused attention + o_proj at batch <= 2; o_proj / down_proj norm tails
-        // at batch 5-32), then the chained kernels' block
+        // at batch 3-32), then the chained kernels' block
         ALLOC(c, c->d_ctr, ((size_t)f.layers * 256 + mega_ctr_ints(f.layers)) * sizeof(int)); ALLOC(c, c->d_err, sizeof(int));
         HIPCHK(c, hipMemset(c->d_ctr, 0, ((size_t)f.layers * 256 + mega_ctr_ints(f.layers)) * sizeof(int)));
         c->d_mctr = c->d_ctr + (size_t)f.layers * 256;
@@ -468,9 +476,9 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         c->n_vtiles = c->lm_head.Npad / 16;
         ALLOC(c, c->part_val, (size_t)B * c->n_vtiles * sizeof(float));
         ALLOC(c, c->part_idx, (size_t)B * c->n_vtiles * sizeof(int));
-        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)(B > 4 ? std::max(B, 32) : B) * H * 2);
-        if (B > 4) ALLOC(c, c->kslab, (size_t)4 * 32 * H * sizeof(float)); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
-        ALLOC(c, c->datt, (size_t)(B > 4 ? std::max(B, 32) : B) * H * 2); ALLOC(c, c->dgu, (size_t)(B > 4 ? std::max(B, 32) : B) * I * 2);
+        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)(B > 2 ? std::max(B, 32) : B) * H * 2);
+        if (B > 2) ALLOC(c, c->kslab, (size_t)4 * 32 * H * sizeof(float)); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
+        ALLOC(c, c->datt, (size_t)(B > 2 ? std::max(B, 32) : B) * H * 2); ALLOC(c, c->dgu, (size_t)(B > 2 ? std::max(B, 32) : B) * I * 2);
     }
     if (f.enable_vision) {
         const int H = f.q_hidden, I = f.q_inter;
@@ -908,7 +916,7 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         } else if (c->fuse_attn_oproj == 1 && (L.wo.N + 15) / 16 <= 256) {
             launch_attn_oproj(dt, at, ao, B, c->d_ctr + (size_t)l * 256, c->d_err, s);
         } else {
-            // batch 5-32: attention writes its output fragment-packed and o_proj runs K-split over two workgroups per tile,
+            // batch 3-32: attention writes its output fragment-packed and o_proj runs K-split over two workgroups per tile,
             // its residual epilogue folded into the RMSNorm in front of gate/up (xsplit32_k)
             GemmArgs ap = ao; ap.xpacked = (ao.W8 && ao.wscale) ? 2 : 1;
             const int kg = (B >= xs_min_rows() && c->kslab) ? xsplit32_groups(ap) : 0;

@@ -68,7 +68,7 @@ void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows
                                                 (T*)out, H, eps, rows, (const float*)nullptr, 0, (T*)nullptr));
 }
 
-// One-round-trip version for H = 4096 (decode at batch 5-32: two of these per layer sit on the step's critical path): a
+// One-round-trip version for H = 4096 (decode at batch 3-32: two of these per layer sit on the step's critical path): a
 // thread owns 2 x 8 elements, every load (row, slabs, norm weight) is issued up front, the row stays in registers between the
 // statistics and the scaling. Same arithmetic and rounding points as rmsnorm_k.
 template <typename T, int PACK>

@@ -83,7 +83,7 @@ int xsplit32_groups(const GemmArgs& a);
 void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s, int* ctr = nullptr, int* err = nullptr,
                      const void* norm_w = nullptr, void* x = nullptr, void* xn = nullptr, float eps = 0.f, int pack = 0);
 bool xsplit32_tail_ok(const GemmArgs& a);
-int xs_min_rows();        // smallest batch on the xstat32 / xsplit32 path (RDX_XS_MINM, default 5)
+int xs_min_rows();        // smallest batch on the xstat32 / xsplit32 path (RDX_XS_MINM, default 3)
 void launch_tiled_gemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s);
 // LDS-DMA GEMM for plain row-major activations (M > 32, K % 64 == 0); `ws` = fp32 split-K workspace (nullable)
 bool gemm_dma_supported(const GemmArgs& a);
@@ -108,7 +108,7 @@ struct DecAttnArgs {
     const uint8_t* key_mask;
     void *kcache, *vcache, *out;
     long long* trace = nullptr;      // debug: 8 timestamps (100 MHz ticks) of workgroup (b=0,h=0)
-    int out_packed = 0;              // stand-alone launches, batch 5-32: write `out` fragment-packed for xsplit32_k (attn_body.h)
+    int out_packed = 0;              // stand-alone launches, batch 3-32: write `out` fragment-packed for xsplit32_k (attn_body.h)
 };
 void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s);
 // decode attention + o_proj(+residual) in ONE launch: the o_proj tile workgroups put their weights in flight

@@ -1,4 +1,4 @@
-// Activation-stationary weight-streaming GEMM for 4 < M <= 32 rows and K = 4096 (batch 5-32 decode: QKV, gate/up, lm_head), gfx950.
+// Activation-stationary weight-streaming GEMM for 2 < M <= 32 rows and K = 4096 (batch 3-32 decode: QKV, gate/up, lm_head), gfx950.
 //
 // skinny32_k re-stages the [32][K] activation block through LDS for every group of four output tiles, one workgroup
 // barrier per 512-deep stage, and its weight stream ran at ~3.9 TB/s. Here the activations never move after start-up:
@@ -378,10 +378,11 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 
 // smallest row count (batch) that takes the activation-stationary / K-split kernels; below it the GEMV family of skinny_body.h
 // (whose LDS stage holds up to 4 rows of 4096). Measured step times, default GEMV path -> these kernels: batch 5 3.31 -> 3.25 ms,
-// batch 8 3.53 -> 3.29, batch 16 4.23 -> 3.53 (rows beyond the batch ride along as zero columns of the 32-row block).
+// batch 8 3.53 -> 3.29, batch 16 4.23 -> 3.53 (rows beyond the batch ride along as zero columns of the 32-row block); batch 3 and
+// 4, whose rows would still fit the GEMV's LDS stage: 3.39 / 3.56 ms there. Batch 1-2 keep the fused / chained GEMV launches.
 int xs_min_rows() {
     const char* e = getenv("RDX_XS_MINM");
-    return e ? atoi(e) : 5;
+    return e ? atoi(e) : 3;
 }
 
 // K groups for this shape (0 = not supported): needs fragment-packed activations (xpacked 1; 2 = the fp8 64-deep order)

@@ -299,9 +299,10 @@ def _production_width_weights(layers):
 
 
 @pytest.mark.parametrize("B,fp8,layers,tail", [(20, False, 1, 0), (20, True, 1, 0), (8, False, 1, 0), (16, True, 1, 0), (5, False, 1, 0),
+                                               (3, False, 1, 0), (4, True, 1, 0),
                                                (20, False, 2, 0), (20, False, 2, 1)])
 def test_batch20_production_width_layer_matches_oracle(B, fp8, layers, tail, monkeypatch):
-    """Batch 5-32 at the production widths (hidden 4096, inter 11008, vocab 32001; one decoder layer so that the oracle
+    """Batch 3-32 at the production widths (hidden 4096, inter 11008, vocab 32001; one decoder layer so that the oracle
     finishes in seconds): QKV / gate-up / lm_head go through the activation-stationary kernel (xstat32.hip) fed by the
     fragment-packed RMSNorm, gate/up hands its SwiGLU output to down_proj fragment-packed, down_proj runs K-split
     (xsplit32_k) and its residual epilogue + the next RMSNorm run as a tail of the same launch; attention hands its output to the
