@@ -832,15 +832,15 @@ static int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int
         void* vc = kv_ptr(c, c->vcache, l);
         launch_rmsnorm(dt, c->px, L.attn_norm, c->pxn, (int)M, H, f.rms_eps, s);
         { GemmArgs a = gargs(c->pxn, H, L.wqkv, nullptr, c->pqkv, c->ld.qkv_ld, (int)M); a.N = L.wqkv.Npad; run_gemm(c, a, EPI_NONE); }
-        // new K/V rows land behind the kept slots (row stride unchanged: shifting the base shifts every (row, head) slab)
+        // new K/V rows land behind the kept slots
         launch_rope_kv_prefill(dt, c->ld, c->pqkv, L.lora_bq, L.lora_bv, c->rope_cos, c->rope_sin, c->d_pos_ids, c->pq,
-                               (char*)kc + (size_t)keep * 128 * 2, (char*)vc + (size_t)keep * 128 * 2, B, T, s);
+                               kc, vc, B, T, keep, s);
         AttnArgs at;
         memset(&at, 0, sizeof(at));
         at.Q = c->pq; at.q_bs = (long)T * H; at.q_ts = H; at.q_hs = 128;
         at.K = kc; at.V = vc; at.k_bs = at.v_bs = (long)f.heads * f.max_len * 128; at.k_ts = at.v_ts = 128; at.k_hs = at.v_hs = (long)f.max_len * 128;
         at.O = c->patt; at.o_bs = (long)T * H; at.o_ts = H; at.o_hs = 128;
-        at.B = B; at.H = f.heads; at.Tq = T; at.Tk = keep + T; at.causal = 1; at.key_mask = c->key_mask; at.km_bs = f.max_len;
+        at.B = B; at.H = f.heads; at.Tq = T; at.Tk = keep + T; at.causal = 1; at.k_perm = 1; at.key_mask = c->key_mask; at.km_bs = f.max_len;
         launch_attention(dt, 128, at, s);
         { GemmArgs a = gargs(c->patt, H, L.wo, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H; run_gemm(c, a, EPI_RESID); }
         launch_rmsnorm(dt, c->px, L.mlp_norm, c->pxn, (int)M, H, f.rms_eps, s);
@@ -1102,7 +1102,8 @@ static int decode_loop(rdx_ctx* c, int B, int max_new, int eos_id, void* scores,
 extern "C" int rdx_kv_read(rdx_ctx* c, int layer, int which, void* dst) {
     if (!c || !c->finalized || !c->cfg.enable_llama) return fail(c, -1, "rdx_kv_read: no llama state");
     if (layer < 0 || layer >= c->cfg.layers || !dst) return fail(c, -1, "rdx_kv_read: bad arguments");
-    HIPCHK(c, hipMemcpyAsync(dst, kv_ptr(c, which ? c->vcache : c->kcache, layer), c->kv_layer_elems * 2, hipMemcpyDeviceToDevice, c->stream));
+    if (which) HIPCHK(c, hipMemcpyAsync(dst, kv_ptr(c, c->vcache, layer), c->kv_layer_elems * 2, hipMemcpyDeviceToDevice, c->stream));
+    else launch_k_unperm(kv_ptr(c, c->kcache, layer), dst, c->kv_layer_elems / ((size_t)c->cfg.max_len * 128), c->cfg.max_len, c->stream);   // K: back from the fragment order
     return 0;
 }
 

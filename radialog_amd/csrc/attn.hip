@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void attention_k(AttnArgs a, int TkP) {
 #pragma unroll
         for (int kc = 0; kc < DC; ++kc) {
             V8 kf;
-            if (key < Tk) kf = as_vec8<T>(ldg16(K + (long)key * a.k_ts + kc * 32 + g * 8));
+            if (key < Tk) kf = as_vec8<T>(ldg16(a.k_perm ? K + kperm(key, kc * 32 + g * 8) : K + (long)key * a.k_ts + kc * 32 + g * 8));
             else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) kf[j] = fromf<T>(0.f);
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* 
                                                           const T* __restrict__ lbv, const T* __restrict__ cos_t,
                                                           const T* __restrict__ sin_t, const int* __restrict__ pos_ids,
                                                           T* __restrict__ qout, T* __restrict__ kcache,
-                                                          T* __restrict__ vcache, int B, int Tn) {
+                                                          T* __restrict__ vcache, int B, int Tn, int slot0) {
     typedef typename Vec8<T>::type V8;
     extern __shared__ float qs[];            // [hidden] q after the LoRA add
     constexpr int D = 128;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* 
         V8 vo;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { qs[n0 + e] = q8[e]; vo[e] = fromf<T>(v8[e]); }
-        stg16(vcache + (((size_t)b * d.heads + hh) * d.max_len + t) * D + dd, as_u4<T>(vo));
+        stg16(vcache + (((size_t)b * d.heads + hh) * d.max_len + slot0 + t) * D + dd, as_u4<T>(vo));
     }
     __syncthreads();
     if (act) {
@@ -215,19 +215,32 @@ __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* 
             ko[e] = fromf<T>(rope_one<T>(k8[e], kp, c, sn));
         }
         stg16(qout + row * H + n0, as_u4<T>(qo));
-        stg16(kcache + (((size_t)b * d.heads + hh) * d.max_len + t) * D + dd, as_u4<T>(ko));
+        stg16(kcache + ((size_t)b * d.heads + hh) * d.max_len * D + kperm(slot0 + t, dd), as_u4<T>(ko));     // fragment order per 16 positions
     }
 }
 
 void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,
                             const void* cos_t, const void* sin_t, const int* pos_ids, void* qout, void* kcache,
-                            void* vcache, int B, int T_, hipStream_t s) {
+                            void* vcache, int B, int T_, int slot0, hipStream_t s) {
     const int threads = ((d.hidden / 8 + 63) / 64) * 64;          // hidden <= 8192
     dim3 grid(T_, B), block(threads);
     const size_t smem = (size_t)d.hidden * sizeof(float);
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rope_kv_prefill_k<T>), grid, block, smem, s, d, (const T*)qkv,
                                                 (const T*)lora_bq, (const T*)lora_bv, (const T*)cos_t, (const T*)sin_t,
-                                                pos_ids, (T*)qout, (T*)kcache, (T*)vcache, B, T_));
+                                                pos_ids, (T*)qout, (T*)kcache, (T*)vcache, B, T_, slot0));
+}
+
+// test introspection: the K cache of one layer back in [B][heads][max_len][128] row-major order
+__global__ void k_unperm_k(const unsigned short* __restrict__ kc, unsigned short* __restrict__ out, int max_len, size_t total8) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece
+    if (i >= total8) return;
+    const size_t slab = i / ((size_t)max_len * 16), rem = i - slab * (size_t)max_len * 16;
+    const int pos = (int)(rem >> 4), dim = (int)(rem & 15) * 8;
+    stg16(out + slab * max_len * 128 + (size_t)pos * 128 + dim, ldg16(kc + slab * max_len * 128 + kperm(pos, dim)));
+}
+void launch_k_unperm(const void* kc, void* out, size_t slabs, int max_len, hipStream_t s) {
+    const size_t total8 = slabs * max_len * 16;
+    hipLaunchKernelGGL(k_unperm_k, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const unsigned short*)kc, (unsigned short*)out, max_len, total8);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

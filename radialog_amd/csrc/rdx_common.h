@@ -138,6 +138,14 @@ __device__ __forceinline__ float block_max(float v, float* scratch) {
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
+// K-cache layout inside one (row, head) slab [max_len][128]: every group of 16 positions is stored in the MFMA A-fragment
+// order [dim / 32][lane (g = (dim % 32) / 8, r = pos % 16)][8], so that a wave's fragment load for the scores (16 positions x
+// 32 dims) is ONE contiguous KiB instead of 16 rows x 16 bytes per quarter wave (64 tag look-ups per load instruction).
+// `dim` is a multiple of 8; max_len is a multiple of 16. V stays row-major (its reads are row-contiguous).
+__host__ __device__ __forceinline__ size_t kperm(int pos, int dim) {
+    return (size_t)(pos >> 4) * 2048 + (size_t)((((dim >> 5) * 64) + ((dim & 31) >> 3) * 16 + (pos & 15)) << 3);
+}
+
 // packed GEMM weight geometry: [n_tile16][k_chunk32][64 lanes][8 elems]; lane = (g<<4)|r holds
 // W[n_tile*16 + r][k_chunk*32 + g*8 .. +8]  -- the MFMA 16x16x32 operand fragment, 1 KiB per block.
 __host__ __device__ __forceinline__ size_t packed_elems(int n, int k) { return (size_t)((n + 15) / 16) * 16 * (size_t)k; }

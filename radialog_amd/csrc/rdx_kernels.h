@@ -47,6 +47,7 @@ struct AttnArgs {        // generic softmax(QK^T/sqrt(D)) V over strided tensors
     long o_bs, o_ts, o_hs;
     int B, H, Tq, Tk;
     int causal;                      // query i attends keys j <= i + (Tk - Tq)
+    int k_perm;                      // K is a decode KV-cache slab in the 16-position fragment order (rdx_common.h kperm), D = 128
     const uint8_t* key_mask; long km_bs;   // nullable [B][>=Tk], 1 = attend
 };
 
@@ -98,7 +99,8 @@ void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s)
 // prefill: LoRA add + RoPE + KV-cache write for T tokens of B rows; q -> qout [B*T][hidden]
 void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,
                             const void* cos_t, const void* sin_t, const int* pos_ids, void* qout, void* kcache,
-                            void* vcache, int B, int T, hipStream_t s);
+                            void* vcache, int B, int T, int slot0, hipStream_t s);     // rows land at cache slots slot0 + t
+void launch_k_unperm(const void* kc, void* out, size_t slabs, int max_len, hipStream_t s);
 // decode: LoRA + RoPE + KV append + attention over the cache for one new token per row
 struct DecAttnArgs {
     LlamaDims d;
