@@ -443,6 +443,7 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         if (R.rc) return R.rc;
         c->ld.hidden = H; c->ld.heads = f.heads; c->ld.head_dim = 128; c->ld.qkv_ld = c->ll[0].wqkv.Npad;
         c->ld.lora_r = f.lora_r; c->ld.lora_scale = f.lora_scale; c->ld.max_len = f.max_len; c->ld.max_pos = f.max_pos;
+        c->ld.k_perm = (getenv("RDX_KPERM") ? atoi(getenv("RDX_KPERM")) : (f.max_batch * f.heads <= 256)) ? 1 : 0;
         const int B = f.max_batch;
         c->kv_layer_elems = (size_t)B * f.heads * f.max_len * 128;
         ALLOC(c, c->kcache, c->kv_layer_elems * f.layers * 2);
@@ -840,7 +841,7 @@ static int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int
         at.Q = c->pq; at.q_bs = (long)T * H; at.q_ts = H; at.q_hs = 128;
         at.K = kc; at.V = vc; at.k_bs = at.v_bs = (long)f.heads * f.max_len * 128; at.k_ts = at.v_ts = 128; at.k_hs = at.v_hs = (long)f.max_len * 128;
         at.O = c->patt; at.o_bs = (long)T * H; at.o_ts = H; at.o_hs = 128;
-        at.B = B; at.H = f.heads; at.Tq = T; at.Tk = keep + T; at.causal = 1; at.k_perm = 1; at.key_mask = c->key_mask; at.km_bs = f.max_len;
+        at.B = B; at.H = f.heads; at.Tq = T; at.Tk = keep + T; at.causal = 1; at.k_perm = c->ld.k_perm; at.key_mask = c->key_mask; at.km_bs = f.max_len;
         launch_attention(dt, 128, at, s);
         { GemmArgs a = gargs(c->patt, H, L.wo, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H; run_gemm(c, a, EPI_RESID); }
         launch_rmsnorm(dt, c->px, L.mlp_norm, c->pxn, (int)M, H, f.rms_eps, s);
@@ -1103,7 +1104,7 @@ extern "C" int rdx_kv_read(rdx_ctx* c, int layer, int which, void* dst) {
     if (!c || !c->finalized || !c->cfg.enable_llama) return fail(c, -1, "rdx_kv_read: no llama state");
     if (layer < 0 || layer >= c->cfg.layers || !dst) return fail(c, -1, "rdx_kv_read: bad arguments");
     if (which) HIPCHK(c, hipMemcpyAsync(dst, kv_ptr(c, c->vcache, layer), c->kv_layer_elems * 2, hipMemcpyDeviceToDevice, c->stream));
-    else launch_k_unperm(kv_ptr(c, c->kcache, layer), dst, c->kv_layer_elems / ((size_t)c->cfg.max_len * 128), c->cfg.max_len, c->stream);   // K: back from the fragment order
+    else launch_k_unperm(kv_ptr(c, c->kcache, layer), dst, c->kv_layer_elems / ((size_t)c->cfg.max_len * 128), c->cfg.max_len, c->ld.k_perm, c->stream);   // K: back from the fragment order
     return 0;
 }
 

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* 
             ko[e] = fromf<T>(rope_one<T>(k8[e], kp, c, sn));
         }
         stg16(qout + row * H + n0, as_u4<T>(qo));
-        stg16(kcache + ((size_t)b * d.heads + hh) * d.max_len * D + kperm(slot0 + t, dd), as_u4<T>(ko));     // fragment order per 16 positions
+        stg16(kcache + ((size_t)b * d.heads + hh) * d.max_len * D + kperm(slot0 + t, dd, d.k_perm), as_u4<T>(ko));     // fragment order per 16 positions
     }
 }
 
@@ -231,16 +231,16 @@ void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, cons
 }
 
 // test introspection: the K cache of one layer back in [B][heads][max_len][128] row-major order
-__global__ void k_unperm_k(const unsigned short* __restrict__ kc, unsigned short* __restrict__ out, int max_len, size_t total8) {
+__global__ void k_unperm_k(const unsigned short* __restrict__ kc, unsigned short* __restrict__ out, int max_len, size_t total8, int perm) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one 16-byte piece
     if (i >= total8) return;
     const size_t slab = i / ((size_t)max_len * 16), rem = i - slab * (size_t)max_len * 16;
     const int pos = (int)(rem >> 4), dim = (int)(rem & 15) * 8;
-    stg16(out + slab * max_len * 128 + (size_t)pos * 128 + dim, ldg16(kc + slab * max_len * 128 + kperm(pos, dim)));
+    stg16(out + slab * max_len * 128 + (size_t)pos * 128 + dim, ldg16(kc + slab * max_len * 128 + kperm(pos, dim, perm)));
 }
-void launch_k_unperm(const void* kc, void* out, size_t slabs, int max_len, hipStream_t s) {
+void launch_k_unperm(const void* kc, void* out, size_t slabs, int max_len, int perm, hipStream_t s) {
     const size_t total8 = slabs * max_len * 16;
-    hipLaunchKernelGGL(k_unperm_k, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const unsigned short*)kc, (unsigned short*)out, max_len, total8);
+    hipLaunchKernelGGL(k_unperm_k, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, s, (const unsigned short*)kc, (unsigned short*)out, max_len, total8, perm);
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -95,7 +95,7 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
             if (u >= u0 && u < u1 && gb < limit) {
                 const int j = min(gb + r, d.max_len - 1);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) kr[u][c] = ldg16(kc + kperm(j, c * 32 + g * 8));
+                for (int c = 0; c < 4; ++c) kr[u][c] = ldg16(kc + kperm(j, c * 32 + g * 8, d.k_perm));
                 kmw[u] = *reinterpret_cast<const unsigned*>(km + min(gb + 4 * g, d.max_len - 4));
             }
         }
@@ -195,7 +195,7 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
 #pragma unroll
             for (int e = 0; e < 8; ++e) { qo[e] = fromf<T>(q8n[e]); ko[e] = fromf<T>(k8[e]); vo[e] = fromf<T>(v8[e]); }
             *reinterpret_cast<u4*>(qT + doct * 8) = as_u4<T>(qo);
-            stg16(kc + kperm(slot, doct * 8), as_u4<T>(ko));      // K rows live in the 16-position fragment order (rdx_common.h)
+            stg16(kc + kperm(slot, doct * 8, d.k_perm), as_u4<T>(ko));      // K rows live in the 16-position fragment order (rdx_common.h)
             stg16(vc + (size_t)slot * D + doct * 8, as_u4<T>(vo));
         }
     }
@@ -239,7 +239,7 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
                 const int gb = (gi + t * CW) * 16;
                 const int j = min(gb + r, d.max_len - 1);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) kf[t][c] = ldg16(kc + kperm(j, c * 32 + g * 8));
+                for (int c = 0; c < 4; ++c) kf[t][c] = ldg16(kc + kperm(j, c * 32 + g * 8, d.k_perm));
                 mw[t] = *reinterpret_cast<const unsigned*>(km + min(gb + 4 * g, d.max_len - 4));
             }
             score_group(kf[0], mw[0], gi * 16);

@@ -142,8 +142,11 @@ __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 // order [dim / 32][lane (g = (dim % 32) / 8, r = pos % 16)][8], so that a wave's fragment load for the scores (16 positions x
 // 32 dims) is ONE contiguous KiB instead of 16 rows x 16 bytes per quarter wave (64 tag look-ups per load instruction).
 // `dim` is a multiple of 8; max_len is a multiple of 16. V stays row-major (its reads are row-contiguous).
-__host__ __device__ __forceinline__ size_t kperm(int pos, int dim) {
-    return (size_t)(pos >> 4) * 2048 + (size_t)((((dim >> 5) * 64) + ((dim & 31) >> 3) * 16 + (pos & 15)) << 3);
+// The order is chosen per context (LlamaDims::k_perm): contexts of up to 8 rows (the 16-wave latency attention: batch-1 attention
+// 8.7 -> 7.3 us) use it, larger ones keep K row-major (the 4-wave throughput attention measured 1.5 us per launch slower with it).
+__host__ __device__ __forceinline__ size_t kperm(int pos, int dim, int perm = 1) {
+    return perm ? (size_t)(pos >> 4) * 2048 + (size_t)((((dim >> 5) * 64) + ((dim & 31) >> 3) * 16 + (pos & 15)) << 3)
+                : (size_t)pos * 128 + dim;
 }
 
 // packed GEMM weight geometry: [n_tile16][k_chunk32][64 lanes][8 elems]; lane = (g<<4)|r holds

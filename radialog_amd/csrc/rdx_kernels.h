@@ -60,6 +60,7 @@ struct LlamaDims {
     float lora_scale;
     int max_len;         // KV slots per (b, head)
     int max_pos;
+    int k_perm;          // K cache slabs in the 16-position fragment order (rdx_common.h kperm) instead of row-major
 };
 
 void launch_pack_weight(int dtype, const float* src, void* dst, int N, int K, int Npad, const int* rowmap, hipStream_t s);
@@ -100,7 +101,7 @@ void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s)
 void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,
                             const void* cos_t, const void* sin_t, const int* pos_ids, void* qout, void* kcache,
                             void* vcache, int B, int T, int slot0, hipStream_t s);     // rows land at cache slots slot0 + t
-void launch_k_unperm(const void* kc, void* out, size_t slabs, int max_len, hipStream_t s);
+void launch_k_unperm(const void* kc, void* out, size_t slabs, int max_len, int perm, hipStream_t s);
 // decode: LoRA + RoPE + KV append + attention over the cache for one new token per row
 struct DecAttnArgs {
     LlamaDims d;

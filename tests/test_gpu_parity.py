@@ -260,11 +260,14 @@ def test_step_graph_replays_after_generate_keep_the_handoff_sound(engine, cfg):
     assert torch.equal(first, toks)
 
 
-def test_batch18_greedy_tokens_match_oracle(cfg, cpu_w):
+@pytest.mark.parametrize("kperm", [1, 0])
+def test_batch18_greedy_tokens_match_oracle(cfg, cpu_w, kperm, monkeypatch):
     """16 < batch <= 32 takes the LDS-staged weight-streaming GEMM (csrc/skinny32.hip) for every decode projection and
     the lm_head, and the 4-wave throughput attention; tokens and logits must match the oracle row by row."""
     from oracle import ref_cpu
     from radialog_amd.engine import RdxEngine, synth_getter
+    # K cache layout (read at rdx_create): 16-position fragment order (small contexts) / row-major (what batch * heads > 256 gets)
+    monkeypatch.setenv("RDX_KPERM", str(kperm))
     B, T, N = 18, 96, 8
     ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, pad_rows=True, seed=3)
     qf = synth.synth("t.qf18", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
