@@ -117,14 +117,18 @@ int rdx_hidden_read(rdx_ctx* ctx, void* dst /*model dtype [B][hidden]: decoder o
  *   what = 0: one decode step (whole graph) at the current state, `iters` replays
  *   what = 1: the gate/up SwiGLU weight-streaming GEMV of every layer in turn, `iters` sweeps -> ms per launch
  *   what = 2: ... the QKV GEMV, 3: o_proj, 4: down_proj, 5: lm_head, 6: decode attention (re-appends the current KV row);
- *   what + 10: the same unit on layer 0 only (weights stay cache resident) */
+ *   what + 10: the same unit on layer 0 only (weights stay cache resident)
+ *   At batch >= 3 the RMSNorm in front of QKV / gate-up / lm_head is a launch of its own: it runs once, outside the timed region, and
+ *   units 1, 2, 5 time the GEMM launches alone. */
 int rdx_time(rdx_ctx* ctx, int what, int iters, float* ms_host);
 /* debug (RDX_MEGA only): one eager decode step of the chained decode-layer kernel with per-workgroup timestamps,
  * host[wg*4 + 0..3] = {start, inputs ready, end (100 MHz ticks), role}; the caller sizes `host` for max_wgs entries */
 int rdx_mega_trace(rdx_ctx* ctx, long long* host, int max_wgs);
 /* debug: 8 timestamps (100 MHz ticks) of workgroup (0,0) of the stand-alone decode-attention kernel of `layer` */
 int rdx_attn_trace(rdx_ctx* ctx, int layer, long long* host);
-/* debug: per-workgroup timestamps of one stand-alone decode GEMV (what: 1 gate/up, 2 qkv, 4 down), host[tile*8 + 0..5] */
+/* debug: per-workgroup timestamps of one stand-alone decode GEMV (what: 1 gate/up, 2 qkv, 4 down), host[tile*8 + 0..5]; the
+ * persistent batch >= 3 kernels (xstat32.hip) write one record per WORKGROUP: entry, first trip's K loop done, first trip done, last
+ * trip begins, its K loop done, end, [6] = trips, [7] = XCC id (tools/xs_trace.py) */
 int rdx_gemv_trace(rdx_ctx* ctx, int what, int layer, long long* host, int max_tiles);
 
 /* one bare GEMM through the production kernels: out = epilogue(X . W^T); X/resid/norm_w/out model dtype, W [N][K] and
