@@ -302,7 +302,7 @@ def _production_width_weights(layers):
 
 
 @pytest.mark.parametrize("B,fp8,layers,tail", [(20, False, 1, 0), (20, True, 1, 0), (8, False, 1, 0), (16, True, 1, 0), (5, False, 1, 0),
-                                               (3, False, 1, 0), (4, True, 1, 0),
+                                               (3, False, 1, 0), (4, True, 1, 0), (1, False, 1, 0), (2, False, 1, 0), (1, True, 1, 0),
                                                (20, False, 2, 0), (20, False, 2, 1)])
 def test_batch20_production_width_layer_matches_oracle(B, fp8, layers, tail, monkeypatch):
     """Batch 3-32 at the production widths (hidden 4096, inter 11008, vocab 32001; one decoder layer so that the oracle
@@ -322,7 +322,7 @@ def test_batch20_production_width_layer_matches_oracle(B, fp8, layers, tail, mon
                                                                       (k.endswith("_proj.weight") or k.endswith("lora_A.weight"))) else v)
                  for k, v in cpu_w.items()}
     T, N = 96, 5
-    ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, pad_rows=True, seed=5)
+    ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, pad_rows=(B > 1), seed=5)
     qf = synth.synth("t.qf20", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
     for dtype in (("bf16",) if (fp8 or layers > 1 or B != 20) else ("bf16", "f16")):
         eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=128, lora=True, vision=False, weights_fp8=fp8)
