@@ -467,7 +467,8 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
             for (int l = 0; l < f.layers; ++l) {
                 const LlamaLayer& L = c->ll[l];
                 ml[l] = MegaLayer{L.wqkv.w, L.wo.w, L.wgu.w, L.wdown.w, L.attn_norm, L.mlp_norm, L.lora_bq, L.lora_bv,
-                                  (char*)c->kcache + (size_t)l * c->kv_layer_elems * 2, (char*)c->vcache + (size_t)l * c->kv_layer_elems * 2};
+                                  (char*)c->kcache + (size_t)l * c->kv_layer_elems * 2, (char*)c->vcache + (size_t)l * c->kv_layer_elems * 2,
+                                  L.wqkv.w8, L.wo.w8, L.wgu.w8, L.wdown.w8, L.wqkv.scale, L.wo.scale, L.wgu.scale, L.wdown.scale};
             }
             ALLOC(c, c->d_mlayers, ml.size() * sizeof(MegaLayer));
             HIPCHK(c, hipMemcpy(c->d_mlayers, ml.data(), ml.size() * sizeof(MegaLayer), hipMemcpyHostToDevice));
@@ -889,9 +890,8 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
     // the hand-off counter shards of the fused launches are cleared by greedy_step_k at the end of the previous step
     // (and of the prefill): a memset node at the head of the step graph was observed to race with the first producers
     // RDX_CHAIN: units chained inside one launch by the fence-free hand-off (mega.hip roles without attention)
-    // (the chained roles stream model-dtype weights only: with fp8 weights the stand-alone fp8 GEMVs are faster)
     const bool chain = c->chain_mlp && mega_supported(c->ld, f.inter, B) && attn_oproj16_supported(c->ld, f.hidden, f.hidden, B) &&
-                       c->fuse_attn_oproj == 2 && !c->ll[0].wdown.w8;
+                       c->fuse_attn_oproj == 2;
     MegaArgs ma;
     if (chain) {
         memset(&ma, 0, sizeof(ma));
@@ -899,6 +899,8 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         ma.dx = c->dx; ma.dqkv = c->dqkv; ma.datt = c->datt; ma.dgu = c->dgu; ma.cos_t = c->rope_cos; ma.sin_t = c->rope_sin;
         ma.cur_rope = c->d_cur_rope; ma.pos = c->d_pos; ma.slot_b = c->d_slot; ma.key_mask = c->key_mask; ma.ctr = c->d_mctr; ma.err = c->d_err;
         ma.naps = c->mega_naps; ma.trace = nullptr;
+        const LlamaLayer& L0 = c->ll[0];        // fp8 weights: the chained roles stream the e4m3 bytes too
+        ma.w8 = (L0.wqkv.w8 && L0.wo.w8 && L0.wgu.w8 && L0.wdown.w8 && f.hidden % 64 == 0 && f.inter % 64 == 0) ? 1 : 0;
     }
     for (int l = 0; l < f.layers; ++l) {
         const LlamaLayer& L = c->ll[l];

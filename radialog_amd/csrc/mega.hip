@@ -233,7 +233,7 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
 
 // OCC = waves per SIMD the register budget is sized for: 8 -> <= 64 VGPRs, two workgroups per CU (attention keeps a
 // small K window and loads V late); 4 -> <= 128 VGPRs, one workgroup per CU (attention as in the stand-alone kernel)
-template <typename T, int OCC, bool WITH_ATT>
+template <typename T, int OCC, bool WITH_ATT, bool W8 = false>
 __global__ __launch_bounds__(MG_THREADS, OCC) void decode_layers_k(MegaArgs ma) {
     extern __shared__ __attribute__((aligned(16))) unsigned char msm[];
     const int per_layer = ma.nwg[0] + ma.nwg[1] + ma.nwg[2] + ma.nwg[3] + ma.nwg[4];
@@ -250,9 +250,9 @@ __global__ __launch_bounds__(MG_THREADS, OCC) void decode_layers_k(MegaArgs ma) 
 #define MG_DONE(role) do { if (tr && threadIdx.x == 0) { tr[2] = (long long)__builtin_amdgcn_s_memrealtime(); tr[3] = (role); } } while (0)
 
     if (rb < ma.nwg[MG_QKV]) {
-        MegaGemm g = {ma.dx, H, L.wqkv, nullptr, 0, ma.dqkv, ma.d.qkv_ld, B, ma.qkv_n, H, L.attn_norm, ma.eps};
+        MegaGemm g = {ma.dx, H, L.wqkv, nullptr, 0, ma.dqkv, ma.d.qkv_ld, B, ma.qkv_n, H, L.attn_norm, ma.eps, L.wqkv8, L.sqkv};
         // first layer of the launch: the kernel boundary already ordered it after the previous launch
-        mega_tile<T, EPI_NONE, true, 4, 2>(g, rb, ma.tiles[MG_QKV], msm,
+        mega_tile<T, EPI_NONE, true, 4, 2, WaitSharded, 4, false, W8>(g, rb, ma.tiles[MG_QKV], msm,
                                            WaitSharded{prev_down, li ? ma.nwg[MG_DOWN] : 0, ma.err, ma.naps, tr});
         publish_sc1(ctr + MG_QKV * MG_CTR_STRIDE, rb);
         MG_DONE(MG_QKV);
@@ -274,24 +274,24 @@ __global__ __launch_bounds__(MG_THREADS, OCC) void decode_layers_k(MegaArgs ma) 
     }
     rb -= ma.nwg[MG_ATT];
     if (rb < ma.nwg[MG_O]) {
-        MegaGemm g = {ma.datt, H, L.wo, ma.dx, H, ma.dx, H, B, H, H, nullptr, 0.f};
-        mega_tile<T, EPI_RESID, false, 1, 2>(g, rb, ma.tiles[MG_O], msm, WaitSharded{ctr + MG_ATT * MG_CTR_STRIDE, (li || ma.r_begin != MG_O) ? ma.nwg[MG_ATT] : 0, ma.err, ma.naps, tr});
+        MegaGemm g = {ma.datt, H, L.wo, ma.dx, H, ma.dx, H, B, H, H, nullptr, 0.f, L.wo8, L.so};
+        mega_tile<T, EPI_RESID, false, 1, 2, WaitSharded, 4, false, W8>(g, rb, ma.tiles[MG_O], msm, WaitSharded{ctr + MG_ATT * MG_CTR_STRIDE, (li || ma.r_begin != MG_O) ? ma.nwg[MG_ATT] : 0, ma.err, ma.naps, tr});
         publish_sc1(ctr + MG_O * MG_CTR_STRIDE, rb);
         MG_DONE(MG_O);
         return;
     }
     rb -= ma.nwg[MG_O];
     if (rb < ma.nwg[MG_GU]) {
-        MegaGemm g = {ma.dx, H, L.wgu, nullptr, 0, ma.dgu, ma.inter, B, 2 * ma.inter, H, L.mlp_norm, ma.eps};
-        mega_tile<T, EPI_SILU_MUL, true, 4, 2>(g, rb, ma.tiles[MG_GU], msm, WaitSharded{ctr + MG_O * MG_CTR_STRIDE, (li || ma.r_begin != MG_GU) ? ma.nwg[MG_O] : 0, ma.err, ma.naps, tr});
+        MegaGemm g = {ma.dx, H, L.wgu, nullptr, 0, ma.dgu, ma.inter, B, 2 * ma.inter, H, L.mlp_norm, ma.eps, L.wgu8, L.sgu};
+        mega_tile<T, EPI_SILU_MUL, true, 4, 2, WaitSharded, 4, false, W8>(g, rb, ma.tiles[MG_GU], msm, WaitSharded{ctr + MG_O * MG_CTR_STRIDE, (li || ma.r_begin != MG_GU) ? ma.nwg[MG_O] : 0, ma.err, ma.naps, tr});
         publish_sc1(ctr + MG_GU * MG_CTR_STRIDE, rb);
         MG_DONE(MG_GU);
         return;
     }
     rb -= ma.nwg[MG_GU];
     {
-        MegaGemm g = {ma.dgu, ma.inter, L.wdown, ma.dx, H, ma.dx, H, B, H, ma.inter, nullptr, 0.f};
-        mega_tile<T, EPI_RESID, false, 1, 6>(g, rb, ma.tiles[MG_DOWN], msm, WaitSharded{ctr + MG_GU * MG_CTR_STRIDE, (li || ma.r_begin != MG_DOWN) ? ma.nwg[MG_GU] : 0, ma.err, ma.naps, tr});
+        MegaGemm g = {ma.dgu, ma.inter, L.wdown, ma.dx, H, ma.dx, H, B, H, ma.inter, nullptr, 0.f, L.wdown8, L.sdown};
+        mega_tile<T, EPI_RESID, false, 1, 6, WaitSharded, 4, false, W8>(g, rb, ma.tiles[MG_DOWN], msm, WaitSharded{ctr + MG_GU * MG_CTR_STRIDE, (li || ma.r_begin != MG_DOWN) ? ma.nwg[MG_GU] : 0, ma.err, ma.naps, tr});
         publish_sc1(ctr + MG_DOWN * MG_CTR_STRIDE, rb);
         MG_DONE(MG_DOWN);
     }
@@ -375,9 +375,11 @@ void launch_decode_roles(int dtype, MegaArgs ma, int R0, int R1, int occ, hipStr
             static bool attr_set[2] = {false, false};
             if (!attr_set[dtype & 1]) {
                 hipFuncSetAttribute((const void*)decode_layers_k<T, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+                hipFuncSetAttribute((const void*)decode_layers_k<T, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
                 attr_set[dtype & 1] = true;
             }
-            hipLaunchKernelGGL((decode_layers_k<T, 4, false>), grid, block, big, s, ma);
+            if (ma.w8) hipLaunchKernelGGL((decode_layers_k<T, 4, false, true>), grid, block, big, s, ma);
+            else hipLaunchKernelGGL((decode_layers_k<T, 4, false>), grid, block, big, s, ma);
         }
         else if (occ == 8) hipLaunchKernelGGL((decode_layers_k<T, 8, true>), grid, block, smem, s, ma);
         else hipLaunchKernelGGL((decode_layers_k<T, 4, true>), grid, block, smem, s, ma);

@@ -121,12 +121,15 @@ void launch_attn_oproj(int dtype, const DecAttnArgs& a, const GemmArgs& g, int B
 
 // Chained decode-layer kernel (mega.hip): QKV GEMV -> attention -> o_proj -> gate/up -> down of `nlayers` consecutive
 // layers in ONE launch, units chained by counter hand-offs instead of kernel boundaries (batch <= 2).
-struct MegaLayer { const void *wqkv, *wo, *wgu, *wdown, *attn_norm, *mlp_norm, *lbq, *lbv; void *kcache, *vcache; };
+struct MegaLayer { const void *wqkv, *wo, *wgu, *wdown, *attn_norm, *mlp_norm, *lbq, *lbv; void *kcache, *vcache;
+                   // fp8 weights (e4m3, 64-deep fragment order) + per-row scales, null when the model dtype copy is streamed
+                   const void *wqkv8, *wo8, *wgu8, *wdown8; const float *sqkv, *so, *sgu, *sdown; };
 struct MegaArgs {
     const MegaLayer* layers;         // device table, one entry per decoder layer
     int layer0;                      // first layer of this launch
     LlamaDims d;
     int inter, qkv_n, B;
+    int w8;                          // chained roles without attention: stream the fp8 weights (every projection quantised)
     float eps;
     void *dx, *dqkv, *datt, *dgu;    // [B][hidden] residual stream, [B][qkv_ld], [B][hidden], [B][inter]
     const void *cos_t, *sin_t, *cur_rope;
