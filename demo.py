@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from radialog_amd import synth                                              # noqa: E402
 from radialog_amd.blip2_qformer import Config, tasks                        # noqa: E402
 from radialog_amd.chexpert_model import CHEXPERT_COLS, ChexpertClassifier   # noqa: E402
-from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM             # noqa: E402
+from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM, PeftModelForCausalLM   # noqa: E402
 from radialog_amd.prompter import new_conversation, report_prompt          # noqa: E402
 from radialog_amd.tokenizer import load_tokenizer                          # noqa: E402
 
@@ -34,26 +34,19 @@ def parse_args():
     p.add_argument("--lora_model", default=None, help="adapter dir (adapter_model.bin incl. img_proj_layer)")
     p.add_argument("--max_new_tokens", type=int, default=300)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
-    return p.parse_args()
+    p.add_argument("--synthetic", action="store_true", help="run on the deterministic random-init weights (no checkpoints are "
+                   "reachable without a network); without it every missing weight file is an error")
+    args = p.parse_args()
+    if args.synthetic:
+        args.options = (args.options or []) + ["model.synthetic=true"]
+    return args
 
 
 def load_image(path, crop=448):
-    """demo.py:173-218 (remap_to_uint8 -> PIL 'L') + the inference transform (ReportDataset.py:96-106); crop=488 gives the
-    findings classifier's `cp_transforms` (demo.py:169)."""
-    import numpy as np
-    from PIL import Image
-    arr = np.asarray(Image.open(path)).astype(float)
-    arr -= arr.min()
-    arr /= max(arr.max(), 1e-12)
-    img = Image.fromarray((arr * 255).astype(np.uint8)).convert("L")
-    w, h = img.size
-    s = 512 / min(w, h)                                                       # Resize(512): shorter side, bilinear
-    img = img.resize((max(512, round(w * s)), max(512, round(h * s))), Image.BILINEAR)
-    w, h = img.size
-    l, t = (w - crop) // 2, (h - crop) // 2                                   # CenterCrop(448 | 488)
-    img = img.crop((l, t, l + crop, t + crop))
-    x = torch.from_numpy(np.asarray(img, dtype=np.float32) / 255.0)[None]     # ToTensor
-    return torch.repeat_interleave(x, 3, dim=0)                               # ExpandChannels
+    """demo.py:205-218 (load_image / remap_to_uint8 -> PIL 'L') + the inference transform (ReportDataset.py:96-106, demo.py:144);
+    crop=488 gives the findings classifier's `cp_transforms` (demo.py:169)."""
+    from radialog_amd import transforms
+    return transforms.create_chest_xray_transform_for_inference(512, center_crop_size=crop)(transforms.load_image(path))
 
 
 def init_blip(cfg):
@@ -63,10 +56,11 @@ def init_blip(cfg):
 
 def init_vicuna(args):
     tok = load_tokenizer(args.vicuna)
-    lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16,
-                                                  device_map="auto", max_batch=1, max_len=1024)
+    dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=dt, device_map="auto", max_batch=1, max_len=1024,
+                                                  synthetic=args.synthetic)
     if args.lora_model:
-        lang_model.load_adapter(args.lora_model)
+        lang_model = PeftModelForCausalLM.from_pretrained(lang_model, args.lora_model, torch_dtype=dt)
     lang_model.reuse_prefix_kv = True       # chat turns re-send the whole conversation: keep the KV rows of the shared token prefix
     return lang_model.eval(), tok
 
@@ -75,6 +69,8 @@ def init_chexpert_predictor(args):
     """demo.py:155-170: the classifier that fills "Predicted Findings:" for images without precomputed labels."""
     if args.chexpert_ckpt:
         return ChexpertClassifier.load_from_checkpoint(args.chexpert_ckpt, num_classes=14, class_names=CHEXPERT_COLS).eval().half()
+    if not args.synthetic:
+        raise RuntimeError("no --chexpert_ckpt given (use --findings / --no-classifier, or --synthetic for random-init weights)")
     from radialog_amd.engine import synth_getter
     m = ChexpertClassifier(num_classes=14)
     return m.set_weight_getter(synth_getter(m.cfg, torch.device("cuda", 0), lora=False)).eval().half()

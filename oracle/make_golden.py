@@ -15,6 +15,10 @@ Pinned here:
   projector  biovil_t/modules.py MLP(use_1x1_convs=True) in eval mode (+ the reshape scramble + LayerNorm restated
              with torch ops exactly as blip2_qformer.py:469 writes them)
   rope/rms   LlamaRotaryEmbedding tables, LlamaRMSNorm rows
+  vit_pooler biovil_t/transformer.py VisionTransformerPooler (Block, MultiHeadAttentionLayer, SinePositionEmbedding are the
+             reference's own code) in eval mode, two-image call. Its three timm==0.4.12 imports are shimmed in-process: DropPath
+             (identity in eval), trunc_normal_ (init only, overwritten by our weights) and Mlp, restated as timm 0.4.12 defines
+             it (fc1 -> act -> drop -> fc2 -> drop): the Mlp stays 'parity unpinned', everything else in the pooler is pinned.
 """
 import importlib.util
 import os
@@ -203,6 +207,59 @@ def make_projector():
     print("projector:", pp.shape, emb.shape)
 
 
+def make_vit_pooler():
+    import types
+    import torch.nn as nn
+
+    class Mlp(nn.Module):                     # timm==0.4.12 timm/models/layers/mlp.py, restated (third-party, absent)
+        def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+            super().__init__()
+            out_features = out_features or in_features
+            hidden_features = hidden_features or in_features
+            self.fc1 = nn.Linear(in_features, hidden_features)
+            self.act = act_layer()
+            self.fc2 = nn.Linear(hidden_features, out_features)
+            self.drop = nn.Dropout(drop)
+
+        def forward(self, x):
+            return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+
+    class DropPath(nn.Module):                # stochastic depth: the identity in eval mode
+        def __init__(self, drop_prob=None):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    timm = types.ModuleType("timm")
+    timm.models = types.ModuleType("timm.models")
+    timm.models.layers = types.ModuleType("timm.models.layers")
+    timm.models.layers.Mlp, timm.models.layers.DropPath = Mlp, DropPath
+    timm.models.layers.trunc_normal_ = torch.nn.init.trunc_normal_
+    sys.modules.update({"timm": timm, "timm.models": timm.models, "timm.models.layers": timm.models.layers})
+    try:
+        ref = _load("biovil_t/transformer.py", "ref_transformer")
+    finally:
+        for k in ("timm", "timm.models", "timm.models.layers"):
+            sys.modules.pop(k, None)
+    v = VisionCfg(img=128, stem=32, planes=(32, 64, 128, 256), blocks=(1, 2, 2, 1), b2v=64, proj=352, pool_blocks=2, pool_heads=2)
+    g, C = v.grid, v.b2v
+    pooler = ref.VisionTransformerPooler(input_dim=C, grid_shape=(g, g), num_heads=v.pool_heads, num_blocks=v.pool_blocks)
+    W = synth.make_weights(synth.vision_specs(v))
+    P = "visual_encoder.encoder.vit_pooler."
+    sd = {k[len(P):]: t for k, t in W.items() if k.startswith(P)}
+    missing, unexpected = pooler.load_state_dict(sd, strict=False)
+    assert not unexpected and not missing, (missing, unexpected)          # pos_embed is a non-persistent buffer
+    pooler.eval()
+    cur = synth.synth("golden.pool_cur", (2, C, g, g), -1.5, 1.5)
+    prev = synth.synth("golden.pool_prev", (2, C, g, g), -1.5, 1.5)
+    with torch.no_grad():
+        out = pooler(current_image=cur, previous_image=prev)
+    np.savez_compressed(os.path.join(OUT, "vit_pooler.npz"), cur=cur.numpy(), prev=prev.numpy(), out=out.numpy(),
+                        pos_embed=pooler.pos_embed.numpy())
+    print("vit_pooler:", out.shape, float(out.abs().mean()))
+
+
 def make_prompter():
     """utils/prompter.py Prompter('vicuna_v11') outputs (the reference resolves data/templates relative to the CWD)."""
     import json
@@ -226,7 +283,7 @@ def make_prompter():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["llama", "qformer", "projector", "prompter"]
+    which = sys.argv[1:] or ["llama", "qformer", "projector", "prompter", "vit_pooler"]
     if "llama" in which:
         make_llama()
     if "qformer" in which:
@@ -235,3 +292,5 @@ if __name__ == "__main__":
         make_projector()
     if "prompter" in which:
         make_prompter()
+    if "vit_pooler" in which:
+        make_vit_pooler()

@@ -239,21 +239,35 @@ def positions_from_mask(mask: torch.Tensor) -> torch.Tensor:
 
 
 class LlamaOracle:
-    def __init__(self, W: Dict[str, torch.Tensor], cfg, dtype=torch.float16, lora: bool = True):
+    def __init__(self, W: Dict[str, torch.Tensor], cfg, dtype=torch.float16, lora: bool = True, exact: bool = False):
         """W: fp32 (or already-rounded) tensors keyed by reference state_dict names; cast to `dtype` here
-        the way `.half()` does for every floating parameter/buffer (demo.py:234)."""
-        self.cfg, self.dtype = cfg, dtype
+        the way `.half()` does for every floating parameter/buffer (demo.py:234).
+        exact=True: the same op sequence and the same rounding points, but every contraction (linear layers, Q.K^T, P.V)
+        is accumulated in fp64 before its single rounding to `dtype` -- the order-independent value both torch's CPU
+        kernels (fp32 accumulation in their blocking order) and the HIP kernels (fp32 MFMA accumulation in theirs)
+        approximate. Used by the parity tests to bound each side's accumulation-order noise."""
+        self.cfg, self.dtype, self.exact = cfg, dtype, exact
         self.W = {k: v.to(dtype) for k, v in W.items()}
         self.lora = lora and any("lora_A" in k for k in W)
         self.cos, self.sin = rope_tables(cfg.head_dim, cfg.max_pos, cfg.rope_base, dtype)
 
     # -- pieces ---------------------------------------------------------------------------------------
+    def _linear(self, x, w, b=None):
+        if not self.exact:
+            return F.linear(x, w, b)
+        return F.linear(x.double(), w.double(), None if b is None else b.double()).to(x.dtype)
+
+    def _mm(self, a, b):
+        if not self.exact:
+            return torch.matmul(a, b)
+        return torch.matmul(a.double(), b.double()).to(a.dtype)
+
     def _proj(self, x, L, nm):
         W = self.W
-        y = F.linear(x, W[L + f"self_attn.{nm}.weight"])
+        y = self._linear(x, W[L + f"self_attn.{nm}.weight"])
         a_key = L + f"self_attn.{nm}.lora_A.weight"
         if self.lora and a_key in W:
-            y = y + F.linear(F.linear(x, W[a_key]), W[L + f"self_attn.{nm}.lora_B.weight"]) * self.cfg.lora_scale
+            y = y + self._linear(self._linear(x, W[a_key]), W[L + f"self_attn.{nm}.lora_B.weight"]) * self.cfg.lora_scale
         return y
 
     def embed(self, ids: torch.Tensor, qformer_embs: Optional[torch.Tensor]) -> torch.Tensor:
@@ -262,7 +276,7 @@ class LlamaOracle:
         E = W["model.embed_tokens.weight"]
         if qformer_embs is None:
             return F.embedding(ids.clamp(max=E.shape[0] - 1), E)
-        img = F.linear(qformer_embs.to(self.dtype), W["model.img_proj_layer.weight"], W["model.img_proj_layer.bias"])
+        img = self._linear(qformer_embs.to(self.dtype), W["model.img_proj_layer.weight"], W["model.img_proj_layer.bias"])
         pos = split_positions(ids)
         rows = []
         for b in range(ids.shape[0]):
@@ -303,15 +317,15 @@ class LlamaOracle:
         if past is not None:
             k = torch.cat([past[0], k], dim=2)
             v = torch.cat([past[1], v], dim=2)
-        s = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(d)
+        s = self._mm(q, k.transpose(2, 3)) / math.sqrt(d)
         s = s + mask
         s = torch.max(s, torch.tensor(torch.finfo(s.dtype).min))
         p = F.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
-        o = torch.matmul(p, v).transpose(1, 2).reshape(B, T, H)
-        x = x + F.linear(o, W[L + "self_attn.o_proj.weight"])
+        o = self._mm(p, v).transpose(1, 2).reshape(B, T, H)
+        x = x + self._linear(o, W[L + "self_attn.o_proj.weight"])
         h = rmsnorm(x, W[L + "post_attention_layernorm.weight"], c.rms_eps)
-        g = F.silu(F.linear(h, W[L + "mlp.gate_proj.weight"])) * F.linear(h, W[L + "mlp.up_proj.weight"])
-        x = x + F.linear(g, W[L + "mlp.down_proj.weight"])
+        g = F.silu(self._linear(h, W[L + "mlp.gate_proj.weight"])) * self._linear(h, W[L + "mlp.up_proj.weight"])
+        x = x + self._linear(g, W[L + "mlp.down_proj.weight"])
         return x, (k, v)
 
     def forward(self, x, key_mask, pos_ids, past=None, all_logits=False, n_layers=None):
@@ -327,7 +341,7 @@ class LlamaOracle:
             new_past.append(kv)
         h = rmsnorm(x, self.W["model.norm.weight"], self.cfg.rms_eps)
         hl = h if all_logits else h[:, -1:]
-        logits = F.linear(hl, self.W["lm_head.weight"])
+        logits = self._linear(hl, self.W["lm_head.weight"])
         return logits, new_past, h
 
     # -- greedy loop (transformers==4.28.1 GenerationMixin.greedy_search, restated) --------------------

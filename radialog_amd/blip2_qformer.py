@@ -96,7 +96,7 @@ class Blip2Qformer:
     """forward_image-only restatement of Blip2Qformer (blip2_qformer.py:26-89,:467-484,:630-657)."""
 
     def __init__(self, vit_model="biovil", img_size=448, num_query_token=32, cross_attention_freq=2, dtype="bf16",
-                 cfg: Optional[RaDialogCfg] = None, max_txt_len=32, **_unused):
+                 cfg: Optional[RaDialogCfg] = None, max_txt_len=32, synthetic: bool = False, **_unused):
         if vit_model != "biovil":
             raise NotImplementedError("RaDialog only instantiates vit_model='biovil' (blip2.py:64-88)")
         base = cfg or RaDialogCfg()
@@ -109,7 +109,7 @@ class Blip2Qformer:
         self.max_txt_len = max_txt_len
         self.device = torch.device("cpu")
         self._engine = None
-        self._weights = None          # getter over reference-named fp32 tensors
+        self._weights = ("synth", None) if synthetic else None     # ("dict", reference-named fp32 tensors) once loaded
         self.training = False
 
     # -- construction ----------------------------------------------------------------------------------------------
@@ -122,27 +122,100 @@ class Blip2Qformer:
         return model
 
     def load_checkpoint_from_config(self, cfg):
-        """base_model.py:89-102: `load_finetuned` -> `finetuned` path, else `pretrained`. With no checkpoint reachable
-        (no network here) the deterministic random-init generator stands in (`synthetic: true`)."""
-        path = cfg.get("finetuned") if cfg.get("load_finetuned", False) else cfg.get("pretrained")
-        if path and os.path.isfile(str(path)):
-            self.load_checkpoint(path)
-        elif cfg.get("synthetic", True):
-            from .engine import synth_getter
+        """base_model.py:89-102: `load_finetuned` (default True) -> `finetuned` path through load_checkpoint, else `pretrained`
+        through load_from_pretrained. The frozen BioViL-T trunk is not part of those files: the reference's constructor loads it
+        from `biovil_t_image_model_proj_size_128.pt` (blip2.py:80-84, pretrained.py:48-60, downloaded into tempfile.gettempdir());
+        here `biovil_t_weights` in the config, $RDX_BIOVIL_T_WEIGHTS or that same temp-dir file name it. `synthetic: true` is the
+        explicit opt-in to the deterministic random-init weights of benchmarks and tests; without it a missing file raises."""
+        if cfg.get("synthetic", False):
             self._weights = ("synth", None)
-        else:
-            raise RuntimeError("checkpoint url or path is invalid")          # base_model.py:43-44
+            return
+        import tempfile
+        pt = cfg.get("biovil_t_weights") or os.environ.get("RDX_BIOVIL_T_WEIGHTS") or \
+            os.path.join(tempfile.gettempdir(), "biovil_t_image_model_proj_size_128.pt")
+        self.load_biovil_t(pt)
+        if cfg.get("load_finetuned", True):
+            path = cfg.get("finetuned", None)
+            assert path is not None, "Found load_finetuned is True, but finetune_path is None."
+            self.load_checkpoint(path)
+        elif cfg.get("load_pretrained", True):
+            self.load_checkpoint(cfg.get("pretrained", None))
+
+    def _state(self) -> Dict[str, torch.Tensor]:
+        if self._weights is None or self._weights[0] != "dict":
+            self._weights = ("dict", {})
+        return self._weights[1]
+
+    def load_biovil_t(self, path):
+        """ImageModel.__init__(pretrained_model_path=...) (biovil_t/model.py:56-65): the BioViL-T state dict (`encoder.*` trunk,
+        backbone_to_vit, vit_pooler; `projector.*` of the stock 128-wide projector) with every `projector` key DROPPED -- the
+        1408-wide projector of this model is not in that file -- loaded under `visual_encoder.`."""
+        if not path or not os.path.isfile(str(path)):
+            raise RuntimeError(f"BioViL-T image-model weights not found at {path!r} (no network access to download them)")
+        sd = torch.load(str(path), map_location="cpu")
+        st = self._state()
+        for k, v in sd.items():
+            if k.startswith("projector") or not torch.is_tensor(v):
+                continue
+            st["visual_encoder." + k] = v.float()
+        return self
 
     def load_checkpoint(self, url_or_filename):
-        """LAVIS checkpoint_N.pth holds {'model': state_dict} with trainable + buffer tensors only (runner_base.py:658-683);
-        the frozen BioViL-T trunk comes from its own .pt (biovil_t/pretrained.py:26-32). Both may be merged by passing
-        a combined state dict file."""
-        if not os.path.isfile(url_or_filename):
-            raise RuntimeError("checkpoint url or path is invalid")
-        ck = torch.load(url_or_filename, map_location="cpu")
+        """base_model.py:29-56 on a LAVIS `checkpoint_N.pth`: {'model': state_dict, 'optimizer': ..., 'config': ..., 'epoch': ...}
+        whose state_dict holds the trainable parameters and ALL buffers only -- parameters with requires_grad=False (the frozen
+        visual encoder: conv / BatchNorm affine / projector weights) were deleted before saving (runner_base.py:662-670), the
+        BatchNorm running statistics were not. Loaded non-strictly over what is already there, like load_state_dict(strict=False)."""
+        if not url_or_filename or not os.path.isfile(str(url_or_filename)):
+            raise RuntimeError("checkpoint url or path is invalid")                   # base_model.py:43-44
+        ck = torch.load(str(url_or_filename), map_location="cpu")
         sd = ck["model"] if isinstance(ck, dict) and "model" in ck else ck
-        self._weights = ("dict", {k: v.float() for k, v in sd.items() if torch.is_tensor(v)})
+        st = self._state()
+        for k, v in sd.items():
+            if torch.is_tensor(v) and v.is_floating_point():
+                st[k] = v.float()
         return self
+
+    load_from_pretrained = load_checkpoint                                             # blip2.py:91-110: same non-strict load
+
+    def _resolve_weights(self):
+        """Getter over the assembled state dict. Every tensor of the hot path must be present; the only family no released file
+        carries is the 1408-wide projector (random at construction in the reference and frozen, so never saved): those tensors
+        are drawn with torch's default initialisers (modules.py:43-47: Conv2d kaiming-uniform, BatchNorm2d ones/zeros), loudly."""
+        import math
+        import warnings
+        from . import synth
+        st = dict(self._weights[1])
+        v = self.cfg.vision
+        J = "visual_encoder.projector.model."
+        drawn = []
+
+        def conv_default(cout, cin):
+            bound = 1.0 / math.sqrt(cin)                   # kaiming_uniform_(a=sqrt(5)) on a 1x1 kernel
+            return (torch.rand(cout, cin, 1, 1) * 2 - 1) * bound
+
+        defaults = {J + "0.weight": lambda: conv_default(v.proj, 2 * v.b2v), J + "1.weight": lambda: torch.ones(v.proj),
+                    J + "1.bias": lambda: torch.zeros(v.proj), J + "1.running_mean": lambda: torch.zeros(v.proj),
+                    J + "1.running_var": lambda: torch.ones(v.proj), J + "3.weight": lambda: conv_default(v.proj, v.proj),
+                    J + "3.bias": lambda: (torch.rand(v.proj) * 2 - 1) / math.sqrt(v.proj)}
+        for k, mk in defaults.items():
+            if k not in st:
+                st[k] = mk()
+                drawn.append(k)
+        if drawn:
+            warnings.warn("Blip2Qformer: no loaded file holds " + ", ".join(drawn) + " -- the reference draws the 1408-wide projector at "
+                          "random when the model is constructed and never saves it (frozen); drawn here with the same initialisers "
+                          "from torch's current RNG state. Pass them in the checkpoint to reproduce a specific run.")
+        need = [k for k in {**synth.vision_specs(v), **synth.qformer_specs(self.cfg.qformer)} if ".vit_pooler." not in k]
+        missing = [k for k in need if k not in st]
+        if missing:
+            raise RuntimeError(f"checkpoint lacks {len(missing)} tensors of the image-encode path, e.g. {missing[:4]}")
+        has_pooler = any(".vit_pooler." in k for k in st)
+
+        def get(name):
+            if ".vit_pooler." in name and not has_pooler:
+                raise KeyError(name)                       # optional two-image mode (weights.vision_items)
+            return st[name]
+        return get
 
     # -- nn.Module-like surface -----------------------------------------------------------------------------------------
     def to(self, device):
@@ -166,11 +239,18 @@ class Blip2Qformer:
             return
         from .engine import RdxEngine, synth_getter
         eng = RdxEngine(self.cfg, dtype=self.dtype, device=self.device.index or 0, vision=True, llama=False)
-        kind, payload = self._weights or ("synth", None)
-        if kind == "synth":
+        if self._weights is None:
+            eng.close()
+            raise RuntimeError("Blip2Qformer has no weights: from_config with a checkpoint, load_checkpoint(...), or `synthetic: true`")
+        if self._weights[0] == "synth":
             get = synth_getter(self.cfg, eng.device)
         else:
-            get = lambda name: payload[name].to(eng.device)          # noqa: E731
+            try:
+                host = self._resolve_weights()
+            except Exception:
+                eng.close()
+                raise
+            get = lambda name: host(name).to(eng.device)          # noqa: E731
         eng.load_weights(get, vision=True, llama=False)
         self._engine = eng
 

@@ -81,10 +81,10 @@ struct rdx_ctx {
     void *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dgu = nullptr;
     float* kslab = nullptr;          // batch 3-32 decode: fp32 partial slabs [<= 4 groups][32][hidden] of a K-split projection
     int pend_groups = 0;             // launch-time state: slabs written by the last xsplit32 launch, not yet added into dx
-    int prenorm_pack = -1;           // launch-time state: >= 0 -> that launch also ran the next RMSNorm (norm tail): dxn holds the rows in this layout
     void *px = nullptr, *pxn = nullptr, *pqkv = nullptr, *pq = nullptr, *patt = nullptr, *pgu = nullptr, *pqe = nullptr, *pimg = nullptr;
     size_t prefill_rows = 0;
     int cur_B = 0, cur_T = 0, cur_max_new = 0, cur_eos = -1, cur_pad = 0;
+    int cur_steps = 0;               // tokens selected since the last prefill (1 after it): bounds rdx_decode_step
     int32_t* cur_tokens = nullptr;
     hipGraphExec_t graph = nullptr;
     int fuse_attn_oproj = 2;    // RDX_FUSE_AO: attention + o_proj in ONE launch with a fence-free hand-off: 2 = 16-wave kernel (mega.hip,
@@ -152,6 +152,16 @@ static int dalloc(rdx_ctx* c, void** p, size_t bytes) {
 }
 #define ALLOC(c, ptr, bytes) do { int rc_ = dalloc((c), (void**)&(ptr), (bytes)); if (rc_) return rc_; } while (0)
 
+// release a buffer obtained with ALLOC before it is replaced (workspaces that grow with the batch / prompt length)
+template <typename P>
+static void dfree(rdx_ctx* c, P*& p) {
+    if (!p) return;
+    auto it = std::find(c->allocs.begin(), c->allocs.end(), (void*)p);
+    if (it != c->allocs.end()) c->allocs.erase(it);
+    hipFree((void*)p);
+    p = nullptr;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // GEMM dispatch
 // ------------------------------------------------------------------------------------------------------------------
@@ -169,12 +179,6 @@ static GemmArgs gargs(const void* X, int ldx, const GemmW& W, const float* bias,
 // The RMSNorm of a projection whose rows do not fit the GEMV's LDS stage runs as its own launch in front of it; returns the
 // arguments of the GEMM proper (activations = c->dxn)
 static GemmArgs skinny_prenorm(rdx_ctx* c, GemmArgs a, int epi) {
-    if (a.norm_w && a.X == c->dx && c->prenorm_pack >= 0) {
-        // the K-split projection in front already ran this RMSNorm as its tail (xsplit32_k, XsTail), in the layout asked for
-        a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr; a.xpacked = c->prenorm_pack;
-        c->prenorm_pack = -1; c->pend_groups = 0;
-        return a;
-    }
     // (batch 3-4 rows would fit the GEMV's LDS stage with the norm fused, but the activation-stationary kernel behind a
     // stand-alone RMSNorm is faster there too: gate/up 41.7 -> 31 + 5 us at batch 4)
     bool standalone = a.norm_w && !skinny_fits_lds(a.M, a.K);
@@ -216,31 +220,20 @@ static bool down_split_ok(rdx_ctx* c, const LlamaLayer& L, int B) {
     return xsplit32_groups(dn) > 0;
 }
 
-// A K-split projection (o_proj, down_proj at batch 3-32) followed by the RMSNorm + projection `next` (norm weight, epilogue):
-// the norm runs as a tail of the K-split launch when the shapes allow (xsplit32_tail_ok), writing c->dxn in the layout `next`
-// reads; otherwise the slabs stay pending for the stand-alone RMSNorm (skinny_prenorm).
-static void launch_ksplit(rdx_ctx* c, const GemmArgs& a, int* ctr, const GemmW* next_w, const void* next_norm, int next_epi) {
-    const rdx_config& f = c->cfg;
-    const int kg = xsplit32_groups(a);
-    if (next_w && next_norm && ctr && xsplit32_tail_ok(a)) {
-        GemmArgs nx = gargs(c->dxn, f.hidden, *next_w, nullptr, nullptr, 0, a.M);
-        const int pack = xstat32_supported(nx, next_epi) ? ((nx.W8 && nx.wscale) ? 2 : 1) : 0;
-        launch_xsplit32(f.dtype, a, c->kslab, c->stream, ctr, c->d_err, next_norm, c->dx, c->dxn, f.rms_eps, pack);
-        c->prenorm_pack = pack; c->pend_groups = 0;
-    } else {
-        launch_xsplit32(f.dtype, a, c->kslab, c->stream);
-        c->pend_groups = kg;
-    }
+// A K-split projection (o_proj, down_proj at batch 3-32): its fp32 slabs stay pending for the stand-alone RMSNorm of the
+// projection that follows (skinny_prenorm), which adds them, rounds and applies the residual.
+static void launch_ksplit(rdx_ctx* c, const GemmArgs& a) {
+    launch_xsplit32(c->cfg.dtype, a, c->kslab, c->stream);
+    c->pend_groups = xsplit32_groups(a);
 }
 
-static void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split, int* ctr = nullptr, const GemmW* next_w = nullptr,
-                        const void* next_norm = nullptr, int next_epi = 0) {
+static void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split) {
     const rdx_config& f = c->cfg;
     GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, f.hidden, B);
     a.resid = c->dx; a.ldr = f.hidden;
     if (split) {
         a.xpacked = (a.W8 && a.wscale) ? 2 : 1;
-        launch_ksplit(c, a, ctr, next_w, next_norm, next_epi);
+        launch_ksplit(c, a);
     } else {
         skinny(c, a, EPI_RESID);
     }
@@ -481,6 +474,7 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)(B > 2 ? std::max(B, 32) : B) * H * 2);
         if (B > 2) ALLOC(c, c->kslab, (size_t)4 * 32 * H * sizeof(float)); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
         ALLOC(c, c->datt, (size_t)(B > 2 ? std::max(B, 32) : B) * H * 2); ALLOC(c, c->dgu, (size_t)(B > 2 ? std::max(B, 32) : B) * I * 2);
+        ALLOC(c, c->pqe, (size_t)B * 32 * f.qformer_dim * 2); ALLOC(c, c->pimg, (size_t)B * 32 * H * 2);      // image splice rows
     }
     if (f.enable_vision) {
         const int H = f.q_hidden, I = f.q_inter;
@@ -577,7 +571,13 @@ static int ensure_enc_ws(rdx_ctx* c, int B) {
     if (B <= c->enc_batch) return 0;
     const rdx_config& f = c->cfg;
     const int S_ = f.v_img, Hp = S_ + 6;
-    // buffers are re-allocated (old ones stay in allocs until destroy; batch growth is rare)
+    // the workspace grows with the largest batch seen: drain the stream, release the old buffers, allocate the new ones
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->enc_batch = 0;
+    dfree(c, c->vin);
+    for (int i = 0; i < 4; ++i) dfree(c, c->vbuf[i]);
+    dfree(c, c->cls_pooled); dfree(c, c->cls_h); dfree(c, c->cls_out);
+    dfree(c, c->v_imgemb); dfree(c, c->qx); dfree(c, c->qt); dfree(c, c->qqkv); dfree(c, c->qctx); dfree(c, c->qh); dfree(c, c->qkvx);
     const size_t act = (size_t)B * (S_ / 2) * (S_ / 2) * (size_t)std::max(f.v_stem, 1) * 2;   // conv1 output
     size_t act2 = (size_t)B * (S_ / 4) * (S_ / 4) * (size_t)f.v_planes[0] * 4 * 2;           // layer1 output
     size_t mx = std::max(act, act2);
@@ -759,11 +759,14 @@ extern "C" int rdx_encode_image2(rdx_ctx* c, const float* image, const float* pr
 static int ensure_prefill_ws(rdx_ctx* c, size_t rows) {
     if (rows <= c->prefill_rows) return 0;
     const rdx_config& f = c->cfg;
+    // grows with the largest batch x prompt length seen (test.py-style evaluation: variable prompt lengths): drain the stream,
+    // release the old buffers, then allocate; a failure leaves prefill_rows = 0 so the next call starts over
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->prefill_rows = 0;
+    dfree(c, c->px); dfree(c, c->pxn); dfree(c, c->pqkv); dfree(c, c->pq); dfree(c, c->patt); dfree(c, c->pgu);
     ALLOC(c, c->px, rows * f.hidden * 2); ALLOC(c, c->pxn, rows * f.hidden * 2);
     ALLOC(c, c->pqkv, rows * c->ld.qkv_ld * 2); ALLOC(c, c->pq, rows * f.hidden * 2);
     ALLOC(c, c->patt, rows * f.hidden * 2); ALLOC(c, c->pgu, rows * f.inter * 2);
-    ALLOC(c, c->pqe, (size_t)f.max_batch * 32 * f.qformer_dim * 2);
-    ALLOC(c, c->pimg, (size_t)f.max_batch * 32 * f.hidden * 2);
     c->prefill_rows = rows;
     return 0;
 }
@@ -812,6 +815,7 @@ static int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int
     const int dt = f.dtype, H = f.hidden;
     hipStream_t s = c->stream;
     c->cur_B = B; c->cur_T = keep + T; c->cur_max_new = max_new; c->cur_eos = eos_id; c->cur_pad = pad_id; c->cur_tokens = out_tokens;
+    c->cur_steps = 1;
 
     if (keep > 0) {
         launch_prep_append(B, T, keep, c->d_img_pos, c->d_pos_ids, c->d_pos, c->d_slot, c->d_step, c->d_unf, s);
@@ -925,7 +929,7 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
             const int kg = (B >= xs_min_rows() && c->kslab) ? xsplit32_groups(ap) : 0;
             at.out_packed = kg > 0 ? ap.xpacked : 0;
             launch_decode_attention(dt, at, B, s);
-            if (kg) launch_ksplit(c, ap, c->d_ctr + (size_t)l * 256, &L.wgu, L.mlp_norm, EPI_SILU_MUL);     // tail: the RMSNorm of gate/up
+            if (kg) launch_ksplit(c, ap);
             else skinny(c, ao, EPI_RESID);
         }
         if (chain && c->chain_mlp == 1) {
@@ -941,9 +945,7 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps;
           a.out_packed = split ? ((L.wdown.w8 && L.wdown.scale) ? 2 : 1) : 0;
           skinny(c, a, EPI_SILU_MUL); }
-        // tail: the RMSNorm of the next layer's QKV, or the final norm in front of lm_head
-        if (l + 1 < f.layers) launch_down(c, L, B, split, c->d_ctr + (size_t)l * 256 + 128, &c->ll[l + 1].wqkv, c->ll[l + 1].attn_norm, EPI_NONE);
-        else launch_down(c, L, B, split, c->d_ctr + (size_t)l * 256 + 128, &c->lm_head, c->final_norm, EPI_LOGITS);
+        launch_down(c, L, B, split);
     }
     lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
 }
@@ -1017,8 +1019,14 @@ extern "C" int rdx_gemv_trace(rdx_ctx* c, int what, int layer, long long* host, 
 extern "C" int rdx_decode_step(rdx_ctx* c, void* logits) {
     if (!c) return -1;
     if (!c->finalized || c->cur_B <= 0) return fail(c, -1, "rdx_decode_step: no prefill has run");
+    // every step appends one KV row per batch row and advances the RoPE position: refuse to walk past what the prefill reserved
+    if (c->cur_steps >= c->cur_max_new)
+        return fail(c, -1, "rdx_decode_step: all %d tokens of this prompt (max_new) have been generated; run a new prefill", c->cur_max_new);
+    if (c->cur_T + c->cur_steps > c->cfg.max_len || c->cur_T + c->cur_steps > c->cfg.max_pos)
+        return fail(c, -1, "rdx_decode_step: KV cache full (%d prompt + %d generated slots of %d)", c->cur_T, c->cur_steps, c->cfg.max_len);
     HIPCHK(c, hipSetDevice(c->device));
     decode_step_launch(c, logits, nullptr, 0);
+    ++c->cur_steps;
     HIPCHK(c, hipGetLastError());
     return 0;
 }
@@ -1090,6 +1098,7 @@ static int decode_loop(rdx_ctx* c, int B, int max_new, int eos_id, void* scores,
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     if (n_steps_host) *n_steps_host = done;
+    c->cur_steps = std::max(done, c->cur_max_new);        // the conversation is complete: further single steps need a new prefill
     int herr = 0;
     HIPCHK(c, hipMemcpy(&herr, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
     if (herr) {
@@ -1140,6 +1149,7 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
         for (int i = 0; i < iters; ++i) HIPCHK(c, hipGraphLaunch(c->graph, c->stream));
         HIPCHK(c, hipEventRecord(e1, c->stream));
         launches = iters;
+        c->cur_steps = std::max(c->cur_steps, c->cur_max_new);
     } else {
         // projections whose RMSNorm is a launch of its own (rows beyond the GEMV's LDS stage: batch > 4): normalise once,
         // outside the timed region, and time the GEMM launches alone

@@ -80,11 +80,7 @@ void launch_xstat32(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 // K-split activation-stationary GEMM for the 256-tile projections at 16 < M <= 32: fp32 partial slabs [groups][32][N], combined
 // (+ residual, rounding) by the following RMSNorm (launch_rmsnorm_packed32 with `slab`). groups = 0: shape not supported
 int xsplit32_groups(const GemmArgs& a);
-// ctr != null: the RMSNorm that follows runs as a tail of the same launch (slab combine + residual into `x` [M][N], normalised rows
-// to `xn` in layout `pack`: 0 row-major, 1 / 2 fragment-packed); ctr = 128 zeroed ints (handoff.h sharded counter)
-void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s, int* ctr = nullptr, int* err = nullptr,
-                     const void* norm_w = nullptr, void* x = nullptr, void* xn = nullptr, float eps = 0.f, int pack = 0);
-bool xsplit32_tail_ok(const GemmArgs& a);
+void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s);
 int xs_min_rows();        // smallest batch on the xstat32 / xsplit32 path (RDX_XS_MINM, default 3)
 void launch_tiled_gemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s);
 // LDS-DMA GEMM for plain row-major activations (M > 32, K % 64 == 0); `ws` = fp32 split-K workspace (nullable)

@@ -201,25 +201,11 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
 // its prologue adds the slabs in kg order, rounds, adds the residual (rmsnorm_k with `slab`): the launch boundary is the sync.
 // fp8 weights (W8): KC counts 64-deep chunks, one 16-byte load feeds two MFMAs per row tile, the activations are packed in the
 // 64-deep order (PACK 2), the per-row scale is applied to the partial; two tiles per trip (TPI) keep 8-12 KiB per wave in flight.
-//
-// Norm tail (`XsTail`, ctr != null; RDX_XSTAIL=1, off by default -- it measured 1.2 us SLOWER per norm than the 5-us launch it
-// replaces: drain + arrival + poll + a dependent round trip of write-through slab reads): the RMSNorm that follows is done inside this launch.
-// Slabs are then stored write-through; every workgroup publishes its arrival on a sharded counter (handoff.h: drain, barrier, one
-// relaxed atomic); workgroups 0..31 wait for all arrivals, then each completes one row -- x[row] += T(sum of slabs) (agent-scope
-// loads), statistics, scaling, output in the consumer's order (row-major / fragment-packed 32- or 64-deep) -- exactly
-// rmsnorm4096_k's arithmetic. They are the last to finish anyway; nothing else is resident, so the wait cannot deadlock (and
-// it times out into `err`).
-struct XsTail {
-    int* ctr; int* err;            // sharded arrival counter (zero at launch; greedy_step_k clears it), sticky error flag
-    const void* norm_w; void* x;   // RMSNorm weight [H] of the NEXT projection; residual rows [M][H], updated in place
-    void* xn; float eps; int pack; // normalised rows out: pack 0 row-major [M][H], 1 / 2 fragment-packed (32-row block)
-};
-
-typedef __attribute__((address_space(1))) float gfloat;
-__device__ __forceinline__ void st4_agent(float* p, float v) { __hip_atomic_store((gfloat*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
+// (A variant that ran that RMSNorm as a tail of this launch -- write-through slabs, arrival counter, workgroups 0..31 finishing one
+// row each -- was measured 1.2 us slower per norm than the 5-us launch it replaced and made low-index workgroups wait on all others,
+// against the liveness rule of handoff.h; removed in round 2.)
 template <typename T, int KC, int KGN, bool W8, int TPI>
-__global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __restrict__ slab, XsTail tl) {
+__global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __restrict__ slab) {
     constexpr int SLOTS = XS_WAVES * KGN, CPW = (KC + SLOTS - 1) / SLOTS, FPL = W8 ? 2 : 1;   // fragments (MFMAs per row tile) per load
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
     float* red = reinterpret_cast<float*>(smx);       // [2 bufs][TPI][8 waves][2 mt][256]
@@ -264,7 +250,6 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 
     const int e_mt = threadIdx.x >> 8, e_idx = threadIdx.x & 255, e_m = e_mt * 16 + (e_idx >> 4), e_nl = e_idx & 15;
     float* sl = slab + ((size_t)kg * 32 + e_m) * a.N;
-    const bool tl_on = tl.ctr != nullptr;
 
     auto trip = [&](int it, auto pf_tag) {
         constexpr bool PF = decltype(pf_tag)::value;
@@ -311,9 +296,7 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 #pragma unroll
             for (int i = 0; i < XS_WAVES; ++i) v += rb[((q * XS_WAVES + i) * 2 + e_mt) * 256 + e_idx];
             const int tl = it * TPI + q, n = (ts + tl * nts) * 16 + e_nl;
-            if (tl < ntl && e_m < a.M && n < a.N) {
-                if (tl_on) st4_agent(sl + n, v * e_sc[q]); else sl[n] = v * e_sc[q];
-            }
+            if (tl < ntl && e_m < a.M && n < a.N) sl[n] = v * e_sc[q];
         }
     };
     if (nit > 1) {
@@ -326,54 +309,6 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
     XS_T(5);
     if (trc) { trc[6] = nit; trc[7] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
 #undef XS_T
-    if (!tl_on) return;
-    // ---- norm tail ------------------------------------------------------------------------------------------------------
-    publish_sc1(tl.ctr, (int)blockIdx.x);
-    if (blockIdx.x >= 32) return;
-    WaitSharded{tl.ctr, (int)gridDim.x, tl.err, 1, nullptr}();
-    typedef typename Vec8<T>::type V8;
-    const int row = blockIdx.x, H = a.N, i = threadIdx.x * 8;               // H = 4096: one 16-byte piece per thread
-    T* xn = reinterpret_cast<T*>(tl.xn);
-    T* dst;
-    if (tl.pack == 0) dst = xn + (size_t)row * H + i;
-    else {
-        const int f = tl.pack == 1 ? (i >> 5) : (2 * (i >> 6) + ((i & 15) >> 3)), g8 = tl.pack == 1 ? ((i & 31) >> 3) : ((i & 63) >> 4);
-        dst = xn + ((size_t)((f * 2 + (row >> 4)) * 64 + g8 * 16 + (row & 15)) << 3);
-    }
-    if (row >= a.M) {                                 // block rows past the batch: zero-filled in the packed layouts
-        if (tl.pack) stg16(dst, (u4){0u, 0u, 0u, 0u});
-        return;
-    }
-    T* xr = reinterpret_cast<T*>(tl.x) + (size_t)row * H + i;
-    V8 v = as_vec8<T>(ldg16(xr));
-    const V8 wv = as_vec8<T>(ldg16(reinterpret_cast<const T*>(tl.norm_w) + i));
-    unsigned long long sp[KGN][4];
-#pragma unroll
-    for (int gq = 0; gq < KGN; ++gq)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sp[gq][k] = ld8_agent(slab + ((size_t)gq * 32 + row) * H + i + 2 * k);
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int gq = 0; gq < KGN; ++gq)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            acc[2 * k] += __builtin_bit_cast(float, (unsigned)sp[gq][k]);
-            acc[2 * k + 1] += __builtin_bit_cast(float, (unsigned)(sp[gq][k] >> 32));
-        }
-    float ss = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        v[j] = fromf<T>(tof<T>(v[j]) + rnd<T>(acc[j]));
-        const float fv = tof<T>(v[j]);
-        ss += fv * fv;
-    }
-    stg16(xr, as_u4<T>(v));
-    ss = block_sum(ss, red);                          // the partial-tile buffers are free (barriers above)
-    const float rs = rsqrtf(ss / (float)H + tl.eps);
-    V8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof<T>(wv[j]) * rnd<T>(tof<T>(v[j]) * rs));
-    stg16(dst, as_u4<T>(o));
 }
 
 // smallest row count (batch) that takes the activation-stationary / K-split kernels; below it the GEMV family of skinny_body.h
@@ -396,17 +331,7 @@ int xsplit32_groups(const GemmArgs& a) {
     return 0;
 }
 
-// the norm tail needs H = N = 4096 rows (one piece per thread) and a grid of at least 32 workgroups
-bool xsplit32_tail_ok(const GemmArgs& a) {
-    const char* e = getenv("RDX_XSTAIL");                     // off by default: measured slower than the RMSNorm launch it replaces
-    if (!e || atoi(e) == 0) return false;
-    return a.N == 4096 && xsplit32_groups(a) > 0;
-}
-
-void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s, int* ctr, int* err, const void* norm_w, void* x, void* xn,
-                     float eps, int pack) {
-    XsTail tl;
-    tl.ctr = ctr; tl.err = err; tl.norm_w = norm_w; tl.x = x; tl.xn = xn; tl.eps = eps; tl.pack = pack;
+void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
     const int kgn = xsplit32_groups(a);
     const int nt = (a.N + 15) / 16;
     const bool w8 = a.W8 && a.wscale;
@@ -414,12 +339,12 @@ void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s, i
     RDX_DISPATCH_T(dtype, T, {
         if (kgn == 4) {
             const int nts = std::min(nt, 256 / 4);
-            if (w8) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab, tl);
-            else hipLaunchKernelGGL((xsplit32_k<T, 344, 4, false, 1>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab, tl);
+            if (w8) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
+            else hipLaunchKernelGGL((xsplit32_k<T, 344, 4, false, 1>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
         } else if (kgn == 2) {
             const int nts = std::min(nt, 256 / 2);
-            if (w8) hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab, tl);
-            else hipLaunchKernelGGL((xsplit32_k<T, 128, 2, false, 1>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab, tl);
+            if (w8) hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
+            else hipLaunchKernelGGL((xsplit32_k<T, 128, 2, false, 1>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
         }
     });
 }

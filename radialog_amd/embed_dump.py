@@ -15,14 +15,18 @@ _MODEL = {}
 
 
 def dump_embeddings(images: torch.Tensor, dicoms: List[str], batch_size: int = 256, dtype: str = "bf16", device: int = 0,
-                    out_path: Optional[str] = None, model: Optional[Blip2Qformer] = None) -> Dict[str, np.ndarray]:
-    """images float32[N,3,448,448] -> {dicom: float32[32,768]}; optionally pickled to `out_path`."""
+                    out_path: Optional[str] = None, model: Optional[Blip2Qformer] = None, synthetic: bool = False) -> Dict[str, np.ndarray]:
+    """images float32[N,3,448,448] -> {dicom: float32[32,768]}; optionally pickled to `out_path` (the file
+    modeling_llama_imgemb.py:454-462 opens). `model` is the loaded Blip2Qformer (pretraining/train.py:118-131 builds it from the
+    config); only `synthetic=True` builds a random-init one here."""
     if len(dicoms) != images.shape[0]:
         raise ValueError("one dicom id per image")
     if model is None:
+        if not synthetic:
+            raise ValueError("dump_embeddings needs a loaded Blip2Qformer (`model=`), or synthetic=True for random-init weights")
         key = (dtype, device, images.shape[-1])
         if key not in _MODEL:
-            _MODEL[key] = Blip2Qformer(img_size=images.shape[-1], dtype=dtype).to(torch.device("cuda", device)).eval()
+            _MODEL[key] = Blip2Qformer(img_size=images.shape[-1], dtype=dtype, synthetic=True).to(torch.device("cuda", device)).eval()
         model = _MODEL[key]
     embeddings = {}
     for s in range(0, len(dicoms), batch_size):

@@ -201,6 +201,7 @@ class RdxEngine:
         toks = torch.full((B, max_new), pad_id, dtype=torch.int32, device=self.device)
         logits = torch.empty(B, self.cfg.llama.vocab, dtype=self.tdtype, device=self.device) if want_logits else None
         self._keep["prefill"] = (ids32, m32, qf, toks)
+        self._conv = None                            # the KV cache is overwritten: nothing of an earlier conversation can be reused
         torch.cuda.synchronize(self.device)
         check(self.ctx, self.lib.rdx_prefill(self.ctx, _ptr(ids32), _ptr(m32), B, T, _ptr(qf), max_new, eos_id, pad_id,
                                              _ptr(toks), _ptr(logits)), "rdx_prefill")

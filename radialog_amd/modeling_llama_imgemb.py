@@ -3,7 +3,7 @@
 What demo.py:221-236,:287-301 and test.py:287-365 do with the reference class keeps working:
     lang_model = LlamaForCausalLM.from_pretrained(path_or_None, torch_dtype=torch.float16, device_map='auto')
     lang_model.base_model.img_proj_layer = nn.Linear(768, hidden)        # weights arrive with the adapter file
-    lang_model = PeftModelForCausalLM.from_pretrained(lang_model, lora_dir)   # here: lang_model.load_adapter(lora_dir)
+    lang_model = PeftModelForCausalLM.from_pretrained(lang_model, lora_dir, torch_dtype=torch.float16)    # same class name here
     out = lang_model.generate(input_ids=ids, dicom=[...] or None, use_img=bool, return_dict_in_generate=True,
                               output_scores=True, max_new_tokens=300)
     out.sequences  int64[B, T+n]   (prompt included; rows that finished early are padded with pad id 0)
@@ -14,6 +14,7 @@ The image embeddings reach `generate` the way the reference passes them (modelin
 """
 from __future__ import annotations
 
+import json
 import os
 import pickle
 from types import SimpleNamespace
@@ -66,29 +67,66 @@ class LlamaForCausalLM:
         self.max_batch, self.max_len = max_batch, max_len
         self.device = torch.device("cuda", device)
         self._engine = None
-        self._state = None            # reference-named fp32 tensors (dict) or None -> synthetic
+        self._state = None            # reference-named fp32 tensors (dict); with _synthetic they overlay the random-init generator
+        self._synthetic = False       # only from_pretrained(synthetic=True) turns the deterministic random-init weights on
         self.training = False
 
     # -- construction -------------------------------------------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, name_or_path=None, torch_dtype=torch.float16, device_map="auto", **kw):
+    def from_pretrained(cls, name_or_path=None, torch_dtype=torch.float16, device_map="auto", synthetic: bool = False, **kw):
+        """`name_or_path` must be a local HF checkpoint directory (safetensors or pytorch_model*.bin shards). Anything else
+        -- a hub id such as the reference's 'lmsys/vicuna-7b-v1.3' (there is no network here), a typo, None -- raises OSError
+        like transformers does for an unreachable model, UNLESS the caller opts in to the deterministic random-init weights
+        with `synthetic=True` (benchmarks and parity tests). Nothing falls back to random weights silently."""
         dt = "f16" if torch_dtype == torch.float16 else "bf16"
+        kw.pop("use_ram_optimized_load", None)
         self = cls(cfg=kw.pop("cfg", None), dtype=dt, **kw)
-        if name_or_path and os.path.isdir(str(name_or_path)):
+        self._synthetic = bool(synthetic)
+        if synthetic:
+            self._state = None
+        elif name_or_path and os.path.isdir(str(name_or_path)):
             self._state = _load_hf_dir(str(name_or_path))
-        elif name_or_path and not kw.get("allow_synthetic", True):
-            raise OSError(f"{name_or_path} is not a local directory (no network access)")
+            self.lora = False                      # a bare base model; PeftModelForCausalLM.from_pretrained / load_adapter adds LoRA
+        else:
+            raise OSError(f"{name_or_path!r} is not a local checkpoint directory (no network access; pass synthetic=True for the "
+                          "deterministic random-init weights of the benchmarks)")
         return self
 
     def load_adapter(self, lora_dir: str):
-        """peft adapter dir: adapter_model.bin = LoRA A/B + img_proj_layer.{weight,bias} (finetune.py:139-145)."""
-        sd = torch.load(os.path.join(lora_dir, "adapter_model.bin"), map_location="cpu")
-        self._state = self._state or {}
+        """peft adapter dir as finetune.py:121-150 writes it: `adapter_model.bin` = LoRA A/B of q_proj and v_proj under peft's key
+        names (`base_model.model.model.layers.N.self_attn.q_proj.lora_A[.default].weight`) + `base_model.model.model.img_proj_layer.
+        {weight,bias}`; `adapter_config.json` carries r, lora_alpha and target_modules (finetune.py:167-173: r=8, alpha=16,
+        ["q_proj", "v_proj"]). The engine's fused LoRA epilogue supports exactly that family: anything else raises."""
+        cfg_path = os.path.join(lora_dir, "adapter_config.json")
+        if not os.path.isfile(cfg_path):
+            raise OSError(f"{cfg_path} not found: not a peft adapter directory")
+        with open(cfg_path) as f:
+            acfg = json.load(f)
+        r, alpha = int(acfg.get("r", 8)), float(acfg.get("lora_alpha", 16))
+        targets = set(acfg.get("target_modules") or [])
+        if targets != {"q_proj", "v_proj"}:
+            raise ValueError(f"adapter targets {sorted(targets)}: the fused LoRA path covers q_proj and v_proj (finetune.py:171)")
+        if r != 8:
+            raise ValueError(f"adapter rank r={r}: the fused LoRA epilogue is built for r=8 (finetune.py:168)")
+        if float(acfg.get("lora_dropout", 0.0)) and not acfg.get("inference_mode", True):
+            raise ValueError("adapter_config.json is not in inference mode")
+        bin_path = os.path.join(lora_dir, "adapter_model.bin")
+        if not os.path.isfile(bin_path):
+            raise OSError(f"{bin_path} not found")
+        sd = torch.load(bin_path, map_location="cpu")
+        self.lcfg = LlamaCfg(**{**self.lcfg.__dict__, "lora_r": r, "lora_alpha": alpha})
+        if self._state is None and not self._synthetic:
+            raise RuntimeError("load_adapter: no base weights loaded (LlamaForCausalLM.from_pretrained first)")
+        self._state = {} if self._state is None else self._state
+        self._adapter_keys = set()
         for k, v in sd.items():
             k = k.replace("base_model.model.", "", 1).replace(".lora_A.default.", ".lora_A.").replace(".lora_B.default.", ".lora_B.")
             self._state[k] = v.float()
+            self._adapter_keys.add(k)
         self.lora = True
+        self._engine = None
         return self
+
 
     def resize_token_embeddings(self, n):                          # test.py:297 (adds the <IMG> row)
         self.lcfg = LlamaCfg(**{**self.lcfg.__dict__, "vocab": n})
@@ -112,10 +150,24 @@ class LlamaForCausalLM:
         cfg = RaDialogCfg(llama=self.lcfg)
         eng = RdxEngine(cfg, dtype=self.dtype, device=self.device.index or 0, max_batch=self.max_batch, max_len=self.max_len,
                         lora=self.lora, vision=False, llama=True)
-        if self._state is None:
-            get = synth_getter(cfg, eng.device, lora=self.lora)
+        if self._state is None and not self._synthetic:
+            eng.close()
+            raise RuntimeError("LlamaForCausalLM has no weights: build it with from_pretrained(local_dir) or from_pretrained(synthetic=True)")
+        if self._synthetic:
+            base, st = synth_getter(cfg, eng.device, lora=self.lora), (self._state or {})
+            get = lambda name: st[name].to(eng.device) if name in st else base(name)          # noqa: E731
         else:
             st, V = self._state, self.lcfg.vocab
+            need = ["model.embed_tokens.weight", "lm_head.weight", "model.norm.weight", "model.img_proj_layer.weight",
+                    "model.img_proj_layer.bias"]
+            if self.lora:
+                need += [f"model.layers.{l}.self_attn.{m}.lora_{ab}.weight" for l in (0, self.lcfg.layers - 1)
+                         for m in ("q_proj", "v_proj") for ab in "AB"]
+            missing = [k for k in need if k not in st]
+            if missing:
+                eng.close()
+                raise KeyError(f"checkpoint lacks {missing}: `img_proj_layer` and the LoRA matrices arrive with the adapter "
+                               "(PeftModelForCausalLM.from_pretrained(lang_model, adapter_dir), demo.py:229-234)")
 
             def get(name):
                 t = st[name].to(eng.device)
@@ -168,8 +220,36 @@ class LlamaForCausalLM:
         seq = torch.cat([input_ids.to(toks.device), toks], dim=1)
         if not return_dict_in_generate:
             return seq
-        sc = tuple(scores[i] for i in range(n)) if output_scores else None
+        # fresh tensors like HF's: the engine reuses its score buffer on the next call
+        sc = tuple(scores[i].clone() for i in range(n)) if output_scores else None
         return GenerateOutput(sequences=seq, scores=sc)
+
+
+class PeftModelForCausalLM:
+    """`PeftModelForCausalLM.from_pretrained(lang_model, adapter_dir, torch_dtype=torch.float16[, use_ram_optimized_load=False])`
+    exactly as demo.py:232-234 / test.py:301 call it (peft@e536616): loads the adapter into `lang_model` and returns an object
+    with the wrapped model's surface (`generate`, `eval`, `half`, `base_model.model` = the LlamaForCausalLM)."""
+
+    def __init__(self, model: "LlamaForCausalLM"):
+        self.base_model = SimpleNamespace(model=model)
+
+    @classmethod
+    def from_pretrained(cls, model: "LlamaForCausalLM", model_id: str, torch_dtype=None, **_kw):
+        model.load_adapter(str(model_id))
+        return cls(model)
+
+    def __getattr__(self, name):
+        return getattr(self.base_model.model, name)
+
+    def half(self):
+        return self
+
+    def eval(self):
+        self.base_model.model.eval()
+        return self
+
+    def generate(self, **kw):
+        return self.base_model.model.generate(**kw)
 
 
 def _load_hf_dir(path: str):

@@ -17,7 +17,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from radialog_amd import synth                                              # noqa: E402
 from radialog_amd.embed_dump import dump_embeddings                         # noqa: E402
-from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM             # noqa: E402
+from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM, PeftModelForCausalLM   # noqa: E402
 from radialog_amd.prompter import new_conversation, report_prompt          # noqa: E402
 from radialog_amd.shard import allgather_ragged, shard_range               # noqa: E402
 from radialog_amd.tokenizer import load_tokenizer                          # noqa: E402
@@ -35,6 +35,7 @@ def main():
     p.add_argument("--batch_size", type=int, default=12)
     p.add_argument("--max_new_tokens", type=int, default=300)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    p.add_argument("--synthetic", action="store_true", help="deterministic random-init weights (no checkpoints reachable offline)")
     args = p.parse_args()
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -47,14 +48,15 @@ def main():
     lo, hi = shard_range(args.num_samples, world, rank)
     dicoms = [f"synthetic-{i:05d}" for i in range(lo, hi)]
     tok = load_tokenizer(args.vicuna)
-    lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=torch.float16 if args.dtype == "f16" else torch.bfloat16,
-                                                  device_map="auto", max_batch=args.batch_size, max_len=1024, device=local)
+    dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
+    lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=dt, device_map="auto", max_batch=args.batch_size * max(args.num_beams, 1),
+                                                  max_len=1024, device=local, synthetic=args.synthetic)
     if args.lora_model:
-        lang_model.load_adapter(args.lora_model)
+        lang_model = PeftModelForCausalLM.from_pretrained(lang_model, args.lora_model, torch_dtype=dt, use_ram_optimized_load=False).half()
     lang_model.eval()
     if args.use_embs:
         images = synth.synth_images(len(dicoms), 448, seed=1000 + lo)
-        lang_model.model.blip_embeddings.update(dump_embeddings(images, dicoms, dtype=args.dtype, device=local))
+        lang_model.model.blip_embeddings.update(dump_embeddings(images, dicoms, dtype=args.dtype, device=local, synthetic=args.synthetic))
 
     all_preds, all_ids = [], []
     for s in range(0, len(dicoms), args.batch_size):

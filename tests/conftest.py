@@ -10,6 +10,7 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: minutes of CPU oracle time (full-depth Vicuna-7B legs); still part of -m gpu")
 
 
 @pytest.fixture(scope="session")

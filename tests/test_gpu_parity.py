@@ -12,12 +12,17 @@ import torch
 
 from radialog_amd import synth
 from radialog_amd.config import small_cfg
+from _parity import check_greedy
 
 pytestmark = pytest.mark.gpu
 
 DT = {"f16": torch.float16, "bf16": torch.bfloat16}
 LOGIT_TOL = {"f16": 1e-2, "bf16": 6e-2}
 ENC_TOL = {"f16": 5e-3, "bf16": 3e-2}
+# share of (row, step) pairs that must have been compared with IDENTICAL tokens (tests/_parity.py). fp16 is the reference's
+# dtype (torch_dtype=float16, demo.py:225) and the parity dtype; bf16 (the bench dtype) rounds 8x coarser, so oracle near-ties
+# within two ulps -- the only place a token may legitimately differ -- are 8x more frequent and end a row's comparison earlier.
+MIN_COVER = {"f16": 0.9, "bf16": 0.75}
 
 
 def _cpu_weights(cfg, lora=True):
@@ -109,7 +114,10 @@ def test_prefill_logits_and_kv_match_oracle(engine, cfg, cpu_w):
     ref_last = logits[:, -1].float()
     err = (lg.float().cpu() - ref_last).abs().max()
     assert float(err) < tol, f"last-position logits differ by {float(err)}"
-    assert torch.equal(toks[:, 0].cpu().long(), ref_last.argmax(-1)) or float(ref_last.topk(2).values.diff().abs().min()) < 4 * tol
+    t0, am = toks[:, 0].cpu().long(), ref_last.argmax(-1)
+    gaps = ref_last.topk(2).values.diff().abs()[:, 0]
+    for b in range(B):
+        assert int(t0[b]) == int(am[b]) or float(gaps[b]) <= 2 * float(err), f"row {b}: first token differs at margin {float(gaps[b])}"
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
@@ -124,16 +132,7 @@ def test_greedy_tokens_identical_to_oracle(engine, cfg, cpu_w, use_graph):
         ref = orc.generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
     toks, scores, n = engine.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=use_graph)
     assert n == N
-    toks = toks.cpu().long()
-    tol = LOGIT_TOL[engine.dtype]
-    for b in range(B):
-        for s in range(N):
-            if toks[b, s] != ref["tokens"][b, s]:
-                # a legitimate divergence needs a near-tie in the oracle at this very step
-                assert float(ref["margins"][s, b]) < 4 * tol, f"row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
-                break
-            err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
-            assert float(err) < tol, f"row {b} step {s}: logits differ by {float(err)}"
+    check_greedy(toks, scores, ref, LOGIT_TOL[engine.dtype], MIN_COVER[engine.dtype], f"{engine.dtype} graph={use_graph}")
 
 
 def test_eos_and_padding_rule(engine, cfg, cpu_w):
@@ -154,9 +153,10 @@ def test_eos_and_padding_rule(engine, cfg, cpu_w):
     nref = ref["tokens"].shape[1]
     # the engine checks for "all finished" every 16 steps, so it may run past the reference; extra tokens are pad
     assert n >= nref
-    if float(ref["margins"].min()) > 4 * LOGIT_TOL[engine.dtype]:
-        assert torch.equal(toks[:, :nref], ref["tokens"])
+    check_greedy(toks, None, ref, LOGIT_TOL[engine.dtype], MIN_COVER[engine.dtype], f"{engine.dtype} eos")
+    if torch.equal(toks[0, :3], ref["tokens"][0, :3]):
         assert int(toks[0, 3:].abs().sum()) == 0      # row 0 finished at step 2 -> pads afterwards
+    assert int(toks[:, nref:].abs().sum()) == 0       # everything behind the reference's stop is padding
 
 
 @pytest.mark.parametrize("mode", [1, 2])
@@ -175,9 +175,8 @@ def test_fused_attention_oproj_launch_matches_oracle(cfg, cpu_w, monkeypatch, mo
     with torch.no_grad():
         ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, torch.float16, lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1)
     for use_graph in (False, True):
-        toks, _, n = eng.generate(ids, qf, max_new=N, eos_id=-1, use_graph=use_graph)
-        same = toks.cpu().long() == ref["tokens"]
-        assert bool(same.all()) or float(ref["margins"].min()) < 4e-2
+        toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, use_graph=use_graph, output_scores=True)
+        check_greedy(toks, scores, ref, LOGIT_TOL["f16"], MIN_COVER["f16"], f"fused attention+o_proj mode {mode} graph={use_graph}")
     eng.close()
 
 
@@ -201,14 +200,7 @@ def test_chained_decode_layer_kernel_matches_oracle(cfg, cpu_w, monkeypatch, lay
         tol = LOGIT_TOL[dtype]
         for use_graph in (False, True):
             toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, output_scores=True, use_graph=use_graph)
-            toks = toks.cpu().long()
-            for b in range(B):
-                for s in range(N):
-                    if toks[b, s] != ref["tokens"][b, s]:
-                        assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
-                        break
-                    err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
-                    assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
+            check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"{dtype}")
         eng.close()
 
 
@@ -230,14 +222,7 @@ def test_chained_mlp_qkv_launch_matches_oracle(cfg, cpu_w, monkeypatch, B, mode)
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1)
         tol = LOGIT_TOL[dtype]
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, output_scores=True, use_graph=True)
-        toks = toks.cpu().long()
-        for b in range(B):
-            for s in range(N):
-                if toks[b, s] != ref["tokens"][b, s]:
-                    assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
-                    break
-                err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
-                assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
+        check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"{dtype}")
         eng.close()
 
 
@@ -277,15 +262,8 @@ def test_batch18_greedy_tokens_match_oracle(cfg, cpu_w, kperm, monkeypatch):
         with torch.no_grad():
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
-        toks = toks.cpu().long()
         tol = LOGIT_TOL[dtype]
-        for b in range(B):
-            for s in range(N):
-                if toks[b, s] != ref["tokens"][b, s]:
-                    assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
-                    break
-                err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
-                assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
+        check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"{dtype}")
         eng.close()
 
 
@@ -301,21 +279,36 @@ def _production_width_weights(layers):
     return _PROD_W[layers]
 
 
-@pytest.mark.parametrize("B,fp8,layers,tail", [(20, False, 1, 0), (20, True, 1, 0), (8, False, 1, 0), (16, True, 1, 0), (5, False, 1, 0),
-                                               (3, False, 1, 0), (4, True, 1, 0), (1, False, 1, 0), (2, False, 1, 0), (1, True, 1, 0),
-                                               (20, False, 2, 0), (20, False, 2, 1)])
-def test_batch20_production_width_layer_matches_oracle(B, fp8, layers, tail, monkeypatch):
-    """Batch 3-32 at the production widths (hidden 4096, inter 11008, vocab 32001; one decoder layer so that the oracle
-    finishes in seconds): QKV / gate-up / lm_head go through the activation-stationary kernel (xstat32.hip) fed by the
-    fragment-packed RMSNorm, gate/up hands its SwiGLU output to down_proj fragment-packed, down_proj runs K-split
-    (xsplit32_k) and its residual epilogue + the next RMSNorm run as a tail of the same launch; attention hands its output to the
-    K-split o_proj the same way. Tokens and per-step logits against the oracle. fp8 = the same path on e4m3 weights (oracle on the fake-quantised
-    weights, bf16 only)."""
+PROD_TOL = {"f16": 1e-2, "bf16": 8e-2}      # north_star: logits within 1e-2 in fp16; bf16 has 8x the ulp
+
+
+def _prefix_err(scores, ref_scores, tok_a, tok_b, N):
+    """max |a - b| over the steps whose inputs are still the same on both sides (tokens equal so far), per row."""
+    worst = 0.0
+    B = tok_a.shape[0]
+    for b in range(B):
+        for s in range(N):
+            worst = max(worst, float((scores[s][b].float().cpu() - ref_scores[s][b].float()).abs().max()))
+            if int(tok_a[b, s]) != int(tok_b[b, s]):
+                break
+    return worst
+
+
+@pytest.mark.parametrize("B,fp8,layers,dtypes", [
+    (32, False, 1, ("f16", "bf16")), (32, True, 1, ("bf16",)), (32, False, 2, ("f16",)),        # BASELINE configs[2] / [4] per-GPU batch
+    (20, False, 1, ("f16", "bf16")), (20, True, 1, ("bf16",)), (8, False, 1, ("bf16",)), (16, True, 1, ("bf16",)),
+    (5, False, 1, ("bf16",)), (3, False, 1, ("f16",)), (4, True, 1, ("bf16",)), (1, False, 1, ("f16", "bf16")),
+    (2, False, 1, ("f16",)), (1, True, 1, ("bf16",)), (20, False, 2, ("bf16",)), (1, False, 2, ("f16",))])
+def test_production_width_layers_match_oracle(B, fp8, layers, dtypes):
+    """Every decode kernel family at the production widths (hidden 4096, inter 11008, vocab 32001; one or two decoder layers so
+    that the oracle finishes in seconds; two layers add the down_proj -> next QKV seam): batch 1-2 fused / chained GEMV launches,
+    batch 3-32 activation-stationary (xstat32.hip) and K-split (xsplit32_k) kernels with fragment-packed hand-offs, batch 32 with
+    the row-major K cache and the full 32-row block, hipGraph replay. Per-step logits within the north_star tolerance of the oracle,
+    tokens identical (tests/_parity.py), and -- accumulation-order noise being what separates any two fp16 implementations -- the
+    HIP logits must be no further from the exactly-accumulated (fp64) evaluation of the same rounding points than the torch-CPU
+    oracle is (factor 1.5 on two maxima of the same noise). fp8 = the same path on e4m3 weights (oracle on the fake-quantised weights)."""
     from oracle import ref_cpu
-    from radialog_amd.config import LlamaCfg, RaDialogCfg
     from radialog_amd.engine import RdxEngine, synth_getter
-    if tail:        # the in-launch norm tail of the K-split kernels (RDX_XSTAIL, off by default)
-        monkeypatch.setenv("RDX_XSTAIL", "1")
     cfg, cpu_w = _production_width_weights(layers)
     if fp8:
         cpu_w = {k: (_fake_quant_rows(v) if k == "lm_head.weight" or (k.startswith("model.layers.") and v.dim() == 2 and
@@ -324,26 +317,25 @@ def test_batch20_production_width_layer_matches_oracle(B, fp8, layers, tail, mon
     T, N = 96, 5
     ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, pad_rows=(B > 1), seed=5)
     qf = synth.synth("t.qf20", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
-    for dtype in (("bf16",) if (fp8 or layers > 1 or B != 20) else ("bf16", "f16")):
+    for dtype in dtypes:
         eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=128, lora=True, vision=False, weights_fp8=fp8)
         eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
         with torch.no_grad():
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
+            truth = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True, exact=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
-        toks = toks.cpu().long()
-        # 4096- and 11008-deep fp32 accumulations in another order than torch's, rounded to the model dtype at every op of the
-        # layer: the worst of 20 x 32001 logits sits 3 ulp off at |logit| ~ 6 (ulp 2^-8 fp16, 2^-5 bf16; mean error 1/3 ulp)
-        tol = {"f16": 2e-2, "bf16": 0.125}[dtype] * (layers ** 0.5)       # the rounding noise adds up layer by layer
-        if fp8:     # the streaming kernels scale the fp32 sum of e4m3 products; the oracle's weights are T(q * scale), each rounded to bf16
+        tol = PROD_TOL[dtype]
+        if fp8:     # the streaming kernels scale the fp32 sum of e4m3 products; the oracle's weights are T(q * scale), each rounded to the model dtype
             tol *= 1.5
-        assert not torch.isnan(scores.float()).any()
-        for b in range(B):
-            for s in range(N):
-                if toks[b, s] != ref["tokens"][b, s]:
-                    assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
-                    break
-                err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
-                assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
+        cmp_, tot, e_ho = check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"B={B} {dtype} fp8={fp8} layers={layers}")
+        tk = toks.cpu().long()
+        e_ht = _prefix_err(scores, truth["scores"], tk, truth["tokens"], N)
+        e_ot = _prefix_err(ref["scores"], truth["scores"], ref["tokens"], truth["tokens"], N)
+        print(f"production width B={B} {dtype} fp8={fp8} layers={layers}: compared {cmp_}/{tot}, |hip-oracle| {e_ho:.4g}, "
+              f"|hip-exact| {e_ht:.4g}, |oracle-exact| {e_ot:.4g}")
+        if not fp8:
+            ulp = 2.0 ** -8 if dtype == "f16" else 2.0 ** -5                 # one ulp at |logit| in [4, 8)
+            assert e_ht <= 1.5 * e_ot + ulp, f"{dtype}: HIP is {e_ht:.4g} from the exact evaluation, the torch-CPU oracle only {e_ot:.4g}"
         eng.close()
 
 
@@ -365,15 +357,8 @@ def test_long_context_decode_streams_past_the_register_window(cfg, cpu_w, B, tp,
         with torch.no_grad():
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
-        toks = toks.cpu().long()
         tol = LOGIT_TOL[dtype]
-        for b in range(B):
-            for s in range(N):
-                if toks[b, s] != ref["tokens"][b, s]:
-                    assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
-                    break
-                err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
-                assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
+        check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"{dtype}")
         eng.close()
 
 
@@ -401,14 +386,7 @@ def test_decode_attention_context_lengths_around_the_register_window_edges(cfg, 
                 ref = oracle.generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
             toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=False)
             assert not torch.isnan(scores.float()).any(), f"{dtype} T={T}: NaN logits"
-            toks = toks.cpu().long()
-            for b in range(B):
-                for s in range(N):
-                    if toks[b, s] != ref["tokens"][b, s]:
-                        assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} T={T} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
-                        break
-                    err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
-                    assert float(err) < tol, f"{dtype} T={T} row {b} step {s}: logits differ by {float(err)}"
+            check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"{dtype} T={T}")
         eng.close()
 
 
@@ -441,13 +419,10 @@ def test_multi_turn_prefix_kv_reuse_matches_full_recompute_and_oracle(cfg, cpu_w
         with torch.no_grad():
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids2, qf, max_new=N2, eos_id=-1, pad_id=0)
         tol = LOGIT_TOL[dtype]
-        for b in range(B):
-            for s in range(N2):
-                if t2[b, s] != ref["tokens"][b, s]:
-                    assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
-                    break
-                assert float((s2[s, b] - ref["scores"][s][b].float()).abs().max()) < tol, f"{dtype} row {b} step {s}: reuse path vs oracle"
-                assert float((s2[s, b] - s2f[s, b].float().cpu()).abs().max()) < tol, f"{dtype} row {b} step {s}: reuse path vs full prefill"
+        check_greedy(t2, s2, ref, tol, MIN_COVER[dtype], f"{dtype} reuse path vs oracle")
+        check_greedy(t2f, s2f, ref, tol, MIN_COVER[dtype], f"{dtype} full prefill vs oracle")
+        same = (t2 == t2f.cpu().long()).long().cumprod(1).bool()           # steps up to the first difference share their inputs
+        assert float(((s2 - s2f.float().cpu()).abs().amax(-1).T * same).max()) < tol, f"{dtype}: reuse path vs full prefill"
         # a third turn whose prompt diverges inside the cached part keeps only the common prefix
         ids3 = ids2.clone()
         ids3[:, T1 + 3] = (ids3[:, T1 + 3] + 7) % 31000 + 3
@@ -508,13 +483,6 @@ def test_fp8_weight_decode_matches_fake_quantised_oracle(cfg, cpu_w, B):
         with torch.no_grad():
             ref = ref_cpu.LlamaOracle(Wq, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
-        toks = toks.cpu().long()
         tol = LOGIT_TOL[dtype]
-        for b in range(B):
-            for s in range(N):
-                if toks[b, s] != ref["tokens"][b, s]:
-                    assert float(ref["margins"][s, b]) < 4 * tol, f"{dtype} row {b} step {s}: token mismatch at margin {float(ref['margins'][s, b])}"
-                    break
-                err = (scores[s, b].float().cpu() - ref["scores"][s][b].float()).abs().max()
-                assert float(err) < tol, f"{dtype} row {b} step {s}: logits differ by {float(err)}"
+        check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"{dtype}")
         eng.close()

@@ -84,7 +84,7 @@ def test_synth_is_deterministic_and_name_keyed():
 def test_config_yaml_and_registry(tmp_path):
     from radialog_amd.blip2_qformer import Blip2Qformer, Config, registry, tasks
     p = tmp_path / "c.yaml"
-    p.write_text("model:\n  arch: blip2\n  vit_model: biovil\n  image_size: 448\n  num_query_token: 32\n")
+    p.write_text("model:\n  arch: blip2\n  vit_model: biovil\n  image_size: 448\n  num_query_token: 32\n  synthetic: true\n")
     cfg = Config(types.SimpleNamespace(cfg_path=str(p), options=["model.max_txt_len=95"]))
     assert cfg.model_cfg.arch == "blip2" and cfg.model_cfg.max_txt_len == 95
     assert registry.get_model_class("blip2") is Blip2Qformer
@@ -96,7 +96,7 @@ def test_config_yaml_and_registry(tmp_path):
 
 def test_generate_wrapper_argument_errors():
     from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM
-    lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.float16)
+    lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.float16, synthetic=True)
     ids = torch.ones(1, 40, dtype=torch.long)
     with pytest.raises(NotImplementedError):
         lm.generate(input_ids=ids, num_beams=3, max_new_tokens=4)

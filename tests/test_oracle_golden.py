@@ -94,3 +94,19 @@ def test_projector_scramble_layernorm(golden_dir):
     # the scramble: row r of the token matrix is flat elements r*C..(r+1)*C-1 of the [C, g*g] matrix
     flat = pp[0].reshape(-1)
     assert torch.equal(pp.reshape(2, -1, v.proj)[0, 3], flat[3 * v.proj: 4 * v.proj])
+
+
+def test_vit_pooler_matches_reference_module(golden_dir):
+    """Two-image mode: oracle/ref_cpu.vit_pooler against the reference's own VisionTransformerPooler / Block /
+    MultiHeadAttentionLayer / SinePositionEmbedding (biovil_t/transformer.py, imported by oracle/make_golden.py with timm's
+    Mlp / DropPath / trunc_normal_ shimmed). Same weights (regenerated here), same inputs."""
+    g = np.load(os.path.join(golden_dir, "vit_pooler.npz"))
+    v = VisionCfg(img=128, stem=32, planes=(32, 64, 128, 256), blocks=(1, 2, 2, 1), b2v=64, proj=352, pool_blocks=2, pool_heads=2)
+    W = synth.make_weights(synth.vision_specs(v))
+    pos = ref_cpu.sine_pos_embed(v.grid, v.b2v)
+    np.testing.assert_allclose(pos.numpy(), g["pos_embed"], rtol=0, atol=1e-6)
+    from radialog_amd.weights import sine_pos_embed as host_pos            # the table the engine uploads
+    np.testing.assert_allclose(host_pos(v.grid, v.b2v).numpy(), g["pos_embed"], rtol=0, atol=1e-6)
+    with torch.no_grad():
+        out = ref_cpu.vit_pooler(torch.from_numpy(g["cur"]), torch.from_numpy(g["prev"]), W, v)
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=2e-5)
