@@ -7,13 +7,20 @@ A "step" is one pass of the hot path over one batch of synthetic input on each r
 Default workload = BASELINE.json configs[1]: 1 x MI355X, batch 1, bf16, random-init weights of the real architecture.
 `--batch 32` gives configs[2] (batch-32 decode, hipGraph step). With N > 1 ranks (one process per GPU, launched by
 torch.distributed.run) every rank runs the same per-GPU batch on its own shard of images (weak scaling) and the
-generated token ids are all-gathered over RCCL/xGMI at the end of each step -- the only collective on the path.
+generated token ids are gathered with ONE RCCL all-gather issued by librdx itself (rdx_allgather_tokens) at the end of each
+step -- the only collective on the path; torch.distributed carries the 128-byte RCCL id, the barrier and the max-over-ranks clock.
 
 Rank 0 prints ONE JSON line. `value` = reports/s of the whole job with inputs resident in HBM. Added objects:
-  roofline     the dominant kernel = the gate/up SwiGLU weight-streaming GEMV (45 % of decode bytes): algorithmic bytes per
-               launch / its average launch duration measured with HIP events on the library's stream (rdx_time).
-  cpu_baseline the CPU oracle (oracle/ref_cpu.py, kind "port") timed on the host cores on a bounded sample of the same
-               workload, extrapolated to reports/s.
+  roofline     bound "hbm": the kernel rocprofv3 ranks first in the decode loop -- at batch <= 2 the chained down(l) -> QKV(l+1)
+               launch `decode_layers_k` (profiles/r02_bench_kernel_stats.md), at batch 3-32 the gate/up SwiGLU `xstat32_k`:
+               algorithmic bytes per launch / its average launch duration measured live with HIP events on the library's stream
+               (rdx_time; the chained launch is bracketed in situ inside real decode steps); `traffic` = HBM bytes per launch
+               from the rocprofv3 PMC passes of this same command (profiles/r02_pmc.json; counters cannot be read in-process).
+               Also the whole-step fractions and the MFMA-side fractions north_star targets (`mfma`: encode and prefill
+               TFLOP/s over the 2.5 PFLOP/s dense bf16 peak).
+  b32          (batch-1 runs on one GPU) BASELINE configs[2] timed in the same process: batch 32, hipGraph decode step.
+  cpu_baseline the CPU oracle (oracle/ref_cpu.py, kind "port") running BASELINE configs[0] for real on the host cores: one
+               448 px image through the full-size encoder, the 160-token prefill and 32 greedy tokens through all 32 layers.
 """
 import argparse
 import json
@@ -27,6 +34,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA peak (the 5 PFLOP/s headline includes 2:1 sparsity)
 
 
 def parse():
@@ -41,24 +49,59 @@ def parse():
     ap.add_argument("--fp8", action="store_true", help="decoder GEMM weights in e4m3 + per-row scale (BASELINE configs[4] weight path); "
                     "not the parity configuration: its oracle is the reference math on the fake-quantised weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-b32", action="store_true", help="skip the configs[2] (batch 32) sub-run of a batch-1 single-GPU bench")
     ap.add_argument("--no-graph", action="store_true")
     return ap.parse_args()
 
 
-def pmc_traffic(batch, dtype, fp8=False):
-    """HBM bytes per launch of the dominant kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3
-    passes, gfx950 read-side doubling): measured offline because counters cannot be read from inside the timed process;
-    the summary lives in profiles/r01_pmc_hbm_traffic.md and its machine-readable twin profiles/r01_pmc.json.
-    Only valid for the configurations it was measured on (bf16: batch 1 with or without fp8 weights, batch 32) -> null otherwise."""
-    if batch not in (1, 32) or dtype != "bf16" or (batch == 32 and fp8):
-        return None
+# ----------------------------------------------------------------------------------------------------------------------
+# algorithmic work, from the shapes
+# ----------------------------------------------------------------------------------------------------------------------
+def encode_flops(cfg):
+    """FLOPs (2 x MAC) of one image through ResNet-50 trunk, backbone_to_vit, projector, Q-Former query path."""
+    v, q = cfg.vision, cfg.qformer
+    s = v.img // 2
+    mac = s * s * v.stem * 3 * 49
+    s, cin = v.img // 4, v.stem
+    for li, (pl, nb) in enumerate(zip(v.planes, v.blocks)):
+        for b in range(nb):
+            so = (s - 1) // 2 + 1 if (b == 0 and li > 0) else s
+            mac += s * s * pl * cin + so * so * pl * pl * 9 + so * so * 4 * pl * pl
+            if b == 0:
+                mac += so * so * 4 * pl * cin
+            cin, s = 4 * pl, so
+    P = s * s
+    mac += P * v.b2v * cin + P * v.proj * 2 * v.b2v + P * v.proj * v.proj
+    H, I, NQ = q.hidden, q.inter, q.n_query
+    for l in range(q.layers):
+        mac += NQ * 4 * H * H + 2 * NQ * NQ * H + 2 * NQ * H * I
+        if q.has_cross(l):
+            mac += 2 * NQ * H * H + 2 * P * H * q.enc_width + 2 * NQ * P * H
+    return 2.0 * mac
+
+
+def llama_param_bytes(lc, wbytes):
+    """bytes of one decode step's weight stream: every GEMM weight once (+ LoRA-A rows fused into QKV), norms, LoRA-B."""
+    H, I = lc.hidden, lc.inter
+    per_layer = ((3 * H + 2 * lc.lora_r) * H * wbytes(3 * H + 2 * lc.lora_r, H) + H * H * wbytes(H, H) + 2 * I * H * wbytes(2 * I, H)
+                 + H * I * wbytes(H, I) + 2 * H * 2 + 2 * H * lc.lora_r * 2)
+    return lc.layers * per_layer + lc.vocab * H * wbytes(lc.vocab, H) + H * 2
+
+
+def prefill_flops(lc, T, B):
+    H, I = lc.hidden, lc.inter
+    per_tok = 2.0 * lc.layers * ((3 * H + 2 * lc.lora_r) * H + H * H + 3 * H * I)
+    attn = lc.layers * 4.0 * T * T * H / 2
+    return B * (per_tok * T + attn + 2.0 * lc.vocab * H + 2.0 * 32 * lc.qformer_dim * H)
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs of
+    this command, FETCH doubled per the gfx950 correction; profiles/r02_pmc_hbm_traffic.md, machine-readable twin r02_pmc.json).
+    Only for configurations that were profiled -> null otherwise."""
     try:
-        with open(os.path.join(REPO, "profiles", "r01_pmc.json")) as f:
-            d = json.load(f)
-        for k, v in d.items():
-            if ("W8" in k) == bool(fp8) and (f"B={batch}," in k):
-                return v["traffic_bytes"]
-        return None
+        with open(os.path.join(REPO, "profiles", "r02_pmc.json")) as f:
+            return json.load(f).get(kernel_key, {}).get("traffic_bytes")
     except Exception:
         return None
 
@@ -66,8 +109,7 @@ def pmc_traffic(batch, dtype, fp8=False):
 def _pick_threads():
     """torch's intra-op pool at os.cpu_count() threads can be far slower than a smaller pool on many-core hosts
     (sync overhead on decode-sized ops); calibrate on a decode-shaped matmul and use the fastest setting."""
-    import os as _os
-    ncpu = _os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
     cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
     w = torch.randn(4096, 4096).to(torch.bfloat16)
     x = torch.randn(1, 4096).to(torch.bfloat16)
@@ -85,62 +127,155 @@ def _pick_threads():
     return best
 
 
-def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens):
-    """Time the CPU oracle on a BOUNDED sample of the same workload: the full-size encode of ONE image, and 1 of the 32
-    decoder layers (+ final norm + lm_head) for the 160-token prefill and 3 decode steps; extrapolate linearly in
-    layers and tokens. Target: 10-30 s of CPU work."""
+def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device):
+    """BASELINE configs[0], for real: the CPU oracle encodes ONE 448 px image, prefills the 160-token prompt and decodes 32 greedy
+    tokens through all 32 production-width layers on the host cores (the weights are the engine's: generated on the GPU tensor by
+    tensor, rounded to the model dtype, copied to the host -- not part of the timed work). The metric is quoted on 256-token
+    reports: reports/s = 1 / (encode + prefill + 256 x the measured per-token time)."""
     from oracle import ref_cpu
     from radialog_amd import synth
-    from radialog_amd.config import LlamaCfg
     threads = _pick_threads()
     dt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtype_name]
+    n_tok = 32
     t_all = time.time()
-    sample_layers, sample_steps = 1, 3
-    lc = cfg.llama
-    sub = LlamaCfg(vocab=lc.vocab, hidden=lc.hidden, inter=lc.inter, layers=sample_layers, heads=lc.heads)
     with torch.no_grad():
         Wv = synth.make_weights({**synth.vision_specs(cfg.vision), **synth.qformer_specs(cfg.qformer)})
         img = synth.synth_images(1, cfg.vision.img)
+        ref_cpu.forward_image(img, Wv, cfg)                                           # cold pass: pages the conv kernels in
         t0 = time.time(); q, _ = ref_cpu.forward_image(img, Wv, cfg); t_enc = time.time() - t0
         del Wv
-        Wl = synth.make_weights(synth.llama_specs(sub, lora=True), dtype=dt)
-        orc = ref_cpu.LlamaOracle(Wl, sub, dt, lora=True)
-        del Wl
-        ids = synth.synth_prompt_ids(1, prompt_len, vocab=lc.vocab)
+        specs = synth.llama_specs(cfg.llama, lora=True)
+        W = {name: gen(name, shape, device).to(dt).cpu() for name, (shape, gen) in specs.items()}
+        orc = ref_cpu.LlamaOracle(W, cfg.llama, dt, lora=True)
+        del W
+        ids = synth.synth_prompt_ids(1, prompt_len, vocab=cfg.llama.vocab)
         km = ids.ne(0).long()
         t0 = time.time()
-        x = orc.embed(ids, q)
-        logits, past, _ = orc.forward(x, km, ref_cpu.positions_from_mask(km))
+        logits, past, _ = orc.forward(orc.embed(ids, q), km, ref_cpu.positions_from_mask(km))
         t_prefill = time.time() - t0
         E = orc.W["model.embed_tokens.weight"]
-        t_steps = []
-        for s in range(sample_steps):
-            t0 = time.time()
+        toks, t0 = [], time.time()
+        for s in range(n_tok):
             nxt = logits[:, -1].argmax(-1)
+            toks.append(int(nxt))
+            if s == n_tok - 1:
+                break
             km = torch.cat([km, km.new_ones(1, 1)], -1)
-            xx = torch.nn.functional.embedding(nxt[:, None], E)
-            logits, past, _ = orc.forward(xx, km, ref_cpu.positions_from_mask(km)[:, -1:], past)
-            t_steps.append(time.time() - t0)
-        t_step = min(t_steps)
-        # lm_head + final norm alone (not proportional to the layer count)
-        h = torch.randn(1, 1, lc.hidden).to(dt)
-        torch.nn.functional.linear(h, orc.W["lm_head.weight"])
-        t0 = time.time()
-        torch.nn.functional.linear(ref_cpu.rmsnorm(h, orc.W["model.norm.weight"], lc.rms_eps), orc.W["lm_head.weight"])
-        t_head = time.time() - t0
-    scale = lc.layers / sample_layers
-    t_prefill_full = max(t_prefill - t_head, 0.0) * scale + t_head
-    t_step_full = max(t_step - t_head, 0.0) * scale + t_head
-    t_report = t_enc + t_prefill_full + new_tokens * t_step_full
+            logits, past, _ = orc.forward(torch.nn.functional.embedding(nxt[:, None], E), km, ref_cpu.positions_from_mask(km)[:, -1:], past)
+        t_tok = (time.time() - t0) / (n_tok - 1)
+    t_cfg0 = t_enc + t_prefill + (n_tok - 1) * t_tok
+    t_report = t_enc + t_prefill + new_tokens * t_tok
     return {
         "value": 1.0 / t_report, "unit": "reports/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
-        "sample": (f"oracle/ref_cpu.py on {threads} torch threads (fastest of a calibration sweep; host has {os.cpu_count()} cpus): "
-                   f"1 image full-size encode ({t_enc:.2f} s, cold) + {sample_layers}/{lc.layers} decoder layers "
-                   f"({dtype_name}) for prefill T={prompt_len} ({t_prefill:.2f} s) and {sample_steps} decode steps "
-                   f"(best {t_step*1e3:.0f} ms), lm_head {t_head*1e3:.0f} ms; extrapolated x{scale:.0f} layers, "
-                   f"{new_tokens} tokens -> {t_report:.1f} s/report; sample wall {time.time()-t_all:.0f} s"),
-        "s_per_token": t_step_full, "s_encode": t_enc, "s_prefill": t_prefill_full,
+        "sample": (f"oracle/ref_cpu.py, BASELINE configs[0] run in full on {threads} torch threads (fastest of a calibration sweep; host "
+                   f"has {os.cpu_count()} cpus): 1 image 448 px full-size encode {t_enc:.2f} s + prefill T={prompt_len} through all "
+                   f"{cfg.llama.layers} layers ({dtype_name}) {t_prefill:.2f} s + {n_tok} greedy tokens at {t_tok*1e3:.0f} ms/token = "
+                   f"{t_cfg0:.1f} s of CPU work; value = 1 / (encode + prefill + {new_tokens} x per-token) = 1 / {t_report:.1f} s; "
+                   f"wall incl. weight generation {time.time()-t_all:.0f} s"),
+        "s_per_token": t_tok, "s_encode": t_enc, "s_prefill": t_prefill, "config0_s": t_cfg0, "tokens": toks[:8],
     }
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms, use_graph):
+    """Per-phase numbers behind the headline (rank 0 only): encoder ms/img, prefill ms, mean decode step, the dominant kernel's
+    live HIP-event duration and the roofline fractions."""
+    lc = cfg.llama
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        eng.encode_image(img, want_image_embeds=False)
+    enc_ms = (time.perf_counter() - t1) / 5 / B * 1e3
+
+    def wbytes(n_rows, k):        # bytes per streamed weight element of a decode projection (mirrors the library's dispatch)
+        if not args.fp8:
+            return 2
+        tiles = (n_rows + 15) // 16
+        lds = B <= 16 and B * k * 2 <= 32 * 1024                     # batch-1..4 GEMV with LDS-staged activations
+        s32 = 16 < B <= 32 and tiles > 512 and k % 512 == 0          # skinny32.hip
+        xs = 3 <= B <= 32 and ((tiles >= 512 and k == 4096) or (128 <= tiles <= 512 and k in (4096, 11008)))   # xstat32.hip
+        return 1 if (lds or s32 or xs) else 2
+
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for _ in range(3):
+        eng.generate(ids, out_q, max_new=1, eos_id=-1, pad_id=0, use_graph=use_graph)
+    torch.cuda.synchronize()
+    prefill_ms = (time.perf_counter() - t2) / 3 * 1e3
+    avg_step_ms = (elapsed_per_step_ms - enc_ms * B - prefill_ms) / max(N - 1, 1)
+    H_, I_ = lc.hidden, lc.inter
+    step_bytes = llama_param_bytes(lc, wbytes)
+    kv_bytes = B * (T + N / 2.0) * 524288 + B * 524288          # SURVEY 8(d): 2 x 32 layers x 4096 x 2 B per cached token
+    # dominant kernel of the decode loop, HIP events on the library's stream
+    eng.generate(ids, out_q, max_new=8, eos_id=-1, pad_id=0, use_graph=use_graph)        # state: a prefill + a few steps
+    dom = None
+    if B <= 2:
+        try:
+            ms = eng.time_unit(7, 8)               # in situ: 8 eager decode steps, an event pair around each of the 32 chained launches
+            nb = H_ * I_ * wbytes(H_, I_) + (3 * H_ + 2 * lc.lora_r) * H_ * wbytes(3 * H_ + 16, H_) + B * (I_ + 2 * H_ + 3 * H_ + 16) * 2 + H_ * 2
+            dom = (f"decode_layers_k<{args.dtype}{',W8' if wbytes(H_, I_) == 1 else ''}> (chained down_proj(l) -> RMSNorm+QKV(l+1) launch, fence-free hand-off)",
+                   ms, nb, f"decode_layers_k B={B} {args.dtype}{' fp8' if args.fp8 else ''}")
+        except Exception:
+            dom = None
+    if dom is None:
+        ms = eng.time_unit(1, 10)
+        wb = wbytes(2 * I_, H_)
+        nb = 2 * I_ * H_ * wb + B * H_ * 2 + H_ * 2 + B * I_ * 2
+        nm = (f"xstat32_k<{args.dtype},EPI_SILU_MUL{',W8' if wb == 1 else ''}> (gate/up SwiGLU, activation-stationary batch 3-32 GEMM)" if B > 2 else
+              f"skinny_gemm_k<{args.dtype},MT,EPI_SILU_MUL,NORM{',W8' if wb == 1 else ''}> (gate/up SwiGLU GEMV)")
+        dom = (nm, ms, nb, f"gate_up B={B} {args.dtype}{' fp8' if args.fp8 else ''}")
+    name, k_ms, k_bytes, key = dom
+    eng.generate(ids, out_q, max_new=8, eos_id=-1, pad_id=0, use_graph=use_graph)
+    step_ms = eng.time_unit(0, 20)
+    enc_tf = encode_flops(cfg) / (enc_ms * 1e-3) / 1e12
+    pre_tf = prefill_flops(lc, T, B) / (prefill_ms * 1e-3) / 1e12
+    roof = {
+        "bound": "hbm", "kernel": name,
+        "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(key),
+        "bytes_per_launch": k_bytes, "us_per_launch": k_ms * 1e3,
+        "decode_step_ms": step_ms, "decode_step_weight_GBs": step_bytes / (step_ms * 1e-3) / 1e9,
+        "decode_step_frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        # average over the timed reports: (weights + KV read/write per SURVEY 8(d)) / mean step time / 8 TB/s
+        "prefill_ms": prefill_ms, "decode_avg_step_ms": avg_step_ms,
+        "decode_avg_frac": (step_bytes + kv_bytes) / (avg_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "mfma": {"peak_tflops": MFMA_PEAK_TFLOPS, "encode_gflop_per_img": encode_flops(cfg) / 1e9, "encode_tflops": enc_tf,
+                 "encode_frac": enc_tf / MFMA_PEAK_TFLOPS, "prefill_tflop": prefill_flops(lc, T, B) / 1e12, "prefill_tflops": pre_tf,
+                 "prefill_frac": pre_tf / MFMA_PEAK_TFLOPS,
+                 "prefill_weight_GBs": step_bytes / (prefill_ms * 1e-3) / 1e9},
+    }
+    return enc_ms, roof
+
+
+def run_steps(eng, cfg, args, B, T, N, rank, world, dist, steps, warmup, use_graph):
+    from radialog_amd import synth
+    from radialog_amd.shard import allgather_tokens
+    img = synth.synth_images(B, cfg.vision.img, seed=16 + rank).to(eng.device)
+    ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, pad_rows=(B > 1), seed=7 + rank).to(eng.device)
+    box = {}
+
+    def step():
+        q, _ = eng.encode_image(img, want_image_embeds=False)
+        box["q"] = q
+        toks, _, n = eng.generate(ids, q, max_new=N, eos_id=-1, pad_id=0, use_graph=use_graph)
+        return allgather_tokens(toks, world, engine=eng)          # librdx's ncclAllGather when a communicator is up, else identity
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    return elapsed, out, img, ids, box.get("q")
 
 
 def main():
@@ -148,7 +283,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 or "RANK" in os.environ:     # launched by torch.distributed.run (also at --nproc-per-node 1)
+    launched = world > 1 or "RANK" in os.environ      # by torch.distributed.run (also at --nproc-per-node 1)
+    if launched:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -157,99 +293,32 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
-    from radialog_amd import synth
     from radialog_amd.config import full_cfg
     from radialog_amd.engine import RdxEngine, synth_getter
-    from radialog_amd.shard import allgather_tokens
+    from radialog_amd.shard import init_comm
 
     cfg = full_cfg()
     B, T, N = args.batch, args.prompt_len, args.new_tokens
     max_len = (T + N + 64 + 31) // 32 * 32
+    use_graph = not args.no_graph
     eng = RdxEngine(cfg, dtype=args.dtype, device=local_rank, max_batch=B, max_len=max_len, lora=True, weights_fp8=args.fp8)
     eng.load_weights(synth_getter(cfg, eng.device, lora=True))
+    if launched:
+        init_comm(eng, rank, world)                   # RCCL communicator inside librdx (rdx_comm_init)
 
-    # this rank's shard of the (synthetic) image batch and prompts, resident in HBM before the timed region
-    img = synth.synth_images(B, cfg.vision.img, seed=16 + rank).to(eng.device)
-    ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, pad_rows=(B > 1), seed=7 + rank).to(eng.device)
-    use_graph = not args.no_graph
-
-    out_q = None
-
-    def step():
-        nonlocal out_q
-        q, _ = eng.encode_image(img, want_image_embeds=False)
-        out_q = q
-        toks, _, n = eng.generate(ids, q, max_new=N, eos_id=-1, pad_id=0, use_graph=use_graph)
-        if world > 1:
-            return allgather_tokens(toks, world)
-        return toks
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        out = step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, out, img, ids, out_q = run_steps(eng, cfg, args, B, T, N, rank, world, dist, args.steps, args.warmup, use_graph)
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
         te = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        allt = [torch.zeros_like(te) for _ in range(world)]
+        dist.all_gather(allt, te)
+        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in allt]
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
     assert out.shape[0] == B * world and out.shape[1] == N
 
     if rank == 0:
-        # encoder ms/img (second half of the metric), measured alone
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            eng.encode_image(img, want_image_embeds=False)
-        enc_ms = (time.perf_counter() - t1) / 5 / B * 1e3
-        # dominant kernel: gate/up SwiGLU GEMV, HIP events on the library's stream
-        lc = cfg.llama
-        gu_ms = eng.time_unit(1, 10)
-        def wbytes(n_rows, k):        # bytes per streamed weight element of a decode projection (mirrors the library's dispatch)
-            if not args.fp8:
-                return 2
-            tiles = (n_rows + 15) // 16
-            lds = B <= 16 and B * k * 2 <= 32 * 1024                     # batch-1..4 GEMV with LDS-staged activations
-            s32 = 16 < B <= 32 and tiles > 512 and k % 512 == 0          # skinny32.hip
-            xs = 3 <= B <= 32 and ((tiles >= 512 and k == 4096) or (128 <= tiles <= 512 and k in (4096, 11008)))   # xstat32.hip
-            return 1 if (lds or s32 or xs) else 2
-        wb = wbytes(2 * lc.inter, lc.hidden)
-        gu_bytes = 2 * lc.inter * lc.hidden * wb + B * lc.hidden * 2 + lc.hidden * 2 + B * lc.inter * 2
-        # whole-decode average: one report minus its encode and its prefill (+ first token), over the N-1 graph-replayed steps
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        for _ in range(3):
-            eng.generate(ids, out_q, max_new=1, eos_id=-1, pad_id=0, use_graph=use_graph)
-        torch.cuda.synchronize()
-        prefill_ms = (time.perf_counter() - t2) / 3 * 1e3
-        avg_step_ms = (elapsed / args.steps * 1e3 - enc_ms * B - prefill_ms) / max(N - 1, 1)
-        kv_bytes = B * (T + N / 2.0) * 524288 + B * 524288          # 2 x 32 layers x 4096 x 2 B per cached token
-        step_ms = eng.time_unit(0, 20)
-        L_avg = T + 64      # rdx_time(0) replays from the state left by the last generate (slot ~ T+N) -- report as measured
-        H_, I_ = lc.hidden, lc.inter
-        step_bytes = (32 * (3 * H_ * H_ * wbytes(3 * H_ + 16, H_) + H_ * H_ * wbytes(H_, H_) + 2 * I_ * H_ * wbytes(2 * I_, H_)
-                            + H_ * I_ * wbytes(H_, I_)) + lc.vocab * H_ * wbytes(lc.vocab, H_) + (32 * 2 * H_ + H_) * 2)
-        roof = {
-            "bound": "hbm", "kernel": (f"xstat32_k<{args.dtype},EPI_SILU_MUL{',W8' if wb == 1 else ''}> (gate/up SwiGLU, activation-stationary batch 3-32 GEMM)" if B > 2 else
-                                       f"skinny_gemm_k<{args.dtype},MT,EPI_SILU_MUL,NORM{',W8' if wb == 1 else ''}> (gate/up SwiGLU GEMV)"),
-            "achieved": gu_bytes / (gu_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gu_bytes / (gu_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(B, args.dtype, args.fp8),
-            "bytes_per_launch": gu_bytes, "us_per_launch": gu_ms * 1e3,
-            "decode_step_ms": step_ms, "decode_step_weight_GBs": step_bytes / (step_ms * 1e-3) / 1e9,
-            "decode_step_frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            # average over the timed reports: (weights + KV read/write per SURVEY 8(d)) / mean step time / 8 TB/s
-            "prefill_ms": prefill_ms, "decode_avg_step_ms": avg_step_ms,
-            "decode_avg_frac": (step_bytes + kv_bytes) / (avg_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        }
+        enc_ms, roof = measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed / args.steps * 1e3, use_graph)
         res = {
             "metric": "reports_per_sec (448px CXR encode + 160-tok prefill + 256-tok greedy decode)",
             "value": args.steps * B * world / elapsed, "unit": "reports/s",
@@ -263,12 +332,30 @@ def main():
                        "parallelism": f"dp{world}", "weights": "random-init (deterministic generator)"},
             "encoder_ms_per_img": enc_ms,
             "tokens_per_s": args.steps * B * world * N / elapsed,
+            "rccl_ranks": eng.comm_world, "per_rank_ms_per_step": per_rank_ms,
+            "collective": ("rdx_allgather_tokens (ncclAllGather inside librdx), int32[%d,%d] per rank per step" % (B, N)) if eng.comm_world else None,
             "roofline": roof,
         }
+        eng.close()
+        if world == 1 and B == 1 and not args.fp8 and not args.no_b32:
+            # BASELINE configs[2] in the same process and JSON line: batch 32, KV cache in HBM, hipGraph-captured decode step
+            B2 = 32
+            eng2 = RdxEngine(cfg, dtype=args.dtype, device=local_rank, max_batch=B2, max_len=max_len, lora=True)
+            eng2.load_weights(synth_getter(cfg, eng2.device, lora=True))
+            k2 = max(2, min(args.steps, 3))
+            el2, out2, img2, ids2, q2 = run_steps(eng2, cfg, args, B2, T, N, rank, 1, None, k2, 1, use_graph)
+            enc2, roof2 = measure_detail(eng2, cfg, args, B2, T, N, img2, ids2, q2, el2 / k2 * 1e3, use_graph)
+            res["b32"] = {"workload": "configs[2]: per-GPU batch 32, same pipeline, hipGraph-captured decode step", "value": k2 * B2 / el2,
+                          "unit": "reports/s", "steps": k2, "warmup": 1, "ms_per_step": el2 / k2 * 1e3, "tokens_per_s": k2 * B2 * N / el2,
+                          "encoder_ms_per_img": enc2, "prefill_ms": roof2["prefill_ms"], "decode_avg_step_ms": roof2["decode_avg_step_ms"],
+                          "decode_avg_frac": roof2["decode_avg_frac"], "kernel": roof2["kernel"], "kernel_frac": roof2["frac"],
+                          "kernel_us": roof2["us_per_launch"], "traffic": roof2["traffic"], "mfma": roof2["mfma"]}
+            eng2.close()
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg, args.dtype, T, N)
+            res["cpu_baseline"] = cpu_baseline(cfg, args.dtype, T, N, torch.device("cuda", local_rank))
         print(json.dumps(res), flush=True)
-    eng.close()
+    else:
+        eng.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

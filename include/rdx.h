@@ -110,6 +110,36 @@ int rdx_prefill_append(rdx_ctx* ctx, const int32_t* ids_tail, int batch, int T_t
 int rdx_generate_append(rdx_ctx* ctx, const int32_t* ids_tail, int batch, int T_tail, int keep_len, int max_new, int eos_id,
                         int pad_id, int32_t* out_tokens, void* scores, int* n_steps_host, int use_graph);
 
+/* LlamaForCausalLM.generate(..., num_beams = k > 1) (test.py:467,:629 pass `num_beams=args.num_beams`): transformers 4.28.1
+ * GenerationMixin.beam_search driven by BeamSearchScorer (length_penalty 1.0, early_stopping False, one returned hypothesis per
+ * prompt by default) over the same forward, with `_reorder_cache` (modeling_llama_imgemb.py:838-843) between steps.
+ *   ids / mask / qformer_embs  rows = groups * num_beams, ALREADY expanded the way _expand_inputs_for_generation lays them out
+ *                (row r belongs to prompt r / num_beams; the k rows of a prompt are identical); rows <= max_batch
+ *   out_tokens_host int32[groups][max_new] (HOST): generated ids of the best hypothesis, pad_id behind its end; the caller appends
+ *                the EOS / pads to a common length like BeamSearchScorer.finalize. out_len_host[groups]: generated length;
+ *                out_score_host[groups] (nullable): sum of log-probs / length ** length_penalty
+ *   step_scores  nullable DEVICE buffer, model dtype [max_new][rows][vocab]: the processed next-token scores (log_softmax) of every
+ *                step, what HF returns as `.scores` for beam search
+ *   n_steps_host decoder forwards consumed (prompt included) */
+int rdx_beam_search(rdx_ctx* ctx, const int32_t* ids, const int32_t* mask, int groups, int num_beams, int T, const float* qformer_embs,
+                    int max_new, int eos_id, int pad_id, float length_penalty, int early_stopping, int32_t* out_tokens_host,
+                    int32_t* out_len_host, float* out_score_host, void* step_scores, int* n_steps_host);
+
+/* Data-parallel report generation: every image / report is an independent unit, each rank (one process per GPU)
+ * runs encode -> prefill -> decode on its own shard with a full weight replica and NO data-path collective; the generated token ids
+ * are gathered once at the end with ONE RCCL all-gather over xGMI. The reference has no inference-time collective (its only
+ * distributed code is LAVIS' training DDP, runner_base.py:101-118): this is the addition north_star asks for.
+ *   rdx_comm_unique_id  rank 0 creates the 128-byte RCCL id (ncclGetUniqueId); the caller hands it to every rank over any host
+ *                       channel (radialog_amd/shard.py uses the launcher's TCP store)
+ *   rdx_comm_init       ncclCommInitRank on the context's device; collective: every rank of `world` must call it
+ *   rdx_allgather_tokens local int32[rows_local][n] (device) -> global int32[world * rows_local][n] (device), rank-major, enqueued
+ *                       on the context's stream (rdx_sync to wait); rows_local and n must be the same on every rank */
+typedef struct rdx_unique_id { char internal[128]; } rdx_unique_id;
+int rdx_comm_unique_id(rdx_unique_id* id_host);
+int rdx_comm_init(rdx_ctx* ctx, const rdx_unique_id* id_host, int rank, int world);
+int rdx_allgather_tokens(rdx_ctx* ctx, const int32_t* local, int32_t* global, int rows_local, int n);
+int rdx_comm_world(rdx_ctx* ctx);                  /* ranks of the initialised communicator, 0 = none */
+
 /* introspection for tests / benchmarks */
 int rdx_kv_read(rdx_ctx* ctx, int layer, int which /*0=K,1=V*/, void* dst /*model dtype [B][heads][max_len][D]*/);
 int rdx_hidden_read(rdx_ctx* ctx, void* dst /*model dtype [B][hidden]: decoder output rows of the last call*/);
@@ -117,6 +147,8 @@ int rdx_hidden_read(rdx_ctx* ctx, void* dst /*model dtype [B][hidden]: decoder o
  *   what = 0: one decode step (whole graph) at the current state, `iters` replays
  *   what = 1: the gate/up SwiGLU weight-streaming GEMV of every layer in turn, `iters` sweeps -> ms per launch
  *   what = 2: ... the QKV GEMV, 3: o_proj, 4: down_proj, 5: lm_head, 6: decode attention (re-appends the current KV row);
+ *   what = 7: the chained down(l) -> QKV(l+1) launch (decode_layers_k, the batch <= 2 default), measured in situ: `iters` eager
+ *             decode steps with an event pair around each of its launches -> ms per launch
  *   what + 10: the same unit on layer 0 only (weights stay cache resident)
  *   At batch >= 3 the RMSNorm in front of QKV / gate-up / lm_head is a launch of its own: it runs once, outside the timed region, and
  *   units 1, 2, 5 time the GEMM launches alone. */

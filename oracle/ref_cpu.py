@@ -339,6 +339,7 @@ class LlamaOracle:
         for l in range(nl):
             x, kv = self.layer(l, x, mask, pos_ids, None if past is None else past[l])
             new_past.append(kv)
+        self.last_hidden = x                                   # decoder output before the final norm (diagnostics)
         h = rmsnorm(x, self.W["model.norm.weight"], self.cfg.rms_eps)
         hl = h if all_logits else h[:, -1:]
         logits = self._linear(hl, self.W["lm_head.weight"])
@@ -376,6 +377,111 @@ class LlamaOracle:
             x = F.embedding(nxt[:, None].clamp(max=E.shape[0] - 1), E)
             logits, past, _ = self.forward(x, key_mask, pos, past)
         return {"tokens": torch.stack(toks, dim=1), "scores": scores, "margins": torch.stack(margins, 0)}
+
+
+    # -- beam search (transformers==4.28.1 GenerationMixin.beam_search + BeamSearchScorer / BeamHypotheses, restated) -----------
+    def generate_beam(self, ids: torch.Tensor, qformer_embs: Optional[torch.Tensor], num_beams: int, max_new: int, eos_id: int = 2,
+                      pad_id: int = 0, length_penalty: float = 1.0, early_stopping: bool = False):
+        """PARITY UNPINNED at the loop level (third-party, like the greedy rule); the per-step forward is the pinned one and the cache
+        reorder is the reference's own `_reorder_cache` (modeling_llama_imgemb.py:838-843: index_select(0, beam_idx) on every K / V).
+        Candidate ties (frequent: fp16 log-probs are quantised to 2^-8 at |lp| ~ 7) are broken towards the lowest beam * V + token
+        index (a stable sort; torch.topk leaves the order of equal values unspecified, on CPU and on the reference's GPU alike).
+        Returns {"tokens": list of B int lists (best hypothesis, generated part), "scores": [B] sequence scores, "sequences":
+        int64 [B, T + n] as finalize() pads them, "min_gap": the smallest score gap, over all live group-steps, at the two places
+        where a numerical error changes WHICH candidates survive -- between the last candidate taken and the next one, and
+        between ranks k - 1 and k (the EOS acceptance rule); an error below half of it changes no decision -- "steps": forwards}."""
+        B, T = ids.shape
+        k = num_beams
+        key_mask = ids.ne(pad_id).long().repeat_interleave(k, 0)
+        xids = ids.repeat_interleave(k, 0)
+        qf = None if qformer_embs is None else qformer_embs.repeat_interleave(k, 0)
+        x = self.embed(xids, qf)
+        logits, past, _ = self.forward(x, key_mask, positions_from_mask(key_mask))
+        beam_scores = torch.zeros(B, k, dtype=torch.float32)
+        beam_scores[:, 1:] = -1e9
+        beam_scores = beam_scores.view(-1)
+        hist = [[] for _ in range(B * k)]
+        hyps = [{"beams": [], "worst": 1e9} for _ in range(B)]
+        done = [False] * B
+        E = self.W["model.embed_tokens.weight"]
+        V = logits.shape[-1]
+        cur_len, steps, min_gap = T, 0, float("inf")
+
+        def add(h, gen, full_len, sum_logprobs):
+            score = sum_logprobs / (full_len ** length_penalty)
+            if len(h["beams"]) < k or score > h["worst"]:
+                h["beams"].append((score, list(gen)))
+                if len(h["beams"]) > k:
+                    order = sorted([(sc, i) for i, (sc, _) in enumerate(h["beams"])])
+                    del h["beams"][order[0][1]]
+                    h["worst"] = order[1][0]
+                else:
+                    h["worst"] = min(score, h["worst"])
+
+        def is_done(h, best_sum, clen):
+            if len(h["beams"]) < k:
+                return False
+            if early_stopping:
+                return True
+            return h["worst"] >= best_sum / clen ** length_penalty
+
+        while True:
+            steps += 1
+            lp = F.log_softmax(logits[:, -1, :], dim=-1)                      # model dtype, like HF on half logits
+            nts = (lp + beam_scores[:, None]).view(B, k * V)                  # fp32 (type promotion)
+            srt = torch.sort(nts, dim=1, descending=True, stable=True)
+            top_s, top_i = srt.values[:, : 2 * k + 1], srt.indices[:, : 2 * k + 1]
+            nb_scores = torch.zeros(B, k)
+            nb_tokens = torch.zeros(B, k, dtype=torch.long)
+            nb_idx = torch.zeros(B, k, dtype=torch.long)
+            for b in range(B):
+                if done[b]:
+                    nb_tokens[b] = pad_id
+                    nb_idx[b] = torch.arange(b * k, (b + 1) * k)              # (HF writes 0 here; those rows are never read again)
+                    continue
+                n = 0
+                for rank in range(2 * k):
+                    tok, sc, frm = int(top_i[b, rank]) % V, float(top_s[b, rank]), b * k + int(top_i[b, rank]) // V
+                    if eos_id >= 0 and tok == eos_id:
+                        if rank >= k:
+                            continue
+                        add(hyps[b], hist[frm], cur_len, sc)
+                    else:
+                        nb_scores[b, n], nb_tokens[b, n], nb_idx[b, n] = sc, tok, frm
+                        n += 1
+                    if n == k:
+                        break
+                assert n == k
+                min_gap = min(min_gap, float(top_s[b, rank] - top_s[b, rank + 1]), float(top_s[b, k - 1] - top_s[b, k]))
+                done[b] = done[b] or is_done(hyps[b], float(top_s[b].max()), cur_len)
+            beam_scores = nb_scores.view(-1)
+            beam_idx, toks = nb_idx.view(-1), nb_tokens.view(-1)
+            hist = [hist[int(beam_idx[r])] + [int(toks[r])] for r in range(B * k)]
+            cur_len += 1
+            key_mask = torch.cat([key_mask, key_mask.new_ones(B * k, 1)], dim=-1)
+            past = [(kk.index_select(0, beam_idx), vv.index_select(0, beam_idx)) for kk, vv in past]        # _reorder_cache
+            if all(done) or cur_len >= T + max_new:
+                break
+            pos = positions_from_mask(key_mask)[:, -1:]
+            x = F.embedding(toks[:, None].clamp(max=E.shape[0] - 1), E)
+            logits, past, _ = self.forward(x, key_mask, pos, past)
+        out_tokens, out_scores = [], []
+        for b in range(B):
+            if not done[b]:
+                for j in range(k):
+                    add(hyps[b], hist[b * k + j], cur_len, float(beam_scores[b * k + j]))
+            best = sorted(hyps[b]["beams"], key=lambda t: t[0]).pop()
+            out_tokens.append(best[1])
+            out_scores.append(best[0])
+        lens = [len(t) for t in out_tokens]
+        sent_max = min(max(lens) + 1, max_new)
+        seq = torch.full((B, sent_max), pad_id, dtype=torch.long)
+        for b in range(B):
+            seq[b, : lens[b]] = torch.tensor(out_tokens[b], dtype=torch.long)
+            if lens[b] < sent_max and eos_id >= 0:
+                seq[b, lens[b]] = eos_id
+        return {"tokens": out_tokens, "scores": torch.tensor(out_scores), "sequences": torch.cat([ids, seq], 1), "min_gap": min_gap,
+                "steps": steps}
 
 
 # =====================================================================================================

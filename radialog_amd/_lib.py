@@ -65,6 +65,12 @@ SYMBOLS = {
     "rdx_prefill_append": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rdx_generate_append": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,
                                       C.POINTER(C.c_int), C.c_int]),
+    "rdx_beam_search": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, _P, _P, _P, _P,
+                                  C.POINTER(C.c_int)]),
+    "rdx_comm_unique_id": (C.c_int, [_P]),
+    "rdx_comm_init": (C.c_int, [_P, _P, C.c_int, C.c_int]),
+    "rdx_allgather_tokens": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
+    "rdx_comm_world": (C.c_int, [_P]),
     "rdx_kv_read": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "rdx_hidden_read": (C.c_int, [_P, _P]),
     "rdx_time": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),

@@ -99,11 +99,10 @@ class Blip2Qformer:
                  cfg: Optional[RaDialogCfg] = None, max_txt_len=32, synthetic: bool = False, **_unused):
         if vit_model != "biovil":
             raise NotImplementedError("RaDialog only instantiates vit_model='biovil' (blip2.py:64-88)")
+        import dataclasses
         base = cfg or RaDialogCfg()
-        v = VisionCfg(img=img_size, stem=base.vision.stem, planes=base.vision.planes, blocks=base.vision.blocks,
-                      b2v=base.vision.b2v, proj=base.vision.proj)
-        q = QFormerCfg(hidden=base.qformer.hidden, layers=base.qformer.layers, heads=base.qformer.heads,
-                       inter=base.qformer.inter, enc_width=v.proj, n_query=num_query_token, cross_freq=cross_attention_freq)
+        v = dataclasses.replace(base.vision, img=img_size)
+        q = dataclasses.replace(base.qformer, enc_width=v.proj, n_query=num_query_token, cross_freq=cross_attention_freq)
         self.cfg = RaDialogCfg(llama=base.llama, qformer=q, vision=v)
         self.dtype = dtype
         self.max_txt_len = max_txt_len

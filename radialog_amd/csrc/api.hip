@@ -2,6 +2,7 @@
 // (image encode -> Q-Former -> img_proj + <IMG> splice -> Llama prefill -> hipGraph-captured greedy decode).
 // Kernels live in gemm.hip / attn.hip / elem.hip; this file only sequences launches on the context's stream.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -47,8 +48,9 @@ struct PoolBlock {          // one VisionTransformerPooler block (two-image mode
 struct GraphKey {
     int B = -1, max_new = 0, eos = 0, pad = 0;
     const void* tokens = nullptr; const void* scores = nullptr;
+    bool fixed = false;             // logits always to `scores` itself (beam search) instead of scores + step * stride
     bool operator==(const GraphKey& o) const {
-        return B == o.B && max_new == o.max_new && eos == o.eos && pad == o.pad && tokens == o.tokens && scores == o.scores;
+        return B == o.B && max_new == o.max_new && eos == o.eos && pad == o.pad && tokens == o.tokens && scores == o.scores && fixed == o.fixed;
     }
 };
 
@@ -104,6 +106,14 @@ struct rdx_ctx {
     bool use_dma_gemm = true;        // RDX_DMA=0: route every large-M GEMM through tiled_gemm_k
     float* gemm_ws = nullptr; size_t gemm_ws_floats = 0;      // split-K slabs of gemm_dma_k
     GraphKey gkey;
+
+    // ---- beam search workspaces (rdx_beam_search), sized on first use ----
+    void* bm_logits = nullptr; float* bm_scores = nullptr; float* bm_cand_s = nullptr; int* bm_cand_i = nullptr;
+    int *bm_tok = nullptr, *bm_src = nullptr; int32_t* bm_out = nullptr; void* bm_scratch = nullptr;
+    size_t bm_scratch_bytes = 0; int bm_rows = 0, bm_new = 0;
+
+    // ---- data-parallel collective (RCCL over xGMI): the one all-gather of generated token ids ----
+    void* comm = nullptr; int comm_rank = 0, comm_world = 0;
 
     // ---- q-former ----
     std::vector<QLayer> ql;
@@ -300,10 +310,75 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// RCCL, bound at run time: librccl is only needed by multi-GPU jobs, and the process usually has torch's copy loaded already
+// (same soname -> the same instance is shared). No RCCL type crosses the C ABI: the unique id travels as 128 opaque bytes.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, rdx_unique_id, int) = nullptr;       // ncclUniqueId is a 128-byte struct passed by value
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string err;
+    bool load() {
+        if (h) return true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;       // torch's instance, if it is there
+        if (!h) for (const char* n : names) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+        GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+        CommInitRank = (int (*)(void**, int, rdx_unique_id, int))dlsym(h, "ncclCommInitRank");
+        AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+        CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+        GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy || !GetErrorString) { err = "librccl lacks an expected symbol"; h = nullptr; return false; }
+        return true;
+    }
+    const char* what(int rc) { return GetErrorString ? GetErrorString(rc) : "?"; }
+};
+Rccl g_rccl;
+constexpr int kNcclInt32 = 2;        // ncclInt32 in rccl.h's ncclDataType_t
+}  // namespace
+
+extern "C" int rdx_comm_unique_id(rdx_unique_id* id_host) {
+    if (!id_host) return fail(nullptr, -1, "rdx_comm_unique_id: null argument");
+    if (!g_rccl.load()) return fail(nullptr, -6, "rdx_comm_unique_id: %s", g_rccl.err.c_str());
+    const int rc = g_rccl.GetUniqueId(id_host);
+    if (rc) return fail(nullptr, -6, "ncclGetUniqueId failed: %s", g_rccl.what(rc));
+    return 0;
+}
+
+extern "C" int rdx_comm_init(rdx_ctx* c, const rdx_unique_id* id_host, int rank, int world) {
+    if (!c || !id_host) return fail(c, -1, "rdx_comm_init: null argument");
+    if (world <= 0 || rank < 0 || rank >= world) return fail(c, -1, "rdx_comm_init: bad rank %d / world %d", rank, world);
+    if (c->comm) return fail(c, -1, "rdx_comm_init: communicator already initialised");
+    if (!g_rccl.load()) return fail(c, -6, "rdx_comm_init: %s", g_rccl.err.c_str());
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = g_rccl.CommInitRank(&c->comm, world, *id_host, rank);
+    if (rc) { c->comm = nullptr; return fail(c, -6, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, g_rccl.what(rc)); }
+    c->comm_rank = rank; c->comm_world = world;
+    return 0;
+}
+
+extern "C" int rdx_allgather_tokens(rdx_ctx* c, const int32_t* local, int32_t* global, int rows_local, int n) {
+    if (!c || !local || !global || rows_local <= 0 || n <= 0) return fail(c, -1, "rdx_allgather_tokens: bad arguments");
+    if (!c->comm) return fail(c, -1, "rdx_allgather_tokens: rdx_comm_init has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int rc = g_rccl.AllGather(local, global, (size_t)rows_local * n, kNcclInt32, c->comm, c->stream);
+    if (rc) return fail(c, -6, "ncclAllGather failed: %s", g_rccl.what(rc));
+    return 0;
+}
+
+extern "C" int rdx_comm_world(rdx_ctx* c) { return (c && c->comm) ? c->comm_world : 0; }
+
 extern "C" void rdx_destroy(rdx_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
     if (c->graph) hipGraphExecDestroy(c->graph);
     for (void* p : c->allocs) hipFree(p);
     hipStreamDestroy(c->stream);
@@ -873,7 +948,8 @@ extern "C" int rdx_prefill_append(rdx_ctx* c, const int32_t* ids_tail, int B, in
 
 static int decode_loop(rdx_ctx* c, int B, int max_new, int eos_id, void* scores, int* n_steps_host, int use_graph);
 
-static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, long step_stride) {
+// evs (timing only, eager launches): a pair of events recorded around every chained down(l) -> QKV(l+1) launch of this step
+static bool decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, long step_stride, std::vector<hipEvent_t>* evs = nullptr) {
     const rdx_config& f = c->cfg;
     const int dt = f.dtype, H = f.hidden, B = c->cur_B;
     hipStream_t s = c->stream;
@@ -889,7 +965,7 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
             launch_decode_layers(dt, ma, std::min(per, f.layers - l0), c->mega_occ, s);
         }
         lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
-        return;
+        return false;
     }
     // the hand-off counter shards of the fused launches are cleared by greedy_step_k at the end of the previous step
     // (and of the prefill): a memset node at the head of the step graph was observed to race with the first producers
@@ -938,7 +1014,9 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         }
         if (chain) {          // RDX_CHAIN=2: gate/up stand-alone, then down(l) -> qkv(l+1) chained
             { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; skinny(c, a, EPI_SILU_MUL); }
+            if (evs) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s); evs->push_back(e); }
             launch_decode_roles(dt, ma, l * 5 + 4, std::min((l + 1) * 5 + 1, f.layers * 5), c->mega_occ, s);
+            if (evs) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, s); evs->push_back(e); }
             continue;
         }
         const bool split = down_split_ok(c, L, B);
@@ -948,6 +1026,7 @@ static void decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, lo
         launch_down(c, L, B, split);
     }
     lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
+    return chain && c->chain_mlp == 2;
 }
 
 // Debug: run ONE eager decode step through the chained decode-layer kernel with per-workgroup timestamps and copy
@@ -1031,15 +1110,15 @@ extern "C" int rdx_decode_step(rdx_ctx* c, void* logits) {
     return 0;
 }
 
-static int build_graph(rdx_ctx* c, void* scores) {
+static int build_graph(rdx_ctx* c, void* scores, bool fixed = false) {
     const rdx_config& f = c->cfg;
     GraphKey k;
-    k.B = c->cur_B; k.max_new = c->cur_max_new; k.eos = c->cur_eos; k.pad = c->cur_pad; k.tokens = c->cur_tokens; k.scores = scores;
+    k.B = c->cur_B; k.max_new = c->cur_max_new; k.eos = c->cur_eos; k.pad = c->cur_pad; k.tokens = c->cur_tokens; k.scores = scores; k.fixed = fixed;
     if (c->graph && k == c->gkey) return 0;
     if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
     hipGraph_t g = nullptr;
     HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-    decode_step_launch(c, scores, scores ? c->d_step : nullptr, (long)c->cur_B * f.vocab);
+    decode_step_launch(c, scores, (scores && !fixed) ? c->d_step : nullptr, (long)c->cur_B * f.vocab);
     HIPCHK(c, hipStreamEndCapture(c->stream, &g));
     HIPCHK(c, hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
     HIPCHK(c, hipGraphDestroy(g));
@@ -1108,6 +1187,156 @@ static int decode_loop(rdx_ctx* c, int B, int max_new, int eos_id, void* scores,
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// beam search: transformers 4.28.1 GenerationMixin.beam_search + BeamSearchScorer, as
+// LlamaForCausalLM.generate(num_beams = k) runs it from test.py:467,:629; _reorder_cache = modeling_llama_imgemb.py:838-843
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+struct BeamHyp { float score; std::vector<int> toks; };
+struct BeamHyps {           // transformers 4.28.1 BeamHypotheses
+    int num_beams; float length_penalty; int early_stopping;
+    std::vector<BeamHyp> beams; float worst = 1e9f;
+    void add(const std::vector<int>& gen, int full_len, float sum_logprobs) {
+        const float score = sum_logprobs / powf((float)full_len, length_penalty);
+        if ((int)beams.size() < num_beams || score > worst) {
+            beams.push_back(BeamHyp{score, gen});
+            if ((int)beams.size() > num_beams) {
+                // sorted([(s, idx)]): drop the lowest score (lowest index on a tie), the runner-up becomes the worst kept score
+                int lo = 0;
+                for (int i = 1; i < (int)beams.size(); ++i) if (beams[i].score < beams[lo].score) lo = i;
+                beams.erase(beams.begin() + lo);
+                float w = beams[0].score;
+                for (const BeamHyp& h : beams) w = std::min(w, h.score);
+                worst = w;
+            } else {
+                worst = std::min(score, worst);
+            }
+        }
+    }
+    bool is_done(float best_sum_logprobs, int cur_len) const {
+        if ((int)beams.size() < num_beams) return false;
+        if (early_stopping) return true;
+        return worst >= best_sum_logprobs / powf((float)cur_len, length_penalty);
+    }
+};
+}  // namespace
+
+extern "C" int rdx_beam_search(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int groups, int num_beams, int T,
+                               const float* qformer_embs, int max_new, int eos_id, int pad_id, float length_penalty,
+                               int early_stopping, int32_t* out_tokens_host, int32_t* out_len_host, float* out_score_host,
+                               void* step_scores, int* n_steps_host) {
+    if (!c) return -1;
+    if (!c->finalized || !c->cfg.enable_llama) return fail(c, -1, "rdx_beam_search: llama weights not finalized");
+    const rdx_config& f = c->cfg;
+    const int rows = groups * num_beams;
+    if (groups <= 0 || num_beams < 2 || num_beams > RDX_MAX_BEAMS) return fail(c, -1, "rdx_beam_search: num_beams must be in [2, %d]", RDX_MAX_BEAMS);
+    if (rows > f.max_batch) return fail(c, -1, "rdx_beam_search: batch %d x %d beams exceeds max_batch %d", groups, num_beams, f.max_batch);
+    if (max_new <= 0 || !out_tokens_host || !out_len_host) return fail(c, -1, "rdx_beam_search: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int K2 = 2 * num_beams, V = f.vocab;
+    const int p_lo = T / 16 * 16, span = (T + max_new + 15) / 16 * 16 - p_lo;
+    if (rows > c->bm_rows || max_new > c->bm_new) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        dfree(c, c->bm_logits); dfree(c, c->bm_scores); dfree(c, c->bm_cand_s); dfree(c, c->bm_cand_i); dfree(c, c->bm_tok); dfree(c, c->bm_src); dfree(c, c->bm_out);
+        const int R = std::max(rows, c->bm_rows), N = std::max(max_new, c->bm_new);
+        c->bm_rows = 0;
+        ALLOC(c, c->bm_logits, (size_t)R * V * 2); ALLOC(c, c->bm_scores, (size_t)R * 4);
+        ALLOC(c, c->bm_cand_s, (size_t)R * 2 * 4); ALLOC(c, c->bm_cand_i, (size_t)R * 2 * 4);
+        ALLOC(c, c->bm_tok, (size_t)R * 4); ALLOC(c, c->bm_src, (size_t)R * 4); ALLOC(c, c->bm_out, (size_t)R * N * 4);
+        c->bm_rows = R; c->bm_new = N;
+    }
+    const size_t need = (size_t)f.layers * 2 * rows * f.heads * span * 256;
+    if (need > c->bm_scratch_bytes) {
+        HIPCHK(c, hipStreamSynchronize(s));
+        dfree(c, c->bm_scratch); c->bm_scratch_bytes = 0;
+        ALLOC(c, c->bm_scratch, need);
+        c->bm_scratch_bytes = need;
+    }
+    // the prompt: every beam row runs it (HF expands input_ids to batch x beams rows, _expand_inputs_for_generation); EOS handling is
+    // the scorer's, so the device-side greedy rule is disabled (eos -1); its argmax tokens go to a dummy buffer and are ignored
+    int rc = prefill_impl(c, ids, mask, rows, T, qformer_embs, 0, max_new, -1, pad_id, c->bm_out, c->bm_logits);
+    if (rc) return rc;
+    rc = build_graph(c, c->bm_logits, /*fixed=*/true);
+    if (rc) return rc;
+
+    std::vector<float> beam_scores(rows, -1e9f), cs((size_t)groups * K2);
+    for (int g = 0; g < groups; ++g) beam_scores[(size_t)g * num_beams] = 0.f;
+    std::vector<int> ci((size_t)groups * K2), next_tok(rows), src(rows);
+    std::vector<std::vector<int>> hist(rows), nh(rows);
+    std::vector<BeamHyps> hyps(groups);
+    for (BeamHyps& h : hyps) { h.num_beams = num_beams; h.length_penalty = length_penalty; h.early_stopping = early_stopping; }
+    std::vector<char> done(groups, 0);
+    int cur_len = T, steps = 0;
+    for (int step = 0; step < max_new; ++step) {
+        HIPCHK(c, hipMemcpyAsync(c->bm_scores, beam_scores.data(), rows * sizeof(float), hipMemcpyHostToDevice, s));
+        void* lp = step_scores ? (char*)step_scores + (size_t)step * rows * V * 2 : nullptr;
+        launch_beam_topk(f.dtype, c->bm_logits, c->bm_scores, groups, num_beams, V, c->bm_cand_s, c->bm_cand_i, lp, s);
+        HIPCHK(c, hipMemcpyAsync(cs.data(), c->bm_cand_s, cs.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipMemcpyAsync(ci.data(), c->bm_cand_i, ci.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        ++steps;
+        // BeamSearchScorer.process
+        for (int g = 0; g < groups; ++g) {
+            const int r0 = g * num_beams;
+            if (done[g]) {
+                for (int b = 0; b < num_beams; ++b) { beam_scores[r0 + b] = 0.f; next_tok[r0 + b] = pad_id; src[r0 + b] = r0 + b; }
+                continue;
+            }
+            int nb = 0;
+            for (int rank = 0; rank < K2 && nb < num_beams; ++rank) {
+                const float sc = cs[(size_t)g * K2 + rank];
+                const int flat = ci[(size_t)g * K2 + rank], from = r0 + flat / V, tok = flat % V;
+                if (eos_id >= 0 && tok == eos_id) {
+                    if (rank >= num_beams) continue;
+                    hyps[g].add(hist[from], cur_len, sc);
+                } else {
+                    beam_scores[r0 + nb] = sc; next_tok[r0 + nb] = tok; src[r0 + nb] = from;
+                    ++nb;
+                }
+            }
+            if (nb < num_beams) return fail(c, -7, "rdx_beam_search: fewer than %d live candidates in group %d (eos-only top-2k)", num_beams, g);
+            done[g] = done[g] || hyps[g].is_done(cs[(size_t)g * K2], cur_len);
+        }
+        for (int r = 0; r < rows; ++r) { nh[r] = hist[src[r]]; nh[r].push_back(next_tok[r]); }
+        hist.swap(nh);
+        ++cur_len;
+        bool all_done = true;
+        for (int g = 0; g < groups; ++g) all_done = all_done && done[g];
+        if (all_done || cur_len >= T + max_new) break;
+        // next forward: _reorder_cache (generated slots only -- the beams of a group share their prompt), chosen tokens in
+        HIPCHK(c, hipMemcpyAsync(c->bm_src, src.data(), rows * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->bm_tok, next_tok.data(), rows * sizeof(int), hipMemcpyHostToDevice, s));
+        bool identity = true;
+        for (int r = 0; r < rows; ++r) identity = identity && src[r] == r;
+        if (step > 0 && !identity)
+            launch_kv_beam_reorder(c->kcache, c->vcache, c->bm_scratch, c->bm_src, rows, f.heads, f.layers, f.max_len, c->kv_layer_elems * 2,
+                                   p_lo, std::min((T + step + 15) / 16 * 16, p_lo + span), s);
+        launch_embed_rows(f.dtype, c->bm_tok, c->embed, V, c->dx, rows, f.hidden, s);
+        HIPCHK(c, hipGraphLaunch(c->graph, s));
+    }
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    c->cur_steps = c->cur_max_new;
+    int herr = 0;
+    HIPCHK(c, hipMemcpy(&herr, c->d_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (herr) { hipMemset(c->d_err, 0, sizeof(int)); return fail(c, -5, "rdx_beam_search: a workgroup hand-off timed out inside a fused launch"); }
+    // BeamSearchScorer.finalize: open beams of unfinished groups become hypotheses, the best one per group is returned
+    for (int g = 0; g < groups; ++g) {
+        if (!done[g]) for (int b = 0; b < num_beams; ++b) hyps[g].add(hist[(size_t)g * num_beams + b], cur_len, beam_scores[(size_t)g * num_beams + b]);
+        int best = 0;                     // sorted(..., key = score) is stable and .pop() takes the last: the latest of equal scores
+        for (int i = 1; i < (int)hyps[g].beams.size(); ++i) if (hyps[g].beams[i].score >= hyps[g].beams[best].score) best = i;
+        const BeamHyp& h = hyps[g].beams[best];
+        const int n = std::min((int)h.toks.size(), max_new);
+        for (int i = 0; i < max_new; ++i) out_tokens_host[(size_t)g * max_new + i] = i < n ? h.toks[i] : pad_id;
+        out_len_host[g] = n;
+        if (out_score_host) out_score_host[g] = h.score;
+    }
+    if (n_steps_host) *n_steps_host = steps;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // introspection
 // ------------------------------------------------------------------------------------------------------------------
@@ -1137,6 +1366,27 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));
     int launches = 0;
+    if (what == 7) {
+        // the chained down(l) -> QKV(l+1) launch (decode_layers_k, batch <= 2), IN SITU: `iters` eager decode steps with an event pair
+        // around each of its launches (the hand-off counters are only valid inside a real step, so it cannot be looped alone)
+        std::vector<int> slot(B);
+        HIPCHK(c, hipMemcpyAsync(slot.data(), c->d_slot, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (slot[0] + iters >= f.max_len) return fail(c, -1, "rdx_time: %d steps would overflow the KV cache (slot %d, max_len %d)", iters, slot[0], f.max_len);
+        std::vector<hipEvent_t> evs;
+        bool chained = true;
+        for (int i = 0; i < iters && chained; ++i) chained = decode_step_launch(c, nullptr, nullptr, 0, &evs);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->cur_steps = std::max(c->cur_steps, c->cur_max_new);
+        double tot = 0.0;
+        for (size_t i = 0; i + 1 < evs.size(); i += 2) { float m = 0.f; hipEventElapsedTime(&m, evs[i], evs[i + 1]); tot += m; }
+        const size_t n = evs.size() / 2;
+        for (hipEvent_t e : evs) hipEventDestroy(e);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        if (!chained || n == 0) return fail(c, -1, "rdx_time(7): the chained down -> QKV launch is not active in this configuration (batch > 2, RDX_CHAIN != 2)");
+        *ms_host = (float)(tot / (double)n);
+        return 0;
+    }
     if (what == 0) {
         int rc = build_graph(c, nullptr);
         if (rc) return rc;

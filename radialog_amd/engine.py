@@ -193,6 +193,29 @@ class RdxEngine:
             self._conv = None
         return toks, scores, n.value
 
+    def beam_search(self, ids: torch.Tensor, qformer_embs: Optional[torch.Tensor], num_beams: int, max_new: int, eos_id: int = 2,
+                    pad_id: int = 0, mask: Optional[torch.Tensor] = None, length_penalty: float = 1.0, early_stopping: bool = False,
+                    output_scores: bool = False):
+        """transformers 4.28.1 beam search over rdx_beam_search. ids int[B, T] (NOT expanded; expanded here with repeat_interleave
+        like _expand_inputs_for_generation). Returns (tokens int32[B, max_new] on the host, lengths int32[B], sequence scores f32[B],
+        step scores [n, B * num_beams, V] model dtype or None, n forwards)."""
+        B, T = ids.shape
+        k = int(num_beams)
+        rep = lambda t, dt: None if t is None else t.to(device=self.device, dtype=dt).repeat_interleave(k, dim=0).contiguous()   # noqa: E731
+        ids32, m32, qf = rep(ids, torch.int32), rep(mask, torch.int32), rep(qformer_embs, torch.float32)
+        toks = torch.zeros(B, max_new, dtype=torch.int32)
+        lens = torch.zeros(B, dtype=torch.int32)
+        seq_scores = torch.zeros(B, dtype=torch.float32)
+        sc = torch.zeros(max_new, B * k, self.cfg.llama.vocab, dtype=self.tdtype, device=self.device) if output_scores else None
+        n = C.c_int(0)
+        self._conv = None
+        torch.cuda.synchronize(self.device)
+        check(self.ctx, self.lib.rdx_beam_search(self.ctx, _ptr(ids32), _ptr(m32), B, k, T, _ptr(qf), max_new, eos_id, pad_id,
+                                                 float(length_penalty), int(bool(early_stopping)), C.c_void_p(toks.data_ptr()),
+                                                 C.c_void_p(lens.data_ptr()), C.c_void_p(seq_scores.data_ptr()), _ptr(sc), C.byref(n)),
+              "rdx_beam_search")
+        return toks, lens, seq_scores, (None if sc is None else sc[: n.value]), n.value
+
     def prefill(self, ids, qformer_embs, max_new, eos_id=2, pad_id=0, mask=None, want_logits=True):
         B, T = ids.shape
         ids32 = ids.to(device=self.device, dtype=torch.int32).contiguous()
@@ -259,6 +282,40 @@ class RdxEngine:
         out = torch.empty(B, self.cfg.cls.classes, dtype=torch.float32, device=self.device)
         torch.cuda.synchronize(self.device)
         check(self.ctx, self.lib.rdx_classify_findings(self.ctx, _ptr(image), B, _ptr(out)), "rdx_classify_findings")
+        return out
+
+    # -- data-parallel collective (RCCL inside the C ABI) ---------------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        """128 opaque bytes from ncclGetUniqueId (rank 0); hand them to every rank, then comm_init everywhere."""
+        buf = C.create_string_buffer(128)
+        rc = self.lib.rdx_comm_unique_id(buf)
+        if rc != 0:
+            msg = self.lib.rdx_last_error(None)
+            raise _lib.RdxError(f"rdx_comm_unique_id failed ({rc}): {msg.decode() if msg else '?'}")
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        buf = C.create_string_buffer(unique_id, 128)
+        check(self.ctx, self.lib.rdx_comm_init(self.ctx, buf, rank, world), "rdx_comm_init")
+
+    @property
+    def comm_world(self) -> int:
+        return int(self.lib.rdx_comm_world(self.ctx))
+
+    def allgather_tokens(self, tokens: torch.Tensor) -> torch.Tensor:
+        """int32[B_local, N] on this device -> int32[world * B_local, N], rank-major: one ncclAllGather on the engine's stream."""
+        if tokens.dtype != torch.int32 or not tokens.is_cuda or tokens.dim() != 2:
+            raise ValueError("allgather_tokens takes an int32 [rows, n] tensor on the engine's device")
+        world = self.comm_world
+        if world <= 0:
+            raise _lib.RdxError("allgather_tokens: no communicator (comm_init / shard.init_comm first)")
+        tokens = tokens.contiguous()
+        out = torch.empty(world * tokens.shape[0], tokens.shape[1], dtype=torch.int32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        check(self.ctx, self.lib.rdx_allgather_tokens(self.ctx, _ptr(tokens), _ptr(out), tokens.shape[0], tokens.shape[1]), "rdx_allgather_tokens")
+        self.sync()
         return out
 
     def time_unit(self, what: int, iters: int) -> float:

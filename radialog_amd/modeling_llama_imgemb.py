@@ -193,9 +193,11 @@ class LlamaForCausalLM:
                  return_dict_in_generate: bool = False, output_scores: bool = False, max_new_tokens: int = 20,
                  attention_mask: Optional[torch.Tensor] = None, num_beams: int = 1, do_sample: bool = False,
                  qformer_embs: Optional[torch.Tensor] = None, eos_token_id: Optional[int] = None,
-                 pad_token_id: Optional[int] = None, **_unused):
-        if num_beams != 1 or do_sample:
-            raise NotImplementedError("the hot path is greedy search (num_beams=1, do_sample=False), as demo.py/test.py run it")
+                 pad_token_id: Optional[int] = None, length_penalty: float = 1.0, early_stopping: bool = False, **_unused):
+        if do_sample:
+            raise NotImplementedError("sampling is not on the path: every reference call site decodes deterministically")
+        if num_beams < 1:
+            raise ValueError("`num_beams` has to be an integer strictly greater than 0")
         if input_ids.dim() != 2:
             raise ValueError("You have to specify decoder_input_ids of shape [batch, seq]")
         B, T = input_ids.shape
@@ -205,6 +207,9 @@ class LlamaForCausalLM:
         if embs is not None and tuple(embs.shape) != (B, 32, self.lcfg.qformer_dim):
             raise ValueError(f"image embeddings should be of size {(B, 32, self.lcfg.qformer_dim)}, but are {tuple(embs.shape)}")
         self._ensure_engine()
+        if num_beams > 1:
+            return self._beam_generate(input_ids, embs, num_beams, max_new_tokens, eos, pad, attention_mask, length_penalty,
+                                       early_stopping, return_dict_in_generate, output_scores)
         # multi-turn chats (demo.py:277-305 re-sends the whole conversation every turn): with `reuse_prefix_kv` set on the model
         # the KV rows of the token prefix shared with the previous call are kept and only the new turn is prefilled
         toks, scores, n = self._engine.generate(input_ids, embs, max_new=max_new_tokens, eos_id=eos, pad_id=pad,
@@ -223,6 +228,33 @@ class LlamaForCausalLM:
         # fresh tensors like HF's: the engine reuses its score buffer on the next call
         sc = tuple(scores[i].clone() for i in range(n)) if output_scores else None
         return GenerateOutput(sequences=seq, scores=sc)
+
+
+def _beam_generate(self, input_ids, embs, num_beams, max_new_tokens, eos, pad, attention_mask, length_penalty, early_stopping,
+                   return_dict_in_generate, output_scores):
+    """Tail of BeamSearchScorer.finalize (transformers 4.28.1): one hypothesis per prompt, EOS appended where a hypothesis ended
+    before the longest one, rows padded to a common length min(longest + 1, T + max_new_tokens)."""
+    if input_ids.shape[0] * num_beams > self.max_batch:
+        raise ValueError(f"batch {input_ids.shape[0]} x num_beams {num_beams} exceeds max_batch {self.max_batch} of this model")
+    toks, lens, seq_scores, step_scores, n = self._engine.beam_search(input_ids, embs, num_beams, max_new_tokens, eos_id=eos, pad_id=pad,
+                                                                      mask=attention_mask, length_penalty=length_penalty,
+                                                                      early_stopping=early_stopping, output_scores=output_scores)
+    B, T = input_ids.shape
+    sent_max = min(int(lens.max()) + 1, max_new_tokens)
+    gen = torch.full((B, sent_max), pad, dtype=torch.int64)
+    for b in range(B):
+        L = int(lens[b])
+        gen[b, :L] = toks[b, :L].to(torch.int64)
+        if L < sent_max and eos >= 0:
+            gen[b, L] = eos
+    seq = torch.cat([input_ids.to(torch.int64).cpu(), gen], dim=1).to(self.device)
+    if not return_dict_in_generate:
+        return seq
+    sc = tuple(step_scores[i].clone() for i in range(step_scores.shape[0])) if output_scores else None
+    return GenerateOutput(sequences=seq, scores=sc, sequences_scores=seq_scores.to(self.device))
+
+
+LlamaForCausalLM._beam_generate = _beam_generate
 
 
 class PeftModelForCausalLM:

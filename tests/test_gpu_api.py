@@ -102,7 +102,8 @@ def test_embedding_dump_round_trip_feeds_generate_by_dicom(tmp_path, monkeypatch
     assert sorted(on_disk) == dicoms and on_disk["d003"].shape == (32, cfg.qformer.hidden) and on_disk["d003"].dtype.name == "float32"
     direct = blip.forward_image(img.cuda())[0]
     for i, d in enumerate(dicoms):                                # batch composition must not change an image's embedding
-        assert float((torch.from_numpy(emb[d]) - direct[i].cpu()).abs().max()) < 2e-3, d
+        e = torch.from_numpy(emb[d]).double()
+        assert float((e - direct[i].cpu().double()).norm() / e.norm()) < 3e-3, d        # fp16 tile / split-K choices differ with the batch
     lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.float16, cfg=cfg.llama, max_batch=3, max_len=128, synthetic=True).eval()
     assert sorted(lm.model.blip_embeddings) == dicoms             # read from the pkl at construction, like the reference
     ids = synth.synth_prompt_ids(3, 48, vocab=cfg.llama.vocab, img_offset=4)
@@ -114,3 +115,23 @@ def test_embedding_dump_round_trip_feeds_generate_by_dicom(tmp_path, monkeypatch
     assert all(torch.equal(x, y) for x, y in zip(a.scores, b.scores))
     with pytest.raises(KeyError):
         lm.generate(input_ids=ids, dicom=["d004", "nope", "d002"], max_new_tokens=2)
+
+
+def test_rccl_allgather_inside_the_c_abi_single_rank():
+    """rdx_comm_unique_id / rdx_comm_init / rdx_allgather_tokens (include/rdx.h) with a one-rank communicator -- the only size a
+    one-GPU box can form; the two-rank data path is covered by tests/test_shard_gloo.py and by bench.py --gpus N under torchrun."""
+    from radialog_amd import shard
+    from radialog_amd._lib import RdxError
+    from radialog_amd.engine import RdxEngine
+    cfg = small_cfg()
+    eng = RdxEngine(cfg, dtype="bf16", device=0, max_batch=2, max_len=64, vision=False)
+    toks = torch.arange(2 * 7, dtype=torch.int32, device=eng.device).view(2, 7)
+    with pytest.raises(RdxError):
+        eng.allgather_tokens(toks)                                # no communicator yet
+    shard.init_comm(eng, 0, 1)
+    assert eng.comm_world == 1
+    out = shard.allgather_tokens(toks, 1, engine=eng)
+    assert out.data_ptr() != toks.data_ptr() and torch.equal(out, toks)
+    with pytest.raises(RdxError):
+        eng.comm_init(eng.comm_unique_id(), 0, 1)                 # already initialised
+    eng.close()

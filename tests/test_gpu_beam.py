@@ -1,0 +1,65 @@
+"""SURVEY.md 8f rank 4 -- beam search (`num_beams` of test.py:267,:467,:629; `_reorder_cache`, modeling_llama_imgemb.py:838-843)
+through rdx_beam_search / LlamaForCausalLM.generate(num_beams=k) against the oracle's restatement of transformers 4.28.1
+beam_search + BeamSearchScorer. fp16 log-probs are quantised to 2^-8, so near-ties between candidates are frequent and ANY two
+fp16 implementations may then prune differently; the oracle reports the smallest gap at a pruning decision (`min_gap`), and identity
+of the returned hypotheses is asserted for every case whose decisions are all further apart than 3 ulps -- at least three such cases
+must exist, so the assertion cannot be empty. The first step's processed scores (log_softmax of the prompt's logits) do not depend
+on any decision and are compared in every case."""
+import pytest
+import torch
+
+from radialog_amd import synth
+from radialog_amd.config import small_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("k,B", [(3, 2), (2, 1), (4, 2)])
+def test_beam_search_matches_oracle(k, B):
+    from oracle import ref_cpu
+    from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM
+    cfg = small_cfg()
+    W = synth.make_weights(synth.llama_specs(cfg.llama))
+    orc = ref_cpu.LlamaOracle(W, cfg.llama, torch.float16, lora=True)
+    lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.float16, cfg=cfg.llama, max_batch=B * k, max_len=128, synthetic=True).eval()
+    T, N = 48, 8
+    decisive = matched = 0
+    for seed in range(40, 52):
+        ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, seed=seed)
+        if B > 1:
+            ids[1] = torch.cat([torch.zeros(3, dtype=torch.long), ids[1, : T - 3]])           # a left-padded row
+        qf = synth.synth(f"t.qfb{seed}", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+        with torch.no_grad():
+            g = orc.generate_greedy(ids, qf, max_new=N, eos_id=-1)
+            eos = int(g["tokens"][0, 3])                                                      # row 0 can finish early; the other runs on
+            ref = orc.generate_beam(ids, qf, k, N, eos_id=eos, pad_id=0)
+            lp0 = torch.nn.functional.log_softmax(orc.forward(orc.embed(ids, qf), ids.ne(0).long(),
+                                                              ref_cpu.positions_from_mask(ids.ne(0).long()))[0][:, -1], dim=-1)
+        out = lm.generate(input_ids=ids, qformer_embs=qf, num_beams=k, max_new_tokens=N, eos_token_id=eos, pad_token_id=0,
+                          return_dict_in_generate=True, output_scores=True)
+        assert out.sequences.shape[0] == B and out.sequences.shape[1] <= T + N and torch.equal(out.sequences[:, :T].cpu(), ids)
+        assert out.scores[0].shape == (B * k, cfg.llama.vocab)
+        err0 = float((out.scores[0].float().cpu()[::k] - lp0.float()).abs().max())           # the k rows of a group start identical
+        assert err0 < 1.5e-2, f"seed {seed}: first-step log-probs differ by {err0}"
+        assert float((out.scores[0].float().cpu()[0] - out.scores[0].float().cpu()[k - 1]).abs().max()) == 0.0
+        if ref["min_gap"] > 3 * 2.0 ** -8:
+            decisive += 1
+            assert torch.equal(out.sequences.cpu(), ref["sequences"]), (f"seed {seed} (min_gap {ref['min_gap']:.4f}): "
+                                                                        f"{out.sequences[:, T:].tolist()} vs oracle {ref['sequences'][:, T:].tolist()}")
+            assert float((out.sequences_scores.cpu() - ref["scores"]).abs().max()) < 5e-3
+        matched += int(out.sequences.shape == ref["sequences"].shape and torch.equal(out.sequences.cpu(), ref["sequences"]))
+    print(f"beam k={k} B={B}: {decisive} decisive cases (all identical), {matched}/12 identical overall")
+    assert decisive >= 3, f"only {decisive} of 12 cases had all pruning decisions further apart than 3 ulps"
+    lm._engine.close()
+
+
+def test_beam_search_argument_errors():
+    from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM
+    cfg = small_cfg()
+    lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.float16, cfg=cfg.llama, max_batch=4, max_len=128, synthetic=True).eval()
+    ids = synth.synth_prompt_ids(2, 48, vocab=cfg.llama.vocab, img_offset=6)
+    with pytest.raises(ValueError):
+        lm.generate(input_ids=ids, num_beams=3, max_new_tokens=4)                              # 2 x 3 rows > max_batch 4
+    seq = lm.generate(input_ids=ids, num_beams=2, max_new_tokens=4, eos_token_id=-1)
+    assert torch.is_tensor(seq) and seq.shape == (2, 52)
+    lm._engine.close()

@@ -99,7 +99,9 @@ def test_generate_wrapper_argument_errors():
     lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.float16, synthetic=True)
     ids = torch.ones(1, 40, dtype=torch.long)
     with pytest.raises(NotImplementedError):
-        lm.generate(input_ids=ids, num_beams=3, max_new_tokens=4)
+        lm.generate(input_ids=ids, do_sample=True, max_new_tokens=4)
+    with pytest.raises(ValueError):
+        lm.generate(input_ids=ids, num_beams=0, max_new_tokens=4)
     with pytest.raises(KeyError):                                   # unknown dicom id, like the reference's dict lookup
         lm.generate(input_ids=ids, dicom=["unknown"], max_new_tokens=4)
     with pytest.raises(ValueError):
