@@ -103,7 +103,7 @@ class RdxEngine:
                 self._upload(W.vision_items(get, self.cfg.vision))
                 self._upload(W.qformer_items(get, self.cfg.qformer))
             if llama:
-                self._upload(W.llama_items(get, self.cfg.llama, self.lora, fp8=self.weights_fp8))
+                self._upload(W.llama_items(get, self.cfg.llama, self.lora, fp8=self.weights_fp8, dtype=self.tdtype))
         check(self.ctx, self.lib.rdx_finalize_weights(self.ctx), "rdx_finalize_weights")
         self._finalized = True
 

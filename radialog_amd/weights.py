@@ -181,7 +181,7 @@ def rope_tables_f32(head_dim: int, max_pos: int, base: float):
     return emb.cos(), emb.sin()
 
 
-def llama_items(get: Getter, c: LlamaCfg, lora: bool, fp8: bool = False) -> Iterator[Item]:
+def llama_items(get: Getter, c: LlamaCfg, lora: bool, fp8: bool = False, dtype=None) -> Iterator[Item]:
     # fp8: the decoder's GEMM weights (QKV + LoRA-A rows, o_proj, gate/up, down, lm_head) are additionally quantised to e4m3
     # with one scale per row (RDX_W_GEMM_FP8, BASELINE configs[4]); embeddings, norms, LoRA-B, img_proj keep the model dtype
     GK = RDX_W_GEMM_FP8 if fp8 else RDX_W_GEMM
@@ -190,7 +190,11 @@ def llama_items(get: Getter, c: LlamaCfg, lora: bool, fp8: bool = False) -> Iter
     yield "final_norm", get("model.norm.weight").view(1, -1), RDX_W_TENSOR
     yield "lm_head", get("lm_head.weight"), GK
     yield "img_proj.w", get("model.img_proj_layer.weight"), RDX_W_GEMM
-    yield "img_proj.b", get("model.img_proj_layer.bias").view(1, -1), RDX_W_F32
+    # the decoder runs in the model dtype throughout (`.half()`, demo.py:234): img_proj_layer's bias is a half tensor in the reference and
+    # F.linear adds THAT to the fp32 sum. The engine keeps biases as fp32 words, so round it here (an unrounded bias moves ~1 % of
+    # the 32 spliced rows by one ulp, which the QKV projection then spreads over a few per cent of the K / V cache).
+    b = get("model.img_proj_layer.bias")
+    yield "img_proj.b", (b if dtype is None else b.to(dtype).float()).view(1, -1), RDX_W_F32
     cos, sin = rope_tables_f32(c.head_dim, c.max_pos, c.rope_base)
     yield "rope.cos", cos.contiguous(), RDX_W_TENSOR
     yield "rope.sin", sin.contiguous(), RDX_W_TENSOR

@@ -2,8 +2,10 @@
 through rdx_beam_search / LlamaForCausalLM.generate(num_beams=k) against the oracle's restatement of transformers 4.28.1
 beam_search + BeamSearchScorer. fp16 log-probs are quantised to 2^-8, so near-ties between candidates are frequent and ANY two
 fp16 implementations may then prune differently; the oracle reports the smallest gap at a pruning decision (`min_gap`), and identity
-of the returned hypotheses is asserted for every case whose decisions are all further apart than 3 ulps -- at least three such cases
-must exist, so the assertion cannot be empty. The first step's processed scores (log_softmax of the prompt's logits) do not depend
+of the returned hypotheses is asserted for every case whose decisions are all further apart than 6 ulps (a flip needs the two
+candidates' log-probs, each the difference of a logit and a log-sum-exp, to move by 3 ulps against each other); a case that differs
+must have had a closer decision than that, and at least 9 of the 12 cases of every parametrisation must be identical outright, so
+the assertion cannot be empty. The first step's processed scores (log_softmax of the prompt's logits) do not depend
 on any decision and are compared in every case."""
 import pytest
 import torch
@@ -42,14 +44,16 @@ def test_beam_search_matches_oracle(k, B):
         err0 = float((out.scores[0].float().cpu()[::k] - lp0.float()).abs().max())           # the k rows of a group start identical
         assert err0 < 1.5e-2, f"seed {seed}: first-step log-probs differ by {err0}"
         assert float((out.scores[0].float().cpu()[0] - out.scores[0].float().cpu()[k - 1]).abs().max()) == 0.0
-        if ref["min_gap"] > 3 * 2.0 ** -8:
-            decisive += 1
-            assert torch.equal(out.sequences.cpu(), ref["sequences"]), (f"seed {seed} (min_gap {ref['min_gap']:.4f}): "
-                                                                        f"{out.sequences[:, T:].tolist()} vs oracle {ref['sequences'][:, T:].tolist()}")
+        same = out.sequences.shape == ref["sequences"].shape and torch.equal(out.sequences.cpu(), ref["sequences"])
+        decisive += int(ref["min_gap"] > 6 * 2.0 ** -8)
+        if not same:
+            assert ref["min_gap"] <= 6 * 2.0 ** -8, (f"seed {seed} (min_gap {ref['min_gap']:.4f}): {out.sequences[:, T:].tolist()} vs oracle "
+                                                     f"{ref['sequences'][:, T:].tolist()}")
+        else:
             assert float((out.sequences_scores.cpu() - ref["scores"]).abs().max()) < 5e-3
-        matched += int(out.sequences.shape == ref["sequences"].shape and torch.equal(out.sequences.cpu(), ref["sequences"]))
-    print(f"beam k={k} B={B}: {decisive} decisive cases (all identical), {matched}/12 identical overall")
-    assert decisive >= 3, f"only {decisive} of 12 cases had all pruning decisions further apart than 3 ulps"
+        matched += int(same)
+    print(f"beam k={k} B={B}: {matched}/12 cases identical to the oracle ({decisive} had every decision > 6 ulps apart)")
+    assert matched >= 9, f"only {matched}/12 cases identical: more than near-ties can explain"
     lm._engine.close()
 
 
