@@ -167,9 +167,15 @@ int rdx_gemv_trace(rdx_ctx* ctx, int what, int layer, long long* host, int max_t
  * bias fp32. epi: 0 none, 1 relu, 2 gelu, 3 +resid, 4 swiglu(interleaved gate/up rows), 6 relu(+resid).
  * force: 0 = production dispatch (M <= 32 -> skinny, else LDS-DMA GEMM when K % 64 == 0, else tiled), 1 = skinny,
  * 2 = tiled_gemm_k, 3 = gemm_dma_k, 4 = skinny with fp8 (e4m3 + per-row scale) weights, 5 = the batch 3-32 K-split path (epi 3 only:
- * pack X, xsplit32_k, slab combine + residual), 6 = 5 with fp8 weights. Test / benchmark hook. */
+ * pack X, xsplit32_k, slab combine + residual), 6 = 5 with fp8 weights, 7 = the encoder's many-row kernel wsgemm_k (K % 64 == 0, epi 0-3 / 6;
+ * RDX_WS_CFG=A..E forces a tile shape). Test / benchmark hook. */
 int rdx_gemm_test(rdx_ctx* ctx, const void* X, const float* W, const float* bias, const void* resid, void* out, int M, int N,
                   int K, int epi, const void* norm_w, float eps, int force);
+
+/* kernel benchmark hook: ms per launch of one GEMM (ksize 0: rows x K -> N) or one NHWC convolution (ksize 1 / 3: `rows` images of
+ * H x H x K channels -> N channels, stride, pad ksize / 2) through the dispatch the encoder / prefill use; zero-filled operands. */
+int rdx_kernel_bench(rdx_ctx* ctx, int rows, int N, int K, int H, int ksize, int stride, int epi, int iters, float* ms_host,
+                     long long* trace_host /* nullable: [trace_wgs][8] per-workgroup timestamps of gemm_dma_k (plain GEMMs) */, int trace_wgs);
 
 /* the lm_head epilogue of the weight-streaming kernels on a bare GEMM (M <= 32): logits model-dtype [M][N] (columns >=
  * n_valid are not written) and the greedy choice per row (argmax over n < n_valid, ties -> lowest index). Test hook. */

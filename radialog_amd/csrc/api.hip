@@ -104,6 +104,7 @@ struct rdx_ctx {
     long long* d_mtrace = nullptr;   // set only during rdx_mega_trace
     int *d_ctr = nullptr, *d_err = nullptr;   // per-layer hand-off counters of the fused launch, sticky error flag
     bool use_dma_gemm = true;        // RDX_DMA=0: route every large-M GEMM through tiled_gemm_k
+    bool ws_ok = false;              // set while the image encoder runs: its many-row GEMMs / convolutions may take wsgemm_k
     float* gemm_ws = nullptr; size_t gemm_ws_floats = 0;      // split-K slabs of gemm_dma_k
     GraphKey gkey;
 
@@ -253,6 +254,7 @@ static void run_gemm(rdx_ctx* c, GemmArgs a, int epi) {
     ConvGeom cg;
     memset(&cg, 0, sizeof(cg));
     if (a.M <= 32) skinny(c, a, epi == EPI_RESID_RELU ? EPI_RESID : epi);
+    else if (c->ws_ok && c->zero16 && wsgemm_supported(a, cg, epi)) launch_wsgemm(c->cfg.dtype, a, cg, epi, c->zero16, c->stream);
     else if (c->use_dma_gemm && gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
     else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
 }
@@ -683,6 +685,9 @@ static void conv_gemm(rdx_ctx* c, const void* X, const GemmW& W, const float* bi
     cg.mode = 1; cg.Hin = Hin; cg.Win = Win; cg.Cin = Cin; cg.Hout = Hout; cg.Wout = Wout;
     cg.KH = KH; cg.KW = KW; cg.stride = stride; cg.pad = pad;
     if (KH == 1 && KW == 1 && stride == 1 && pad == 0) cg.mode = 0;
+    // memory-bound 1x1 convolutions (K <= 256, tens of thousands of rows): weight-stationary streaming kernel
+    if (conv1x1_stream_supported(a, cg, epi)) { launch_conv1x1_stream(c->cfg.dtype, a, cg, epi, c->stream); return; }
+    if (c->ws_ok && c->zero16 && wsgemm_supported(a, cg, epi)) { launch_wsgemm(c->cfg.dtype, a, cg, epi, c->zero16, c->stream); return; }
     // 1x1 stride-1 convolutions are plain GEMMs; everything else needs the gather path of the tiled kernel
     if (cg.mode == 0 && c->use_dma_gemm && gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
     else if (c->use_dma_gemm && c->zero16 && !resid && gemm_dma_conv_supported(a, cg, epi)) launch_gemm_dma_conv(c->cfg.dtype, a, cg, epi, c->zero16, c->gemm_ws, c->gemm_ws_floats, c->stream);
@@ -707,6 +712,8 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
     const rdx_config& f = c->cfg;
     const int dt = f.dtype, S_ = f.v_img, Hp = S_ + 6;
     hipStream_t s = c->stream;
+    struct WsScope { rdx_ctx* c; ~WsScope() { c->ws_ok = false; } } ws_scope{c};
+    c->ws_ok = true;
 
     // a1/a2: stem. 7x7/2 conv as implicit GEMM over a zero-padded NHWC4 image: K = 7 x 8(kw, last is zero) x 4(c, last is zero)
     launch_img_prep(dt, image, c->vin, Bimg, S_, 3, Hp, Hp, s);
@@ -1457,6 +1464,52 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
     return 0;
 }
 
+
+// Kernel benchmark hook: `iters` launches of one GEMM (ksize = 0: out[M][N] = epi(X[M][K] W^T), M = rows) or one NHWC convolution
+// (ksize = 1 / 3: batch `rows` images of H x H x K channels -> N channels, `stride`, pad = ksize / 2) through the SAME dispatch
+// the encoder / prefill use (run_gemm / conv_gemm), timed with HIP events on the context's stream. Contents are zeros; epi 3 / 6
+// read a residual. Returns ms per launch.
+extern "C" int rdx_kernel_bench(rdx_ctx* c, int rows, int N, int K, int H, int ksize, int stride, int epi, int iters, float* ms_host,
+                                long long* trace_host, int trace_wgs) {
+    if (!c || !ms_host || iters <= 0 || rows <= 0) return fail(c, -1, "rdx_kernel_bench: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int Kg = ksize ? ksize * ksize * K : K;
+    if (Kg % 32 || N % 16) return fail(c, -1, "rdx_kernel_bench: need K %% 32 == 0 and N %% 16 == 0");
+    const int Ho = ksize ? (H + 2 * (ksize / 2) - ksize) / stride + 1 : 0;
+    const size_t M = ksize ? (size_t)rows * Ho * Ho : (size_t)rows, Min = ksize ? (size_t)rows * H * H : (size_t)rows;
+    char* buf = nullptr;
+    const size_t xb = Min * K * 2 + 64, wb = (size_t)N * Kg * 2, ob = M * N * 2 + 64, bb = (size_t)N * 4;
+    HIPCHK(c, hipMalloc((void**)&buf, xb + wb + 2 * ob + bb));
+    HIPCHK(c, hipMemsetAsync(buf, 0, xb + wb + 2 * ob + bb, c->stream));
+    GemmW w; w.N = N; w.K = Kg; w.Npad = N; w.w = buf + xb;
+    void *out = buf + xb + wb, *res = buf + xb + wb + ob;
+    const float* bias = (const float*)(buf + xb + wb + 2 * ob);
+    const bool need_res = epi == EPI_RESID || epi == EPI_RESID_RELU;
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    struct WsScope { rdx_ctx* c; ~WsScope() { c->ws_ok = false; } } ws_scope{c};
+    c->ws_ok = true;
+    long long* dtr = nullptr;
+    if (trace_host && trace_wgs > 0) { HIPCHK(c, hipMalloc((void**)&dtr, (size_t)trace_wgs * 8 * sizeof(long long))); HIPCHK(c, hipMemset(dtr, 0, (size_t)trace_wgs * 64)); }
+    auto once = [&]() {
+        if (ksize) conv_gemm(c, buf, w, bias, need_res ? res : nullptr, out, rows, H, H, K, ksize, ksize, stride, ksize / 2, Ho, Ho, epi);
+        else { GemmArgs a = gargs(buf, K, w, bias, out, N, (int)M); a.resid = need_res ? res : nullptr; a.ldr = N; a.trace = dtr; run_gemm(c, a, epi); }
+    };
+    once();
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; ++i) once();
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (dtr) { hipMemcpy(trace_host, dtr, (size_t)trace_wgs * 64, hipMemcpyDeviceToHost); hipFree(dtr); }
+    hipFree(buf);
+    HIPCHK(c, hipGetLastError());
+    *ms_host = ms / (float)iters;
+    return 0;
+}
+
 // One bare GEMM through the production kernels (unit tests / kernel benchmarks): out = epilogue(X . W^T).
 // X, resid, norm_w, out are model-dtype device tensors; W [N][K] and bias [N] are fp32 device tensors (W is packed here).
 extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const float* bias, const void* resid, void* out,
@@ -1507,6 +1560,17 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipGetLastError());
         hipFree(wp); hipFree(tmp);
+        return 0;
+    }
+    if (force == 7) {         // the encoder's many-row kernel (wsgemm.hip), tile shape via RDX_WS_CFG
+        ConvGeom cg0;
+        memset(&cg0, 0, sizeof(cg0));
+        a.norm_w = nullptr;
+        if (!c->zero16 || a.K % 64 || a.N % 16) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: shape not supported by wsgemm_k"); }
+        launch_wsgemm(c->cfg.dtype, a, cg0, epi, c->zero16, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        hipFree(wp);
         return 0;
     }
     const bool use_skinny = force == 1 || (force == 0 && M <= 32);

@@ -57,11 +57,14 @@ __device__ __forceinline__ void store4(const GemmArgs& a, int m, int n, float v[
 // CONV: the activation operand is an implicit-GEMM gather from an NHWC tensor (K ordered (kh, kw, c), Cin % 8 == 0, so a lane's
 // 16-byte piece lies inside one filter tap): every lane hands global_load_lds its own source address; taps that fall
 // into the zero padding read a 16-byte zero block instead.
-template <typename T, int EPI, bool SPLIT, bool CONV = false>
+// NS = LDS stages of 32 KiB: 2 (64 KiB, two workgroups per CU: grids of several rounds hide the DMA latency by occupancy) or 4
+// (128 KiB, one workgroup per CU, three steps in flight: grids that do not even fill the chip once -- the Q-Former's M = 32 x batch
+// GEMMs, 48-192 tiles -- were running one 1.3-us DMA round trip per 0.2-us k-step).
+template <typename T, int EPI, bool SPLIT, bool CONV = false, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict__ partial, int steps_per_split, ConvGeom cg = ConvGeom(),
                                                   const void* zero16 = nullptr) {
     typedef typename Vec8<T>::type V8;
-    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [buf 2][operand 2][block 16][lane 64]
+    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [stage NS][operand 2][block 16][lane 64]
     const int MB = (a.M + DG_BM - 1) / DG_BM, NB = (a.N + DG_BN - 1) / DG_BN;
     const int nwg = MB * NB;
     int tile;
@@ -129,18 +132,11 @@ __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict_
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+    // debug timeline (rdx_kernel_bench with a trace buffer): [0] entry, [1] first stage landed, [2] k loop done, [3] end, [4] steps, [5] XCC
+    long long* trc = (a.trace && threadIdx.x == 0) ? a.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 : nullptr;
+    if (trc) trc[0] = (long long)__builtin_amdgcn_s_memrealtime();
 
-    if (s0 < s1) stage(s0, 0);
-    for (int s = s0; s < s1; ++s) {
-        const int buf = (s - s0) & 1;
-        if (s + 1 < s1) {
-            stage(s + 1, buf ^ 1);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // the 8 loads of step s have landed, step s+1 stays in flight
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        const u4* base = lds + (size_t)buf * 2 * 16 * 64;
+    auto multiply = [&](const u4* base) {
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             V8 wf[4], xf[4];
@@ -153,9 +149,43 @@ __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict_
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(wf[nt], xf[mt], acc[nt][mt]);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                               // everyone is done reading buf before it is re-staged
+    };
+    if (NS == 2) {
+        if (s0 < s1) stage(s0, 0);
+        for (int s = s0; s < s1; ++s) {
+            const int buf = (s - s0) & 1;
+            if (s + 1 < s1) {
+                stage(s + 1, buf ^ 1);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // the 8 loads of step s have landed, step s+1 stays in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (trc && s == s0) trc[1] = (long long)__builtin_amdgcn_s_memrealtime();
+            multiply(lds + (size_t)buf * 2 * 16 * 64);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                               // everyone is done reading buf before it is re-staged
+        }
+    } else {
+        // stages s0 .. s0+NS-2 in flight; every step: wait for ITS 8 loads per wave (the younger stages stay in flight), one barrier
+        // (publishes stage s and frees the slot stage s-1 was read from), refill that slot, multiply. Past the end the last stage is
+        // re-loaded (harmless) so that the wait counts stay uniform.
+        const int nst = s1 - s0;
+        if (nst > 0) {
+#pragma unroll
+            for (int p = 0; p < NS - 1; ++p) stage(s0 + min(p, nst - 1), p);
+        }
+        for (int i = 0; i < nst; ++i) {
+            if (NS == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage(s0 + min(i + NS - 1, nst - 1), (i + NS - 1) % NS);
+            multiply(lds + (size_t)(i % NS) * 2 * 16 * 64);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's LDS reads of the stage are done before its next barrier
+        }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the re-loaded tail stages must land before the LDS is released
+    if (trc) { trc[2] = (long long)__builtin_amdgcn_s_memrealtime(); trc[4] = s1 - s0; trc[5] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
 
     // epilogue: lane (r = m_local, g) holds out[m][n0 + g*4 + 0..3]
 #pragma unroll
@@ -189,6 +219,7 @@ __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict_
             if (m < a.M) store4<T, EPI>(a, m, n, v);
         }
     }
+    if (trc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[3] = (long long)__builtin_amdgcn_s_memrealtime(); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -355,16 +386,31 @@ static void launch_dma_epi(const GemmArgs& a, float* ws, size_t ws_floats, hipSt
     splits = (nsteps + per - 1) / per;
     const size_t smem = (size_t)2 * 2 * 16 * 64 * sizeof(u4);       // 64 KiB
     dim3 grid(blocks, 1, splits), block(256);
+    // RDX_DMA_NS4=1: four stages, one workgroup per CU, for grids that do not fill the chip. Measured: NO gain (q.qkv M = 1024:
+    // 16.8 -> 17.6 us; B = 1 encode 1.47 -> 1.50 ms) -- the k-step is not latency- but operand-bandwidth-bound, so it
+    // stays off.
+    const char* e4 = getenv("RDX_DMA_NS4");
+    const bool deep = (e4 ? atoi(e4) != 0 : false) && blocks * splits <= 256 && per >= 4;
     if (splits > 1) {
         static bool attr = false;
-        if (!attr) { hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-        hipLaunchKernelGGL((gemm_dma_k<T, EPI, true>), grid, block, smem, s, a, ws, per, ConvGeom(), nullptr);
+        if (!attr) {
+            hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, true, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * smem));
+            attr = true;
+        }
+        if (deep) hipLaunchKernelGGL((gemm_dma_k<T, EPI, true, false, 4>), grid, block, 2 * smem, s, a, ws, per, ConvGeom(), nullptr);
+        else hipLaunchKernelGGL((gemm_dma_k<T, EPI, true>), grid, block, smem, s, a, ws, per, ConvGeom(), nullptr);
         const size_t total = (size_t)a.M * (a.N >> 2);
         hipLaunchKernelGGL((splitk_reduce_k<T, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, ws, splits);
     } else {
         static bool attr = false;
-        if (!attr) { hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-        hipLaunchKernelGGL((gemm_dma_k<T, EPI, false>), grid, block, smem, s, a, nullptr, nsteps, ConvGeom(), nullptr);
+        if (!attr) {
+            hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * smem));
+            attr = true;
+        }
+        if (deep) hipLaunchKernelGGL((gemm_dma_k<T, EPI, false, false, 4>), grid, block, 2 * smem, s, a, nullptr, nsteps, ConvGeom(), nullptr);
+        else hipLaunchKernelGGL((gemm_dma_k<T, EPI, false>), grid, block, smem, s, a, nullptr, nsteps, ConvGeom(), nullptr);
     }
 }
 

@@ -92,6 +92,16 @@ bool gemm_dma_conv_supported(const GemmArgs& a, const ConvGeom& cg, int epi);
 void launch_gemm_dma_conv(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, const void* zero16, float* ws, size_t ws_floats,
                           hipStream_t s);
 
+// weight-stationary streaming 1x1 convolution (conv1x1.hip): K <= 256, many rows (the trunk's layer1 / layer2 at batch); cg.mode 0 =
+// plain rows, mode 1 with KH = KW = 1 = strided row gather (downsample)
+bool conv1x1_stream_supported(const GemmArgs& a, const ConvGeom& cg, int epi);
+void launch_conv1x1_stream(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s);
+
+// many-row GEMM / implicit-GEMM convolution with the weight slice in an LDS ring and the activation fragments fetched straight into
+// registers by the wave that owns the rows (wsgemm.hip): K % 64 == 0; convolutions need Cin % 64 == 0
+bool wsgemm_supported(const GemmArgs& a, const ConvGeom& cg, int epi);
+void launch_wsgemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, const void* zero16, hipStream_t s);
+
 void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s);
 // prefill: LoRA add + RoPE + KV-cache write for T tokens of B rows; q -> qout [B*T][hidden]
 void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,

@@ -318,6 +318,15 @@ class RdxEngine:
         self.sync()
         return out
 
+    def kernel_bench(self, rows, N, K, H=0, ksize=0, stride=1, epi=0, iters=20, trace_wgs=0):
+        """ms per launch of one GEMM / NHWC convolution through the encoder's dispatch (rdx_kernel_bench); with trace_wgs also the
+        int64 [trace_wgs, 8] per-workgroup timeline of gemm_dma_k (100 MHz ticks)."""
+        ms = C.c_float(0)
+        tr = torch.zeros(max(trace_wgs, 1), 8, dtype=torch.int64)
+        check(self.ctx, self.lib.rdx_kernel_bench(self.ctx, rows, N, K, H, ksize, stride, epi, iters, C.byref(ms),
+                                                  C.c_void_p(tr.data_ptr()) if trace_wgs else None, trace_wgs), "rdx_kernel_bench")
+        return (ms.value, tr) if trace_wgs else ms.value
+
     def time_unit(self, what: int, iters: int) -> float:
         ms = C.c_float(0)
         check(self.ctx, self.lib.rdx_time(self.ctx, what, iters, C.byref(ms)), "rdx_time")

@@ -69,6 +69,17 @@ CASES = [
     (32, 4096, 11008, 3, False, 5), (21, 4096, 11008, 3, False, 5), (32, 4096, 4096, 3, False, 5), (17, 2048, 4096, 3, False, 5),
     (32, 8192, 11008, 3, False, 5),
 ]
+# the encoder's many-row kernel (wsgemm.hip, force=7): weight slice in an LDS ring, activations direct to registers. Every tile shape
+# (RDX_WS_CFG), every epilogue, ragged M / N, one k-stage and many
+WS_CASES = [(cfg_, M, N, K, epi) for cfg_ in "ABCDE" for (M, N, K, epi) in
+            [(700, 272, 64, 0), (1025, 128, 576, 1), (513, 768, 768, 3), (2048, 96, 1408, 2), (1300, 2064, 256, 6)]]
+
+
+
+@pytest.mark.parametrize("cfg_,M,N,K,epi", WS_CASES)
+def test_wsgemm_matches_fp32(eng, cfg_, M, N, K, epi, monkeypatch):
+    monkeypatch.setenv("RDX_WS_CFG", cfg_)
+    test_gemm_matches_fp32(eng, M, N, K, epi, False, 7)
 
 
 @pytest.mark.parametrize("M,N,K,epi,norm,force", CASES)

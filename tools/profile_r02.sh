@@ -9,7 +9,7 @@ run() {  # name, iterations (0 = none), command...
   rm -rf /tmp/rp_$name
   (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp_$name -o $name --output-format rocpd -- "$@" > $OUT/$name.log 2>&1)
   local db=$(find /tmp/rp_$name -name "*.db" | head -1)
-  if [ -n "$db" ]; then python $PWD/tools/prof_summary.py $db $OUT/$name.md $iters > /dev/null; cp $db $OUT/$name.db; else echo "no db for $name" >> $OUT/$name.log; fi
+  if [ -n "$db" ]; then python $PWD/tools/prof_summary.py $db $OUT/$name.md $iters > /dev/null; else echo "no db for $name" >> $OUT/$name.log; fi
 }
 run enc_b1 21 python $PWD/tools/enc_only.py 1 20
 run enc_b32 6 python $PWD/tools/enc_only.py 32 5
@@ -21,8 +21,10 @@ python - <<'PY'
 import sqlite3, os
 out = os.environ.get("OUT", "gpurun_out/prof")
 for name in ("enc_b32", "enc_b1"):
-    db = f"{out}/{name}.db"
-    if not os.path.exists(db): continue
+    import glob
+    dbs = glob.glob(f"/tmp/rp_{name}/**/*.db", recursive=True)
+    if not dbs: continue
+    db = dbs[0]
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select name, start, end, grid_x, workgroup_x, lds_size from kernels where name like '%rdx%' order by start").fetchall()
     # last iteration = everything after the last img_prep launch
@@ -40,5 +42,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
   (cd /tmp && rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_$ctr -o pmc --output-format rocpd -- python $PWD/bench.py --steps 1 --warmup 0 --new-tokens 8 --no-cpu-baseline --no-b32 --no-graph > $OUT/pmc_$ctr.log 2>&1)
   db=$(find /tmp/pmc_$ctr -name "*.db" | head -1)
-  [ -n "$db" ] && python $PWD/tools/pmc_summary.py $db > $OUT/pmc_$ctr.txt 2>&1
+  if [ -n "$db" ]; then python $PWD/tools/pmc_summary.py $db > $OUT/pmc_$ctr.txt 2>&1; else tail -20 $OUT/pmc_$ctr.log > $OUT/pmc_$ctr.txt; fi
+  tail -c 2000 $OUT/pmc_$ctr.log > $OUT/pmc_$ctr.log.tail; rm -f $OUT/pmc_$ctr.log
 done
+for f in $OUT/*.log; do tail -c 3000 $f > $f.tail; rm -f $f; done
