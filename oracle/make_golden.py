@@ -15,6 +15,7 @@ Pinned here:
   projector  biovil_t/modules.py MLP(use_1x1_convs=True) in eval mode (+ the reshape scramble + LayerNorm restated
              with torch ops exactly as blip2_qformer.py:469 writes them)
   rope/rms   LlamaRotaryEmbedding tables, LlamaRMSNorm rows
+  downstream downstream_tasks/automated_correction.py + chexpert_classification_downstream.py prompt builders (strings)
   vit_pooler biovil_t/transformer.py VisionTransformerPooler (Block, MultiHeadAttentionLayer, SinePositionEmbedding are the
              reference's own code) in eval mode, two-image call. Its three timm==0.4.12 imports are shimmed in-process: DropPath
              (identity in eval), trunc_normal_ (init only, overwritten by our weights) and Mlp, restated as timm 0.4.12 defines
@@ -260,6 +261,40 @@ def make_vit_pooler():
     print("vit_pooler:", out.shape, float(out.abs().mean()))
 
 
+def make_downstream():
+    """downstream_tasks/*.py prompt builders (the correction module imports the CheXbert labeller at module level -- stubbed)."""
+    import json
+    import types
+    stub = types.ModuleType("chexbert.run_chexbert")
+    stub.run_chexbert_labeler = lambda *a, **k: None
+    pkg = types.ModuleType("chexbert")
+    sys.modules.update({"chexbert": pkg, "chexbert.run_chexbert": stub})
+    try:
+        corr = _load("downstream_tasks/automated_correction.py", "ref_corr")
+        cls = _load("downstream_tasks/chexpert_classification_downstream.py", "ref_cls")
+    finally:
+        sys.modules.pop("chexbert", None)
+        sys.modules.pop("chexbert.run_chexbert", None)
+    cols = ["No Finding", "Enlarged Cardiomediastinum", "Cardiomegaly", "Lung Opacity", "Lung Lesion", "Edema", "Consolidation",
+            "Pneumonia", "Atelectasis", "Pneumothorax", "Pleural Effusion", "Pleural Other", "Fracture", "Support Devices"]
+    hist = ["A chat. USER: Image information: X. write the report ASSISTANT:The heart is enlarged. No effusion.",
+            "A chat. USER: q ASSISTANT:Clear lungs.", "A chat. USER: q ASSISTANT:Right pneumothorax with chest tube.",
+            "A chat. USER: q ASSISTANT:Stable."]
+    preds = np.zeros((4, 14), dtype=np.int64)
+    labels = np.zeros((4, 14), dtype=np.int64)
+    preds[0, [2, 10]] = 1; labels[0, [2, 5, 8]] = 1            # fp: effusion; fn: edema, atelectasis
+    preds[1, [0]] = 1; labels[1, [3, 6, 7]] = 1                 # fp: only No Finding (ignored); fn: three
+    preds[2, [9, 13, 12]] = 1; labels[2, [9]] = 1               # fp: two; no fn
+    preds[3, [0]] = 1; labels[3, [0]] = 1                       # nothing to correct
+    gold = {"cols": cols, "history": hist, "preds": preds.tolist(), "labels": labels.tolist(),
+            "correction_prompts": corr.get_correction_prompts(list(hist), cols, preds, labels),
+            "correction_labels": [list(map(list, x)) for x in corr.get_correction_labels(cols, preds, labels)],
+            "bin_prompts": cls.get_chexpert_prompts_bin(list(hist), cols), "all_prompts": cls.get_chexpert_prompts_all(list(hist), cols)}
+    with open(os.path.join(OUT, "downstream.json"), "w") as f:
+        json.dump(gold, f, indent=1)
+    print("downstream:", len(gold["correction_prompts"]), len(gold["bin_prompts"][0]))
+
+
 def make_prompter():
     """utils/prompter.py Prompter('vicuna_v11') outputs (the reference resolves data/templates relative to the CWD)."""
     import json
@@ -283,7 +318,7 @@ def make_prompter():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["llama", "qformer", "projector", "prompter", "vit_pooler"]
+    which = sys.argv[1:] or ["llama", "qformer", "projector", "prompter", "vit_pooler", "downstream"]
     if "llama" in which:
         make_llama()
     if "qformer" in which:
@@ -294,3 +329,5 @@ if __name__ == "__main__":
         make_prompter()
     if "vit_pooler" in which:
         make_vit_pooler()
+    if "downstream" in which:
+        make_downstream()

@@ -36,6 +36,9 @@ def main():
     p.add_argument("--max_new_tokens", type=int, default=300)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     p.add_argument("--synthetic", action="store_true", help="deterministic random-init weights (no checkpoints reachable offline)")
+    p.add_argument("--do_corr", action="store_true", help="automatic prompt correction on top of the reports (test.py:437-500)")
+    p.add_argument("--do_cp_bin_qa", action="store_true", help="14 yes/no CheXpert questions per study (test.py:545-590)")
+    p.add_argument("--do_cp_all_qa", action="store_true", help="'List all the findings' follow-up (test.py:608-650)")
     args = p.parse_args()
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -49,7 +52,7 @@ def main():
     dicoms = [f"synthetic-{i:05d}" for i in range(lo, hi)]
     tok = load_tokenizer(args.vicuna)
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
-    lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=dt, device_map="auto", max_batch=args.batch_size * max(args.num_beams, 1),
+    lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=dt, device_map="auto", max_batch=max(args.batch_size, 14 if args.do_cp_bin_qa else 1) * max(args.num_beams, 1),
                                                   max_len=1024, device=local, synthetic=args.synthetic)
     if args.lora_model:
         lang_model = PeftModelForCausalLM.from_pretrained(lang_model, args.lora_model, torch_dtype=dt, use_ram_optimized_load=False).half()
@@ -58,7 +61,7 @@ def main():
         images = synth.synth_images(len(dicoms), 448, seed=1000 + lo)
         lang_model.model.blip_embeddings.update(dump_embeddings(images, dicoms, dtype=args.dtype, device=local, synthetic=args.synthetic))
 
-    all_preds, all_ids = [], []
+    all_preds, all_ids, preds_history = [], [], []
     for s in range(0, len(dicoms), args.batch_size):
         batch = dicoms[s: s + args.batch_size]
         texts = []
@@ -71,6 +74,7 @@ def main():
         out = lang_model.generate(input_ids=input_ids, dicom=batch if args.use_embs else None, return_dict_in_generate=True,
                                   output_scores=True, max_new_tokens=args.max_new_tokens, num_beams=args.num_beams)
         preds = tok.batch_decode(out.sequences, skip_special_tokens=True)
+        preds_history.extend(preds)
         all_preds.extend([q.split("ASSISTANT:")[1] if "ASSISTANT:" in q else q for q in preds])
         gen = out.sequences[:, input_ids.shape[1]:]
         pad = torch.zeros(gen.shape[0], args.max_new_tokens, dtype=torch.int32, device=gen.device)
@@ -80,6 +84,25 @@ def main():
     if world > 1:
         counts = [shard_range(args.num_samples, world, r)[1] - shard_range(args.num_samples, world, r)[0] for r in range(world)]
         ids = allgather_ragged(ids, counts, world)
+    if args.do_corr or args.do_cp_bin_qa or args.do_cp_all_qa:
+        # downstream re-prompting (test.py:437-674): the whole conversation + one new USER turn; CheXbert labels are not available here,
+        # so the correction prompts are driven by synthetic label disagreements of the same shape
+        from radialog_amd import downstream as D
+        from radialog_amd.chexpert_model import CHEXPERT_COLS
+        import numpy as np
+        rng = np.random.default_rng(0)
+        dc = dicoms if args.use_embs else None
+        if args.do_corr:
+            P, L = rng.integers(0, 2, (len(dicoms), 14)), rng.integers(0, 2, (len(dicoms), 14))
+            corr = D.run_correction(lang_model, tok, D.get_correction_prompts(list(preds_history), CHEXPERT_COLS, P, L), dc, args.num_beams)
+            print(f"rank {rank}: {len(corr)} corrected reports; first: {corr[0][:80]!r}")
+        if args.do_cp_bin_qa:
+            yn = D.run_binary_qa(lang_model, tok, D.get_chexpert_prompts_bin(list(preds_history), CHEXPERT_COLS), CHEXPERT_COLS, dc)
+            print(f"rank {rank}: binary QA label matrix {yn.shape}, positives {int(yn.sum())}")
+        if args.do_cp_all_qa:
+            oh = D.run_findings_qa(lang_model, tok, D.get_chexpert_prompts_all(list(preds_history), CHEXPERT_COLS), CHEXPERT_COLS, dc,
+                                   num_beams=args.num_beams)
+            print(f"rank {rank}: findings QA label matrix {oh.shape}, positives {int(oh.sum())}")
     if rank == 0:
         print(f"generated {ids.shape[0]} reports x {ids.shape[1]} token slots on {world} GPU(s); first: {all_preds[0][:120]!r}")
 
