@@ -231,11 +231,15 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
         if (!V_EARLY) { load_v(0, VR_LO, 0x7fffffff); load_v(VR_LO, VR, slot); }     // K registers are free now
         // contexts beyond the register window: two groups per trip, all eight fragment loads issued before the first MFMA
         // (the register window is dead by now); a group past the context is loaded from a clamped row and stores nothing
+        // (the second group of the last trip may lie past the context: wave-uniform skip -- it would store nothing, and its
+        // loads are real HBM traffic: at batch 32 the clamped rows were a fifth of the kernel's bytes)
         for (int gi = KG * CW + cw; gi * 16 < slot; gi += 2 * CW) {
             u4 kf[2][4];
             unsigned mw[2];
+            const bool two = (gi + CW) * 16 < slot;                   // wave-uniform
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
+                if (t == 1 && !two) break;
                 const int gb = (gi + t * CW) * 16;
                 const int j = min(gb + r, d.max_len - 1);
 #pragma unroll
@@ -243,7 +247,7 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
                 mw[t] = *reinterpret_cast<const unsigned*>(km + min(gb + 4 * g, d.max_len - 4));
             }
             score_group(kf[0], mw[0], gi * 16);
-            score_group(kf[1], mw[1], (gi + CW) * 16);               // positions >= slot are not stored
+            if (two) score_group(kf[1], mw[1], (gi + CW) * 16);      // positions >= slot are not stored
         }
     }
     if (w == 0) {                                                               // the new position itself
@@ -304,7 +308,8 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int j = j0 + t * SPAN + cw * 4 + jsub;
-                vt[t] = ldg16(vc + (size_t)min(j, d.max_len - 1) * D + doct * 8);
+                // rows of a whole wave past the context (wave-uniform test) are not fetched: zero row, P = 0
+                vt[t] = (j0 + t * SPAN + cw * 4 < slot) ? ldg16(vc + (size_t)min(j, d.max_len - 1) * D + doct * 8) : (u4){0u, 0u, 0u, 0u};
                 pt[t] = j < slot ? rnd<T>(expf(S[j] - mx) / sum) : 0.f;
             }
 #pragma unroll
