@@ -13,5 +13,5 @@ try:
 except Exception as e:
     print("query failed:", e)
     rows = []
-for r in rows[:30]:
+for r in rows[:200]:
     print(f"{r[1]:12s} n={r[2]:6d} avg={r[3]:14.1f} min={r[4]:14.1f} max={r[5]:14.1f}  {r[0][:110]}")
