@@ -177,6 +177,10 @@ int rdx_gemm_test(rdx_ctx* ctx, const void* X, const float* W, const float* bias
 int rdx_kernel_bench(rdx_ctx* ctx, int rows, int N, int K, int H, int ksize, int stride, int epi, int iters, float* ms_host,
                      long long* trace_host /* nullable: [trace_wgs][8] per-workgroup timestamps of gemm_dma_k (plain GEMMs) */, int trace_wgs);
 
+/* microbenchmark: aggregate GB/s that `wgs` 256-thread workgroups pull from a cache-resident buffer (bytes_per_wg each, read `reps`
+ * times; shared = 1: all read the same region); mode 0 = global_load_dwordx4 to registers, 1 = global_load_lds_dwordx4 (LDS-DMA) */
+int rdx_l2_bench(rdx_ctx* ctx, int mode, long long bytes_per_wg, int shared, int reps, int wgs, float* gbps_host);
+
 /* the lm_head epilogue of the weight-streaming kernels on a bare GEMM (M <= 32): logits model-dtype [M][N] (columns >=
  * n_valid are not written) and the greedy choice per row (argmax over n < n_valid, ties -> lowest index). Test hook. */
 int rdx_logits_test(rdx_ctx* ctx, const void* X, const float* W, int M, int N, int n_valid, int K, void* out_logits,

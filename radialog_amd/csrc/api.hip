@@ -719,8 +719,13 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
     launch_img_prep(dt, image, c->vin, Bimg, S_, 3, Hp, Hp, s);
     if (previous) launch_img_prep(dt, previous, (char*)c->vin + (size_t)Bimg * Hp * Hp * 4 * 2, Bimg, S_, 3, Hp, Hp, s);
     int Hc = S_ / 2;
-    conv_gemm(c, c->vin, c->v_conv1, c->v_conv1_b, nullptr, c->vbuf[0], B, Hp, Hp, 4, 7, 8, 2, 0, Hc, Hc, EPI_RELU);
-    launch_maxpool(dt, c->vbuf[0], c->vbuf[1], B, Hc, Hc, f.v_stem, s);
+    if (stem_pool_supported(f.v_stem)) {
+        // conv1 + bn1 + relu + maxpool in one launch: the 224^2 x 64 stem output never goes to HBM (stem.hip)
+        launch_stem_pool(dt, c->vin, c->v_conv1.w, c->v_conv1_b, c->vbuf[1], B, Hp, Hc, S_ / 4, f.v_stem, s);
+    } else {
+        conv_gemm(c, c->vin, c->v_conv1, c->v_conv1_b, nullptr, c->vbuf[0], B, Hp, Hp, 4, 7, 8, 2, 0, Hc, Hc, EPI_RELU);
+        launch_maxpool(dt, c->vbuf[0], c->vbuf[1], B, Hc, Hc, f.v_stem, s);
+    }
     Hc = S_ / 4;
     int C = f.v_stem;
     void *cur = c->vbuf[1], *t1 = c->vbuf[0], *t2 = c->vbuf[2], *t3 = c->vbuf[3];
@@ -1507,6 +1512,31 @@ extern "C" int rdx_kernel_bench(rdx_ctx* c, int rows, int N, int K, int H, int k
     hipFree(buf);
     HIPCHK(c, hipGetLastError());
     *ms_host = ms / (float)iters;
+    return 0;
+}
+
+// Microbenchmark: GB/s that `wgs` workgroups (256 threads) pull from a cache-resident buffer, `bytes_per_wg` each (shared = 1: all
+// read the same region), read `reps` times; mode 0 = global_load_dwordx4, 1 = global_load_lds_dwordx4. Returns the aggregate GB/s.
+extern "C" int rdx_l2_bench(rdx_ctx* c, int mode, long long bytes_per_wg, int shared, int reps, int wgs, float* gbps_host) {
+    if (!c || !gbps_host || bytes_per_wg < 65536 || wgs <= 0 || reps <= 0) return fail(c, -1, "rdx_l2_bench: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    char* buf = nullptr;
+    const size_t total = shared ? (size_t)bytes_per_wg : (size_t)bytes_per_wg * wgs;
+    HIPCHK(c, hipMalloc((void**)&buf, total + 64));
+    HIPCHK(c, hipMemsetAsync(buf, 1, total + 64, c->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    launch_l2_bench(mode, buf, (size_t)bytes_per_wg, shared, 1, wgs, (unsigned*)(buf + total), c->stream);        // warm the caches
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    launch_l2_bench(mode, buf, (size_t)bytes_per_wg, shared, reps, wgs, (unsigned*)(buf + total), c->stream);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(buf);
+    HIPCHK(c, hipGetLastError());
+    *gbps_host = (float)((double)bytes_per_wg * wgs * reps / (ms * 1e-3) / 1e9);
     return 0;
 }
 

@@ -102,6 +102,13 @@ void launch_conv1x1_stream(int dtype, const GemmArgs& a, const ConvGeom& cg, int
 bool wsgemm_supported(const GemmArgs& a, const ConvGeom& cg, int epi);
 void launch_wsgemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, const void* zero16, hipStream_t s);
 
+// fused ResNet stem (stem.hip): 7x7/2 conv + bias + ReLU + 3x3/2 max pool from the padded NHWC4 image to [B][Ho][Ho][stem]
+bool stem_pool_supported(int stem_channels);
+void launch_stem_pool(int dtype, const void* in, const void* Wp, const float* bias, void* out, int B, int Hp, int Hc, int Ho, int stem,
+                      hipStream_t s);
+
+void launch_l2_bench(int mode, const void* buf, size_t bytes_per_wg, int shared, int reps, int wgs, unsigned* sink, hipStream_t s);
+
 void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s);
 // prefill: LoRA add + RoPE + KV-cache write for T tokens of B rows; q -> qout [B*T][hidden]
 void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,
