@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict_
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
     // debug timeline (rdx_kernel_bench with a trace buffer): [0] entry, [1] first stage landed, [2] k loop done, [3] end, [4] steps, [5] XCC
     long long* trc = (a.trace && threadIdx.x == 0) ? a.trace + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 8 : nullptr;
-    if (trc) trc[0] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (trc) { trc[0] = (long long)__builtin_amdgcn_s_memrealtime(); trc[6] = (long long)__builtin_amdgcn_s_memtime(); }
 
     auto multiply = [&](const u4* base) {
 #pragma unroll
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict_
             if (m < a.M) store4<T, EPI>(a, m, n, v);
         }
     }
-    if (trc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[3] = (long long)__builtin_amdgcn_s_memrealtime(); }
+    if (trc) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); trc[3] = (long long)__builtin_amdgcn_s_memrealtime(); trc[7] = (long long)__builtin_amdgcn_s_memtime(); }
 }
 
 // ------------------------------------------------------------------------------------------------------------------

@@ -16,4 +16,6 @@ print("  first stage landed - entry: med %.2f max %.2f" % ((tr[:, 1] - tr[:, 0])
 print("  k loop (after first stage): med %.2f max %.2f  -> per step %.3f us" % ((tr[:, 2] - tr[:, 1]).median() / 100, (tr[:, 2] - tr[:, 1]).max() / 100, (tr[:, 2] - tr[:, 1]).median() / 100 / max(tr[0, 4] - 1, 1)))
 print("  epilogue: med %.2f max %.2f" % ((tr[:, 3] - tr[:, 2]).median() / 100, (tr[:, 3] - tr[:, 2]).max() / 100))
 print("  end us: med %.2f max %.2f" % (us(tr[:, 3]).median(), us(tr[:, 3]).max()))
+clk = ((tr[:, 7] - tr[:, 6]) / ((tr[:, 3] - tr[:, 0]) / 100.0)).median()       # shader cycles (s_memtime) per us of s_memrealtime
+print("  shader clock while the kernel runs: %.0f MHz" % clk)
 eng.close()
