@@ -1385,15 +1385,25 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
         HIPCHK(c, hipMemcpyAsync(slot.data(), c->d_slot, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         if (slot[0] + iters >= f.max_len) return fail(c, -1, "rdx_time: %d steps would overflow the KV cache (slot %d, max_len %d)", iters, slot[0], f.max_len);
-        std::vector<hipEvent_t> evs;
+        std::vector<hipEvent_t> evs, nul;
         bool chained = true;
-        for (int i = 0; i < iters && chained; ++i) chained = decode_step_launch(c, nullptr, nullptr, 0, &evs);
+        for (int i = 0; i < iters && chained; ++i) {
+            chained = decode_step_launch(c, nullptr, nullptr, 0, &evs);
+            // calibration: an EMPTY bracket (two event records back to back) costs stream time of its own; it is measured in the same
+            // stream, once per step, and subtracted from every bracket below
+            hipEvent_t a0, a1; hipEventCreate(&a0); hipEventCreate(&a1);
+            hipEventRecord(a0, c->stream); hipEventRecord(a1, c->stream);
+            nul.push_back(a0); nul.push_back(a1);
+        }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->cur_steps = std::max(c->cur_steps, c->cur_max_new);
-        double tot = 0.0;
+        double tot = 0.0, empty = 0.0;
         for (size_t i = 0; i + 1 < evs.size(); i += 2) { float m = 0.f; hipEventElapsedTime(&m, evs[i], evs[i + 1]); tot += m; }
+        for (size_t i = 0; i + 1 < nul.size(); i += 2) { float m = 0.f; hipEventElapsedTime(&m, nul[i], nul[i + 1]); empty += m; }
         const size_t n = evs.size() / 2;
+        if (!nul.empty()) tot -= empty / (double)(nul.size() / 2) * (double)n;
         for (hipEvent_t e : evs) hipEventDestroy(e);
+        for (hipEvent_t e : nul) hipEventDestroy(e);
         hipEventDestroy(e0); hipEventDestroy(e1);
         if (!chained || n == 0) return fail(c, -1, "rdx_time(7): the chained down -> QKV launch is not active in this configuration (batch > 2, RDX_CHAIN != 2)");
         *ms_host = (float)(tot / (double)n);

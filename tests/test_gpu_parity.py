@@ -491,3 +491,22 @@ def test_fp8_weight_decode_matches_fake_quantised_oracle(cfg, cpu_w, B):
         tol = LOGIT_TOL[dtype]
         check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"{dtype}")
         eng.close()
+
+
+def test_decode_step_refuses_to_walk_past_the_reserved_slots(cfg):
+    """rdx_decode_step appends a KV row and advances the RoPE position on every call: it must stop at the max_new the prefill
+    reserved (and after a completed rdx_generate) instead of writing past the cache (round-1 advisor finding)."""
+    from radialog_amd.engine import RdxEngine, synth_getter
+    from radialog_amd._lib import RdxError
+    eng = RdxEngine(cfg, dtype="bf16", device=0, max_batch=1, max_len=64, lora=True, vision=False)
+    eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+    ids = _prompt(cfg, 1, 40, seed=9)
+    eng.prefill(ids, None, max_new=3)                # token 0 selected
+    eng.decode_step(); eng.decode_step()             # tokens 1, 2
+    with pytest.raises(RdxError, match="max_new"):
+        eng.decode_step()
+    with pytest.raises(RdxError):                     # 40 + 30 > max_len 64: refused at the prefill already
+        eng.prefill(ids, None, max_new=30)
+    eng.generate(ids, None, max_new=4, eos_id=-1)
+    assert eng.lib.rdx_decode_step(eng.ctx, None) != 0          # a completed generate leaves nothing to step through
+    eng.close()
