@@ -8,7 +8,8 @@ Default workload = BASELINE.json configs[1]: 1 x MI355X, batch 1, bf16, random-i
 `--batch 32` gives configs[2] (batch-32 decode, hipGraph step). With N > 1 ranks (one process per GPU, launched by
 torch.distributed.run) every rank runs the same per-GPU batch on its own shard of images (weak scaling) and the
 generated token ids are gathered with ONE RCCL all-gather issued by librdx itself (rdx_allgather_tokens) at the end of each
-step -- the only collective on the path; torch.distributed carries the 128-byte RCCL id, the barrier and the max-over-ranks clock.
+step -- the only collective on the path; torch.distributed (a gloo group on the host) carries the 128-byte RCCL id, the barrier and
+the max-over-ranks clock.
 
 Rank 0 prints ONE JSON line. `value` = reports/s of the whole job with inputs resident in HBM. Added objects:
   roofline     bound "hbm": the kernel rocprofv3 ranks first in the decode loop -- at batch <= 2 the chained down(l) -> QKV(l+1)
@@ -287,7 +288,13 @@ def main():
     if launched:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # launcher-side plumbing only (RCCL id broadcast, barrier, max-over-ranks clock): a gloo group on the host. The data-path
+        # collective is librdx's own RCCL communicator; `RDX_BENCH_PG=nccl` puts the plumbing on torch's RCCL group instead.
+        backend = os.environ.get("RDX_BENCH_PG", "gloo")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         dist = None
     if args.gpus != world and rank == 0 and world > 1:
@@ -309,7 +316,7 @@ def main():
     elapsed, out, img, ids, out_q = run_steps(eng, cfg, args, B, T, N, rank, world, dist, args.steps, args.warmup, use_graph)
     per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        te = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if dist.get_backend() == "nccl" else "cpu")
         allt = [torch.zeros_like(te) for _ in range(world)]
         dist.all_gather(allt, te)
         per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in allt]

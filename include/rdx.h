@@ -148,8 +148,7 @@ int rdx_hidden_read(rdx_ctx* ctx, void* dst /*model dtype [B][hidden]: decoder o
  *   what = 1: the gate/up SwiGLU weight-streaming GEMV of every layer in turn, `iters` sweeps -> ms per launch
  *   what = 2: ... the QKV GEMV, 3: o_proj, 4: down_proj, 5: lm_head, 6: decode attention (re-appends the current KV row);
  *   what = 7: the chained down(l) -> QKV(l+1) launch (decode_layers_k, the batch <= 2 default), measured in situ: `iters` eager
- *             decode steps with an event pair around each of its launches (the cost of an empty event pair, measured in the same
- *             stream, subtracted) -> ms per launch
+ *             decode steps with an event pair around each of its launches (bracket = launch gap + kernel) -> ms per launch
  *   what + 10: the same unit on layer 0 only (weights stay cache resident)
  *   At batch >= 3 the RMSNorm in front of QKV / gate-up / lm_head is a launch of its own: it runs once, outside the timed region, and
  *   units 1, 2, 5 time the GEMM launches alone. */

@@ -1401,7 +1401,9 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
         for (size_t i = 0; i + 1 < evs.size(); i += 2) { float m = 0.f; hipEventElapsedTime(&m, evs[i], evs[i + 1]); tot += m; }
         for (size_t i = 0; i + 1 < nul.size(); i += 2) { float m = 0.f; hipEventElapsedTime(&m, nul[i], nul[i + 1]); empty += m; }
         const size_t n = evs.size() / 2;
-        if (!nul.empty()) tot -= empty / (double)(nul.size() / 2) * (double)n;
+        // (the empty bracket costs MORE than what an event adds around a kernel -- subtracting it put the result 6 % under rocprof's
+        // kernel duration -- so it is measured but NOT subtracted: the bracket = launch gap + kernel, 7 % over rocprof, conservative)
+        (void)empty;
         for (hipEvent_t e : evs) hipEventDestroy(e);
         for (hipEvent_t e : nul) hipEventDestroy(e);
         hipEventDestroy(e0); hipEventDestroy(e1);

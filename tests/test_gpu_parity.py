@@ -324,13 +324,20 @@ off the exact value where torch's CPU FMA chain leaves 0.03 %, tests/diag/mfma_r
         eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
         with torch.no_grad():
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
-            truth = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True, exact=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
+            # the exactly-accumulated evaluation costs as much again: on the legs that span the kernel families (batch 1, 20, 32)
+            with_exact = (not fp8) and layers == 1 and B in (1, 20, 32)
+            truth = (ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True, exact=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
+                     if with_exact else None)
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
         tol = PROD_TOL[dtype] * layers ** 0.5        # accumulation-order noise adds up layer by layer (two layers: 1.4e-2 in fp16)
         if fp8:     # the streaming kernels scale the fp32 sum of e4m3 products; the oracle's weights are T(q * scale), each rounded to the model dtype
             tol *= 2.0
         cmp_, tot, e_ho = check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"B={B} {dtype} fp8={fp8} layers={layers}")
         tk = toks.cpu().long()
+        if truth is None:
+            print(f"production width B={B} {dtype} fp8={fp8} layers={layers}: compared {cmp_}/{tot}, |hip-oracle| {e_ho:.4g}")
+            eng.close()
+            continue
         e_ht = _prefix_err(scores, truth["scores"], tk, truth["tokens"], N)
         e_ot = _prefix_err(ref["scores"], truth["scores"], ref["tokens"], truth["tokens"], N)
         print(f"production width B={B} {dtype} fp8={fp8} layers={layers}: compared {cmp_}/{tot}, |hip-oracle| {e_ho:.4g}, "
