@@ -254,7 +254,8 @@ static void run_gemm(rdx_ctx* c, GemmArgs a, int epi) {
     ConvGeom cg;
     memset(&cg, 0, sizeof(cg));
     if (a.M <= 32) skinny(c, a, epi == EPI_RESID_RELU ? EPI_RESID : epi);
-    else if (c->ws_ok && c->zero16 && wsgemm_supported(a, cg, epi)) launch_wsgemm(c->cfg.dtype, a, cg, epi, c->zero16, c->stream);
+    else if ((c->ws_ok || (a.M > 128 && a.M <= 256 && a.N >= 2048)) && c->zero16 && wsgemm_supported(a, cg, epi))
+        launch_wsgemm(c->cfg.dtype, a, cg, epi, c->zero16, c->stream);       // the encoder's GEMMs; a single prompt's prefill GEMMs
     else if (c->use_dma_gemm && gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
     else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
 }

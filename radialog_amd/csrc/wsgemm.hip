@@ -28,6 +28,12 @@ typedef __attribute__((address_space(3))) void* ws_lptr_t;
 
 constexpr int WS_ROWB = 144;            // epilogue scratch row pitch: 64 columns x 2 B + 16 B (conflict-free 8-byte column writes)
 
+// SwiGLU on interleaved gate/up tiles (weights.py: rows 0..7 of a 16-row tile = gate, 8..15 = up): T(T(silu(T(g))) * T(u))
+template <typename T> __device__ __forceinline__ float ws_swiglu(float gate_acc, float up_acc) {
+    const float gt = rnd<T>(gate_acc), up = rnd<T>(up_acc);
+    return rnd<T>(silu(gt)) * up;                  // the product is rounded by the store
+}
+
 template <typename T, int EPI, int NT, int MT, int WAVES, bool CONV>
 __global__ __launch_bounds__(WAVES * 64) void wsgemm_k(GemmArgs a, ConvGeom cg, const void* zero16) {
     typedef typename Vec8<T>::type V8;
@@ -35,7 +41,8 @@ __global__ __launch_bounds__(WAVES * 64) void wsgemm_k(GemmArgs a, ConvGeom cg, 
     constexpr int WB = 2 * NT / WAVES;                          // weight blocks (1 KiB) this wave DMAs per stage
     static_assert(WB >= 1 && WB * WAVES == 2 * NT, "NT / WAVES mismatch");
     constexpr int ROWS = 16 * MT, STAGE = NT * 2 * 64;          // u4 per weight stage
-    constexpr int CHN = NT < 4 ? NT : 4, NCH = NT / CHN, LPR = CHN * 2, RPP = 64 / LPR, PASSES = ROWS / RPP;
+    constexpr bool SILU = (EPI == EPI_SILU_MUL);   // output has N / 2 columns: 8 per 16-column tile
+    constexpr int CHN = NT < 4 ? NT : 4, NCH = NT / CHN, LPR = SILU ? CHN : CHN * 2, RPP = 64 / LPR, PASSES = ROWS / RPP;
     extern __shared__ __attribute__((aligned(16))) u4 lds[];    // [3 stages][NT][2 kc][64]   (epilogue: per-wave scratch)
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -149,8 +156,9 @@ __global__ __launch_bounds__(WAVES * 64) void wsgemm_k(GemmArgs a, ConvGeom cg, 
     constexpr bool RES = (EPI == EPI_RESID || EPI == EPI_RESID_RELU);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int nc0 = N0 + c * CHN * 16;
+        const int nc0 = N0 + c * CHN * 16;                          // first weight row (GEMM column) of the chunk
         if (nc0 >= a.N) break;                                      // (block-uniform) ragged last column block
+        const int oc0 = SILU ? (nc0 >> 1) : nc0, OW = SILU ? (a.N >> 1) : a.N;      // output column of the chunk, output width
         u4 rsd[PASSES];
         if (RES) {
 #pragma unroll
@@ -167,6 +175,16 @@ __global__ __launch_bounds__(WAVES * 64) void wsgemm_k(GemmArgs a, ConvGeom cg, 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 T4 o;
+                if (SILU) {
+                    // gate columns sit at g = 0, 1, their up partners at g + 2 = lane ^ 32; the gate lanes write 4 of the tile's 8 outputs
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float up = __shfl_xor(acc[nt][mt][e], 32, 64);
+                        o[e] = fromf<T>(ws_swiglu<T>(acc[nt][mt][e], up));
+                    }
+                    if (g < 2) *reinterpret_cast<T4*>(scr + (16 * mt + r) * WS_ROWB + q * 16 + g * 8) = o;
+                    continue;
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float v = acc[nt][mt][e] + b4[e];
@@ -180,7 +198,7 @@ __global__ __launch_bounds__(WAVES * 64) void wsgemm_k(GemmArgs a, ConvGeom cg, 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // one wave, in-order LDS: the chunk is in the scratch
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
-            const int row = p * RPP + rr, m = m0 + row, n = nc0 + pc * 8;
+            const int row = p * RPP + rr, m = m0 + row, n = oc0 + pc * 8;
             u4 v = *reinterpret_cast<const u4*>(scr + row * WS_ROWB + pc * 16);
             if (RES) {
                 const V8 cv = as_vec8<T>(v), rv = as_vec8<T>(rsd[p]);
@@ -193,7 +211,7 @@ __global__ __launch_bounds__(WAVES * 64) void wsgemm_k(GemmArgs a, ConvGeom cg, 
                 }
                 v = as_u4<T>(o);
             }
-            if (m < a.M && n + 8 <= a.N) stg16(O + (size_t)m * a.ldo + n, v);
+            if (m < a.M && n + 8 <= OW) stg16(O + (size_t)m * a.ldo + n, v);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // scratch reads done before the next chunk overwrites it
     }
@@ -207,8 +225,13 @@ __global__ __launch_bounds__(WAVES * 64) void wsgemm_k(GemmArgs a, ConvGeom cg, 
 bool wsgemm_supported(const GemmArgs& a, const ConvGeom& cg, int epi) {
     const char* e = getenv("RDX_WSGEMM");                        // 0 = off; else minimum row count
     const int min_rows = e ? atoi(e) : 512;
-    if (min_rows <= 0 || a.M < min_rows || a.K % 64 || a.N % 16 || a.ldo % 8) return false;
-    if (!(epi == EPI_NONE || epi == EPI_RELU || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_RESID_RELU)) return false;
+    // RDX_WSGEMM_PROMPT=1: one prompt's prefill GEMMs on the single-row-block shapes F / G / H. Measured and rejected: prefill of a
+    // 160-token prompt 7.5 -> 10.7 ms (T = 250: 8.8 -> 12.5 ms) -- off by default, the shapes stay covered by tests/test_gpu_gemm.py.
+    static const bool prompt_on = getenv("RDX_WSGEMM_PROMPT") && atoi(getenv("RDX_WSGEMM_PROMPT"));
+    const bool prompt_shape = prompt_on && a.M > 128 && a.M <= 256 && a.N >= 2048 && a.K <= 4096;
+    if (min_rows <= 0 || (a.M < min_rows && !prompt_shape) || a.K % 64 || a.N % 16 || a.ldo % 8) return false;
+    if (!(epi == EPI_NONE || epi == EPI_RELU || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_RESID_RELU || epi == EPI_SILU_MUL)) return false;
+    if (epi == EPI_SILU_MUL && (a.bias || cg.mode == 1)) return false;
     if ((epi == EPI_RESID || epi == EPI_RESID_RELU) && (!a.resid || a.ldr % 8)) return false;
     if (a.N % 8) return false;
     // where it measured faster than gemm_dma_k at batch 32 (tools/enc_kernels.py; RDX_WSGEMM_ALL=1 lifts the restriction): the
@@ -217,7 +240,11 @@ bool wsgemm_supported(const GemmArgs& a, const ConvGeom& cg, int epi) {
     // bandwidth of a CU either way and the 128 x 128 LDS-DMA tiles do as well or better there.
     static const bool all = getenv("RDX_WSGEMM_ALL") && atoi(getenv("RDX_WSGEMM_ALL"));
     if (cg.mode == 1) return cg.Cin % 64 == 0 && (all || cg.Cin <= 128);
-    return a.ldx % 8 == 0 && (all || ((epi == EPI_RESID || epi == EPI_RESID_RELU) && a.K <= 768));
+    // one prompt's prefill GEMMs (128 < M <= 256 rows, wide N, K <= 4096: QKV, o_proj, gate/up; down_proj keeps the split-K LDS-DMA
+    // kernel): the single-row-block shapes F / G / H
+    const bool one_prompt = prompt_shape && (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL);
+    if (epi == EPI_SILU_MUL) return a.ldx % 8 == 0 && (one_prompt || all) && a.M <= 256;
+    return a.ldx % 8 == 0 && (all || one_prompt || ((epi == EPI_RESID || epi == EPI_RESID_RELU) && a.K <= 768));
 }
 
 template <typename T, int EPI, int NT, int MT, int WAVES, bool CONV>
@@ -231,13 +258,29 @@ static void launch_ws_cfg(const GemmArgs& a, const ConvGeom& cg, const void* zer
 
 template <typename T, int EPI, bool CONV>
 static void launch_ws_epi(const GemmArgs& a, const ConvGeom& cg, const void* zero16, hipStream_t s) {
-    const char* e = getenv("RDX_WS_CFG");                        // force a tile shape: A, B, C
+    const char* e = getenv("RDX_WS_CFG");                        // force a tile shape: A .. H
+    // one prompt (or a few): 128 < M <= 256 rows. ONE row block of 4 waves x 64 rows holds every row (the weight slice is staged once,
+    // not once per 128-row tile, and each 1-KiB weight fragment read from LDS feeds 4 MFMAs); the column tile is as wide as still
+    // fills the chip: 128 (F), 64 (G) or 32 (H) columns
+    if (!CONV && a.M > 128 && a.M <= 256 && !(e && *e)) {
+        const int t128 = (a.N + 127) / 128;
+        if (t128 >= 160) launch_ws_cfg<T, EPI, 8, 4, 4, false>(a, cg, zero16, s);
+        else if (t128 >= 80) launch_ws_cfg<T, EPI, 4, 4, 4, false>(a, cg, zero16, s);
+        else launch_ws_cfg<T, EPI, 2, 4, 4, false>(a, cg, zero16, s);
+        return;
+    }
     const int wgA = ((a.M + 511) / 512) * ((a.N + 127) / 128), wgB = ((a.M + 127) / 128) * ((a.N + 127) / 128);
     char cfg = a.N <= 64 ? 'D' : (wgA >= 200 ? 'A' : (wgB >= 160 ? 'B' : 'C'));
     if (e && *e) cfg = *e;
     // (the implicit-GEMM address state of a convolution does not fit next to 128 accumulators: its large tile is 256 rows, E)
     if (cfg == 'A' && (CONV || (e && *e == 'E'))) cfg = 'E';
     if (CONV && cfg == 'A') cfg = 'E';
+    if (cfg == 'F' || cfg == 'G' || cfg == 'H') {
+        if (cfg == 'F') launch_ws_cfg<T, EPI, 8, 4, 4, false>(a, cg, zero16, s);
+        else if (cfg == 'G') launch_ws_cfg<T, EPI, 4, 4, 4, false>(a, cg, zero16, s);
+        else launch_ws_cfg<T, EPI, 2, 4, 4, false>(a, cg, zero16, s);
+        return;
+    }
     if (cfg == 'D') launch_ws_cfg<T, EPI, 4, 4, 8, CONV>(a, cg, zero16, s);          // N <= 64: 512 rows x 64 columns
     else if (cfg == 'E') launch_ws_cfg<T, EPI, 8, 2, 8, CONV>(a, cg, zero16, s);
     else if (cfg == 'A') launch_ws_cfg<T, EPI, 8, 4, 8, false>(a, cg, zero16, s);
@@ -253,6 +296,7 @@ static void launch_ws_T(const GemmArgs& a, const ConvGeom& cg, int epi, const vo
         case EPI_GELU: launch_ws_epi<T, EPI_GELU, CONV>(a, cg, zero16, s); break;
         case EPI_RESID: launch_ws_epi<T, EPI_RESID, CONV>(a, cg, zero16, s); break;
         case EPI_RESID_RELU: launch_ws_epi<T, EPI_RESID_RELU, CONV>(a, cg, zero16, s); break;
+        case EPI_SILU_MUL: if (!CONV) launch_ws_epi<T, EPI_SILU_MUL, false>(a, cg, zero16, s); break;
         default: break;
     }
 }

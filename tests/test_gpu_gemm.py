@@ -73,12 +73,19 @@ CASES = [
 # (RDX_WS_CFG), every epilogue, ragged M / N, one k-stage and many
 WS_CASES = [(cfg_, M, N, K, epi) for cfg_ in "ABCDE" for (M, N, K, epi) in
             [(700, 272, 64, 0), (1025, 128, 576, 1), (513, 768, 768, 3), (2048, 96, 1408, 2), (1300, 2064, 256, 6)]]
+# the single-prompt prefill shapes F / G / H (one 256-row block, 128 / 64 / 32 columns) incl. the SwiGLU epilogue on interleaved gate/up tiles
+WS_CASES += [(cfg_, M, N, K, epi) for cfg_ in "FGH" for (M, N, K, epi) in
+             [(160, 2064, 512, 0), (160, 4096, 1024, 3), (200, 2048, 512, 4), (129, 4128, 256, 4), (256, 2048, 4096, 0)]]
+WS_CASES += [("", 160, 22016, 4096, 4), ("", 160, 12304, 4096, 0), ("", 160, 4096, 4096, 3)]        # the production prefill shapes, default dispatch
 
 
 
 @pytest.mark.parametrize("cfg_,M,N,K,epi", WS_CASES)
 def test_wsgemm_matches_fp32(eng, cfg_, M, N, K, epi, monkeypatch):
-    monkeypatch.setenv("RDX_WS_CFG", cfg_)
+    if cfg_:
+        monkeypatch.setenv("RDX_WS_CFG", cfg_)
+    else:
+        monkeypatch.delenv("RDX_WS_CFG", raising=False)
     test_gemm_matches_fp32(eng, M, N, K, epi, False, 7)
 
 
