@@ -845,6 +845,7 @@ extern "C" int rdx_encode_image2(rdx_ctx* c, const float* image, const float* pr
 // Llama prefill / decode
 // ------------------------------------------------------------------------------------------------------------------
 static int ensure_prefill_ws(rdx_ctx* c, size_t rows) {
+    rows = (rows + 15) & ~(size_t)15;            // the fragment-packed layouts hold whole row tiles of 16
     if (rows <= c->prefill_rows) return 0;
     const rdx_config& f = c->cfg;
     // grows with the largest batch x prompt length seen (test.py-style evaluation: variable prompt lengths): drain the stream,
@@ -920,12 +921,32 @@ static int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int
     }
     launch_embed_splice(dt, ids, c->d_img_pos, c->embed, f.vocab, c->pimg, 32, c->px, B, T, H, qformer_embs ? 1 : 0, s);
 
+    // few rows (one or two prompts): the projections are weight-stream bound -> weight-stationary kernels over fragment-packed
+    // activations (wstat.hip); the producers (RMSNorm, attention, the SwiGLU epilogue) write that order directly
+    const int mtl = (int)((M + 15) / 16);
+    static const int ws_maxm = getenv("RDX_WSTAT_MAXM") ? atoi(getenv("RDX_WSTAT_MAXM")) : 384;
+    // measured (tools/prefill_only.py, 32 layers): wstat's time grows with the row tiles of 16, the 128-row tile GEMMs' with the row tiles of 128 --
+    // M = 64: 4.84 vs 5.34 ms, 100: 6.06 / 6.26, 160: 7.30 / 7.64, 320: 11.43 / 11.92, but 250: 9.56 / 8.86. Take wstat when the 128-row
+    // tiling would pad by 24 rows or more.
+    static const int ws_minpad = getenv("RDX_WSTAT_MINPAD") ? atoi(getenv("RDX_WSTAT_MINPAD")) : 24;
+    bool ws = (int)M > 32 && (int)M <= ws_maxm && (int)((M + 127) / 128 * 128 - M) >= ws_minpad;
+    if (ws) {
+        GemmArgs p = gargs(c->pxn, H, c->ll[0].wqkv, nullptr, c->pqkv, c->ld.qkv_ld, (int)M); p.xpacked = 3; p.mtiles = mtl;
+        GemmArgs d = gargs(c->pgu, f.inter, c->ll[0].wdown, nullptr, c->px, H, (int)M); d.xpacked = 3; d.mtiles = mtl;
+        ws = wstat_supported(p, EPI_NONE) && wstat_supported(d, EPI_RESID);
+    }
+    auto prompt_gemm = [&](GemmArgs a, int epi, bool packed_out) {
+        if (!ws) { run_gemm(c, a, epi); return; }
+        a.xpacked = 3; a.mtiles = mtl; a.out_packed = packed_out ? 3 : 0;
+        launch_wstat(dt, a, epi, s);
+    };
     for (int l = 0; l < f.layers; ++l) {
         const LlamaLayer& L = c->ll[l];
         void* kc = kv_ptr(c, c->kcache, l);
         void* vc = kv_ptr(c, c->vcache, l);
-        launch_rmsnorm(dt, c->px, L.attn_norm, c->pxn, (int)M, H, f.rms_eps, s);
-        { GemmArgs a = gargs(c->pxn, H, L.wqkv, nullptr, c->pqkv, c->ld.qkv_ld, (int)M); a.N = L.wqkv.Npad; run_gemm(c, a, EPI_NONE); }
+        if (ws) launch_rmsnorm_packed(dt, c->px, L.attn_norm, c->pxn, (int)M, mtl, H, f.rms_eps, s);
+        else launch_rmsnorm(dt, c->px, L.attn_norm, c->pxn, (int)M, H, f.rms_eps, s);
+        { GemmArgs a = gargs(c->pxn, H, L.wqkv, nullptr, c->pqkv, c->ld.qkv_ld, (int)M); a.N = L.wqkv.Npad; prompt_gemm(a, EPI_NONE, false); }
         // new K/V rows land behind the kept slots
         launch_rope_kv_prefill(dt, c->ld, c->pqkv, L.lora_bq, L.lora_bv, c->rope_cos, c->rope_sin, c->d_pos_ids, c->pq,
                                kc, vc, B, T, keep, s);
@@ -935,11 +956,13 @@ static int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int
         at.K = kc; at.V = vc; at.k_bs = at.v_bs = (long)f.heads * f.max_len * 128; at.k_ts = at.v_ts = 128; at.k_hs = at.v_hs = (long)f.max_len * 128;
         at.O = c->patt; at.o_bs = (long)T * H; at.o_ts = H; at.o_hs = 128;
         at.B = B; at.H = f.heads; at.Tq = T; at.Tk = keep + T; at.causal = 1; at.k_perm = c->ld.k_perm; at.key_mask = c->key_mask; at.km_bs = f.max_len;
+        at.o_packed_mt = ws ? mtl : 0;
         launch_attention(dt, 128, at, s);
-        { GemmArgs a = gargs(c->patt, H, L.wo, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H; run_gemm(c, a, EPI_RESID); }
-        launch_rmsnorm(dt, c->px, L.mlp_norm, c->pxn, (int)M, H, f.rms_eps, s);
-        { GemmArgs a = gargs(c->pxn, H, L.wgu, nullptr, c->pgu, f.inter, (int)M); run_gemm(c, a, EPI_SILU_MUL); }
-        { GemmArgs a = gargs(c->pgu, f.inter, L.wdown, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H; run_gemm(c, a, EPI_RESID); }
+        { GemmArgs a = gargs(c->patt, H, L.wo, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H; prompt_gemm(a, EPI_RESID, false); }
+        if (ws) launch_rmsnorm_packed(dt, c->px, L.mlp_norm, c->pxn, (int)M, mtl, H, f.rms_eps, s);
+        else launch_rmsnorm(dt, c->px, L.mlp_norm, c->pxn, (int)M, H, f.rms_eps, s);
+        { GemmArgs a = gargs(c->pxn, H, L.wgu, nullptr, c->pgu, f.inter, (int)M); prompt_gemm(a, EPI_SILU_MUL, true); }
+        { GemmArgs a = gargs(c->pgu, f.inter, L.wdown, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H; prompt_gemm(a, EPI_RESID, false); }
     }
     launch_gather_last(dt, c->px, c->datt, B, T, H, s);      // datt doubles as the [B][H] last-position buffer
     lm_head_and_greedy(c, c->datt, B, logits, nullptr, 0, /*advance=*/0);
@@ -1496,7 +1519,8 @@ extern "C" int rdx_kernel_bench(rdx_ctx* c, int rows, int N, int K, int H, int k
     const int Ho = ksize ? (H + 2 * (ksize / 2) - ksize) / stride + 1 : 0;
     const size_t M = ksize ? (size_t)rows * Ho * Ho : (size_t)rows, Min = ksize ? (size_t)rows * H * H : (size_t)rows;
     char* buf = nullptr;
-    const size_t xb = Min * K * 2 + 64, wb = (size_t)N * Kg * 2, ob = M * N * 2 + 64, bb = (size_t)N * 4;
+    const bool kb_wstat = getenv("RDX_KB_WSTAT") && atoi(getenv("RDX_KB_WSTAT")) && !ksize;
+    const size_t xb = ((Min + 15) & ~(size_t)15) * K * 2 + 64, wb = (size_t)N * Kg * 2, ob = M * N * 2 + 64, bb = (size_t)N * 4;
     HIPCHK(c, hipMalloc((void**)&buf, xb + wb + 2 * ob + bb));
     HIPCHK(c, hipMemsetAsync(buf, 0, xb + wb + 2 * ob + bb, c->stream));
     GemmW w; w.N = N; w.K = Kg; w.Npad = N; w.w = buf + xb;
@@ -1511,7 +1535,14 @@ extern "C" int rdx_kernel_bench(rdx_ctx* c, int rows, int N, int K, int H, int k
     if (trace_host && trace_wgs > 0) { HIPCHK(c, hipMalloc((void**)&dtr, (size_t)trace_wgs * 8 * sizeof(long long))); HIPCHK(c, hipMemset(dtr, 0, (size_t)trace_wgs * 64)); }
     auto once = [&]() {
         if (ksize) conv_gemm(c, buf, w, bias, need_res ? res : nullptr, out, rows, H, H, K, ksize, ksize, stride, ksize / 2, Ho, Ho, epi);
-        else { GemmArgs a = gargs(buf, K, w, bias, out, N, (int)M); a.resid = need_res ? res : nullptr; a.ldr = N; a.trace = dtr; run_gemm(c, a, epi); }
+        else {
+            GemmArgs a = gargs(buf, K, w, bias, out, N, (int)M); a.resid = need_res ? res : nullptr; a.ldr = N; a.trace = dtr;
+            if (kb_wstat) {       // RDX_KB_WSTAT=1: the single prompt's weight-stationary kernel on (zero) fragment-packed activations
+                a.xpacked = 3; a.mtiles = (int)((M + 15) / 16); a.bias = nullptr;
+                if (wstat_supported(a, epi)) { launch_wstat(c->cfg.dtype, a, epi, c->stream); return; }
+            }
+            run_gemm(c, a, epi);
+        }
     };
     once();
     HIPCHK(c, hipEventRecord(e0, c->stream));
@@ -1600,6 +1631,19 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
         launch_xsplit32(c->cfg.dtype, a, (float*)(tmp + 2 * xb), c->stream);
         HIPCHK(c, hipMemcpyAsync(out, resid, (size_t)M * N * 2, hipMemcpyDeviceToDevice, c->stream));
         launch_rmsnorm_packed32(c->cfg.dtype, out, nullptr, tmp + xb, M, N, eps, 0, (const float*)(tmp + 2 * xb), kg, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        hipFree(wp); hipFree(tmp);
+        return 0;
+    }
+    if (force == 8) {         // the single prompt's weight-stationary kernel (wstat.hip): RMSNorm / re-layout into the fragment-packed order, then the GEMM
+        const int mtl = (M + 15) / 16;
+        char* tmp = nullptr;
+        HIPCHK(c, hipMalloc((void**)&tmp, (size_t)mtl * 16 * K * 2));
+        launch_rmsnorm_packed(c->cfg.dtype, X, norm_w, tmp, M, mtl, K, eps, c->stream);        // norm_w == null: re-layout only
+        a.X = tmp; a.xpacked = 3; a.mtiles = mtl; a.norm_w = nullptr;
+        if (!wstat_supported(a, epi)) { hipFree(wp); hipFree(tmp); return fail(c, -1, "rdx_gemm_test: shape not supported by wstat_k"); }
+        launch_wstat(c->cfg.dtype, a, epi, c->stream);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipGetLastError());
         hipFree(wp); hipFree(tmp);

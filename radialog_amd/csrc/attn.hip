@@ -128,6 +128,14 @@ __global__ __launch_bounds__(256) void attention_k(AttnArgs a, int TkP) {
             T4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = fromf<T>(acc[e]);
+            if (a.o_packed_mt) {
+                // fragment-packed for wstat_k (o_proj): row m = b Tq + q, column k = h D + 16 dt + 4 g .. + 4 -> half of the 16-byte piece of
+                // lane (g' = (k % 32) / 8, r' = m % 16) in fragment (k / 32, m / 16)
+                const long m = (long)b * Tq + q;
+                const int k = h * D + dt * 16 + g * 4;
+                T* Op = reinterpret_cast<T*>(a.O);
+                *reinterpret_cast<T4*>(Op + ((((long)(k >> 5) * a.o_packed_mt + (m >> 4)) * 64 + ((k & 31) >> 3) * 16 + (m & 15)) << 3) + (k & 7)) = o;
+            } else
             *reinterpret_cast<T4*>(O + (long)q * a.o_ts + dt * 16 + g * 4) = o;
         }
     }

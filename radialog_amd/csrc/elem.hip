@@ -10,6 +10,7 @@ namespace rdx {
 // block, [fragment f][row tile mt][lane (g, r)][8], so that a wave's activation fragment is one contiguous KiB. A thread's 8
 // elements k = i .. i + 8 of row m are exactly one lane's piece: PACK 1 (32-deep fragments): f = i / 32, g = (i % 32) / 8;
 // PACK 2 (the fp8 weights' 64-deep chunks): f = 2 (i / 64) + (i % 16) / 8, g = (i % 64) / 16. Rows >= n_rows are zero-filled.
+// PACK 3 (one prompt's prefill, consumer wstat_k): the PACK 1 order over `groups` row tiles instead of 2 (no slabs on that path).
 template <typename T, int PACK>
 __global__ __launch_bounds__(256) void rmsnorm_k(const T* x, const T* __restrict__ w, T* __restrict__ out,
                                                  int H, float eps, int n_rows, const float* __restrict__ slab, int groups, T* xw) {
@@ -18,8 +19,8 @@ __global__ __launch_bounds__(256) void rmsnorm_k(const T* x, const T* __restrict
     const size_t row = blockIdx.x;
     auto dst = [&](int i) -> T* {
         if (PACK == 0) return out + row * H + i;
-        const int f = PACK == 1 ? (i >> 5) : (2 * (i >> 6) + ((i & 15) >> 3)), g = PACK == 1 ? ((i & 31) >> 3) : ((i & 63) >> 4);
-        return out + ((size_t)((f * 2 + (int)(row >> 4)) * 64 + g * 16 + (int)(row & 15)) << 3);
+        const int f = PACK != 2 ? (i >> 5) : (2 * (i >> 6) + ((i & 15) >> 3)), g = PACK != 2 ? ((i & 31) >> 3) : ((i & 63) >> 4);
+        return out + ((size_t)((f * (PACK == 3 ? groups : 2) + (int)(row >> 4)) * 64 + g * 16 + (int)(row & 15)) << 3);
     };
     if (PACK && (int)row >= n_rows) {
         for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) stg16(dst(i), (u4){0u, 0u, 0u, 0u});
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(256) void rmsnorm_k(const T* x, const T* __restrict
     float ss = 0.f;
     for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {
         V8 v = as_vec8<T>(ldg16(xr + i));
-        if (slab) {
+        if (PACK != 3 && slab) {
             // pending K-split projection (xsplit32_k): x[row] += T(sum of the groups' fp32 partials, fixed order) -- the residual
             // epilogue of o_proj / down_proj, done here at the launch boundary; the completed row is written back (same thread
             // re-reads it below)
@@ -68,6 +69,11 @@ void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows
                                                 (T*)out, H, eps, rows, (const float*)nullptr, 0, (T*)nullptr));
 }
 
+void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, int rows, int mtiles, int H, float eps, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T, 3>), dim3(mtiles * 16), dim3(256), 0, s, (const T*)x, (const T*)w,
+                                                (T*)out, H, eps, rows, (const float*)nullptr, mtiles, (T*)nullptr));
+}
+
 // One-round-trip version for H = 4096 (decode at batch 3-32: two of these per layer sit on the step's critical path): a
 // thread owns 2 x 8 elements, every load (row, slabs, norm weight) is issued up front, the row stays in registers between the
 // statistics and the scaling. Same arithmetic and rounding points as rmsnorm_k.
@@ -80,8 +86,8 @@ __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __rest
     const size_t row = blockIdx.x;
     auto dst = [&](int i) -> T* {
         if (PACK == 0) return out + row * H + i;
-        const int f = PACK == 1 ? (i >> 5) : (2 * (i >> 6) + ((i & 15) >> 3)), g = PACK == 1 ? ((i & 31) >> 3) : ((i & 63) >> 4);
-        return out + ((size_t)((f * 2 + (int)(row >> 4)) * 64 + g * 16 + (int)(row & 15)) << 3);
+        const int f = PACK != 2 ? (i >> 5) : (2 * (i >> 6) + ((i & 15) >> 3)), g = PACK != 2 ? ((i & 31) >> 3) : ((i & 63) >> 4);
+        return out + ((size_t)((f * (PACK == 3 ? groups : 2) + (int)(row >> 4)) * 64 + g * 16 + (int)(row & 15)) << 3);
     };
     const int i0 = threadIdx.x * 8, i1 = i0 + 2048;
     if (PACK && (int)row >= n_rows) {

@@ -30,7 +30,9 @@ struct GemmArgs {
     // output row; `W` then holds the dequantised model-dtype copy the other kernels use
     const void* W8; const float* wscale;
     int out_packed;                  // xstat32_k, EPI_SILU_MUL: write the output fragment-packed (input of xsplit32_k)
-    int xpacked;                     // xstat32_k: X is the fragment-packed 32-row block written by launch_rmsnorm_packed32 (1 / 2)
+    int xpacked;                     // xstat32_k: X is the fragment-packed 32-row block written by launch_rmsnorm_packed32 (1 / 2);
+                                     // 3 (wstat_k): fragment-packed [k / 32][mtiles][lane][8] over `mtiles` row tiles of 16 (out_packed 3 alike)
+    int mtiles;
     long long* trace;                // debug: [tile][8] timestamps (100 MHz ticks) written by thread 0 of every workgroup (skinny_tile)
 };
 
@@ -49,6 +51,7 @@ struct AttnArgs {        // generic softmax(QK^T/sqrt(D)) V over strided tensors
     int causal;                      // query i attends keys j <= i + (Tk - Tq)
     int k_perm;                      // K is a decode KV-cache slab in the 16-position fragment order (rdx_common.h kperm), D = 128
     const uint8_t* key_mask; long km_bs;   // nullable [B][>=Tk], 1 = attend
+    int o_packed_mt;                 // != 0: O is written fragment-packed for wstat_k, [(h D + d) / 32][o_packed_mt][lane][8], row = b Tq + q
 };
 
 // Decode-loop state lives in device memory, per batch row (slot_b[b] = KV slot the next token is written to,
@@ -99,6 +102,10 @@ void launch_conv1x1_stream(int dtype, const GemmArgs& a, const ConvGeom& cg, int
 
 // many-row GEMM / implicit-GEMM convolution with the weight slice in an LDS ring and the activation fragments fetched straight into
 // registers by the wave that owns the rows (wsgemm.hip): K % 64 == 0; convolutions need Cin % 64 == 0
+// weight-stationary GEMM for one prompt's prefill: activations fragment-packed (xpacked 3) and streamed past register-resident weights (wstat.hip)
+bool wstat_supported(const GemmArgs& a, int epi);
+void launch_wstat(int dtype, const GemmArgs& a, int epi, hipStream_t s);
+void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, int rows, int mtiles, int H, float eps, hipStream_t s);
 bool wsgemm_supported(const GemmArgs& a, const ConvGeom& cg, int epi);
 void launch_wsgemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, const void* zero16, hipStream_t s);
 

@@ -80,6 +80,19 @@ WS_CASES += [("", 160, 22016, 4096, 4), ("", 160, 12304, 4096, 0), ("", 160, 409
 
 
 
+# the single prompt's weight-stationary kernel (wstat.hip, force=8): fragment-packed activations (with and without the RMSNorm in the packing
+# launch) streamed past register-resident weights; K = 4096 (one and two tiles per workgroup, ragged last workgroup: 769 tiles) and K = 11008,
+# whole and ragged row tiles, every epilogue it serves, bias
+WSTAT_CASES = [(160, 12304, 4096, 0, True), (160, 4096, 4096, 3, False), (160, 22016, 4096, 4, True), (160, 4096, 11008, 3, False),
+               (33, 2064, 4096, 0, False), (250, 4112, 4096, 3, True), (47, 512, 11008, 3, False), (320, 2080, 4096, 4, False),
+               (129, 1040, 4096, 0, False)]
+
+
+@pytest.mark.parametrize("M,N,K,epi,norm", WSTAT_CASES)
+def test_wstat_matches_fp32(eng, M, N, K, epi, norm):
+    test_gemm_matches_fp32(eng, M, N, K, epi, norm, 8)
+
+
 @pytest.mark.parametrize("cfg_,M,N,K,epi", WS_CASES)
 def test_wsgemm_matches_fp32(eng, cfg_, M, N, K, epi, monkeypatch):
     if cfg_:

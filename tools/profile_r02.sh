@@ -40,3 +40,11 @@ if [ $what = all ] || [ $what = shapes ]; then
   python $ROOT/tools/enc_kernels.py 1 > $OUT/enc_shapes_b1.txt 2>&1
 fi
 du -sh $OUT
+if [ $what = prefill ]; then
+  trace prefill_b1 11 python $ROOT/tools/prefill_only.py 1 160 10
+fi
+if [ $what = prefill_pmc ]; then
+  for ctr in FETCH_SIZE TCC_HIT_sum TCC_MISS_sum; do
+    pmc prefill $ctr python $ROOT/tools/prefill_only.py 1 160 2
+  done
+fi
