@@ -231,12 +231,18 @@ __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict_
 // in flight. Waves 2 (M) x 4 (N), wave tile 128 x 64 = 8 x 4 MFMA tiles (128 accumulator registers, two waves per SIMD).
 // One barrier per stage: it publishes stage s and at the same time frees the slot that stage s+3 is then loaded into.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int G2_BM = 256, G2_BN = 256, G2_NS = 4;
+// MTW = row tiles of 16 per wave: 8 -> 256-row block (32 KiB stages, 128 KiB ring); 10 -> 320-row block (36 KiB stages, 144 KiB ring, 160
+// accumulator registers), for shapes where it saves a round: M = 5120, N = 4096 (o_proj / down of the batch-32 prefill) is 320 tiles of
+// 256 x 256 -- two rounds on 256 CUs, the second a quarter full -- but exactly 256 tiles of 320 x 256.
+constexpr int G2_BN = 256, G2_NS = 4;
 
-template <typename T, int EPI>
+template <typename T, int EPI, int MTW>
 __global__ __launch_bounds__(512, 2) void gemm_dma256_k(GemmArgs a) {
     typedef typename Vec8<T>::type V8;
-    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [stage 4][operand 2][block 16][lane 64]
+    constexpr int G2_BM = 32 * MTW, XS = 2 * MTW;                      // activation sub-tiles of 16 rows per stage
+    constexpr int XPW = (XS + 7) / 8;                                   // ... staged per wave (the last waves re-stage sub-tile XS - 1: same bytes)
+    constexpr int SUB = 16 + XS;                                        // KiB (sub-tiles) per stage
+    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [stage 4][W 16 | X XS][lane 64]
     const int MB = (a.M + G2_BM - 1) / G2_BM, NB = (a.N + G2_BN - 1) / G2_BN;
     const int nwg = MB * NB;
     int tile;
@@ -254,45 +260,49 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_k(GemmArgs a) {
     const T* X = reinterpret_cast<const T*>(a.X);
     const u4* Wp = reinterpret_cast<const u4*>(a.W) + lane;
 
-    // this wave stages sub-tiles 2w, 2w+1 of each operand; addresses: one base per block, advanced by the stage index
+    // this wave stages weight sub-tiles 2w, 2w+1 and activation sub-tiles XPW w ..; addresses: one base per sub-tile, advanced by the stage index
     const u4* wsrc[2];
-    const T* xsrc[2];
+    const T* xsrc[XPW];
+    int xst[XPW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int st = w * 2 + j;
-        wsrc[j] = Wp + (size_t)min((N0 >> 4) + st, NT16 - 1) * KC * 64;
-        xsrc[j] = X + (size_t)min(M0 + st * 16 + r, a.M - 1) * a.ldx + g * 8;
+    for (int j = 0; j < 2; ++j) wsrc[j] = Wp + (size_t)min((N0 >> 4) + w * 2 + j, NT16 - 1) * KC * 64;
+#pragma unroll
+    for (int j = 0; j < XPW; ++j) {
+        xst[j] = min(w * XPW + j, XS - 1);
+        xsrc[j] = X + (size_t)min(M0 + xst[j] * 16 + r, a.M - 1) * a.ldx + g * 8;
     }
     auto stage = [&](int s, int slot) {                                 // s is clamped by the caller: loads are unconditional
-        u4* base = lds + (size_t)slot * 2 * 16 * 64;
+        u4* base = lds + (size_t)slot * SUB * 64;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int st = w * 2 + j;
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + (size_t)s * 64), (lptr_t)(base + st * 64), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[j] + (size_t)s * 32), (lptr_t)(base + (16 + st) * 64), 16, 0, 0);
-        }
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + (size_t)s * 64), (lptr_t)(base + (w * 2 + j) * 64), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < XPW; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[j] + (size_t)s * 32), (lptr_t)(base + (16 + xst[j]) * 64), 16, 0, 0);
     };
+    constexpr int LPS = 2 + XPW;                                        // loads per wave per stage
 
-    v4f acc[4][8];
+    v4f acc[4][MTW];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MTW; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
-    for (int p = 0; p < G2_NS - 1; ++p) stage(min(p, nsteps - 1), p);   // stages 0..2 in flight: 12 loads per wave
+    for (int p = 0; p < G2_NS - 1; ++p) stage(min(p, nsteps - 1), p);   // stages 0..2 in flight
     for (int s = 0; s < nsteps; ++s) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // this wave's 4 loads of stage s have landed
+        if (LPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // this wave's loads of stage s have landed (two younger stages may fly)
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                   // ... everyone's have, and everyone finished stage s-1
         stage(min(s + G2_NS - 1, nsteps - 1), (s + G2_NS - 1) % G2_NS); // into the slot stage s-1 was read from (past the end:
                                                                         // the last stage again, harmless, keeps the wait counted)
-        const u4* base = lds + (size_t)(s % G2_NS) * 2 * 16 * 64;
+        const u4* base = lds + (size_t)(s % G2_NS) * SUB * 64;
         V8 wf[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) wf[nt] = as_vec8<T>(base[(wn * 4 + nt) * 64 + lane]);
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const V8 xf = as_vec8<T>(base[(16 + wm * 8 + mt) * 64 + lane]);
+        for (int mt = 0; mt < MTW; ++mt) {
+            const V8 xf = as_vec8<T>(base[(16 + wm * MTW + mt) * 64 + lane]);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma16(wf[nt], xf, acc[nt][mt]);
         }
@@ -306,8 +316,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_k(GemmArgs a) {
         const int n = N0 + (wn * 4 + nt) * 16 + g * 4;
         if (n >= a.N) continue;                                     // whole 16-column tile at once (N % 16 == 0)
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int m = M0 + (wm * 8 + mt) * 16 + r;
+        for (int mt = 0; mt < MTW; ++mt) {
+            const int m = M0 + (wm * MTW + mt) * 16 + r;
             float v[4] = {acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]};
             if (EPI == EPI_SILU_MUL) {
                 float u[4];
@@ -365,13 +375,24 @@ static void launch_dma_epi(const GemmArgs& a, float* ws, size_t ws_floats, hipSt
     {   // large M: the 256 x 256 tile kernel with the 4-stage ring, as long as its grid still covers the chip
         const char* e256 = getenv("RDX_DMA256");
         const int big = e256 ? atoi(e256) : 256;                  // minimum number of 256 x 256 tiles (0 = never)
-        const int MB2 = (a.M + G2_BM - 1) / G2_BM, NB2 = (a.N + G2_BN - 1) / G2_BN;
+        const int MB2 = (a.M + 255) / 256, NB2 = (a.N + G2_BN - 1) / G2_BN;
         // (the short-K / narrow-N 1x1 convolutions of the encoder are memory-bound and do better with the small tile)
         if (big && a.M >= 1024 && a.K >= 512 && a.N >= 1024 && MB2 * NB2 >= big) {
+            // 320-row blocks when they save rounds on the 256 CUs: cost = rounds x rows per block
+            static const int allow320 = getenv("RDX_DMA320") ? atoi(getenv("RDX_DMA320")) : 1;
+            const int MB3 = (a.M + 319) / 320;
+            const long c256 = (long)((MB2 * NB2 + 255) / 256) * 256, c320 = (long)((MB3 * NB2 + 255) / 256) * 320;
+            if (allow320 && c320 < c256) {
+                const size_t smem3 = (size_t)G2_NS * (16 + 20) * 64 * sizeof(u4);   // 144 KiB
+                static bool attr3 = false;
+                if (!attr3) { hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3); attr3 = true; }
+                hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 10>), dim3(MB3 * NB2), dim3(512), smem3, s, a);
+                return;
+            }
             const size_t smem2 = (size_t)G2_NS * 2 * 16 * 64 * sizeof(u4);   // 128 KiB
             static bool attr2 = false;
-            if (!attr2) { hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); attr2 = true; }
-            hipLaunchKernelGGL((gemm_dma256_k<T, EPI>), dim3(MB2 * NB2), dim3(512), smem2, s, a);
+            if (!attr2) { hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); attr2 = true; }
+            hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 8>), dim3(MB2 * NB2), dim3(512), smem2, s, a);
             return;
         }
     }

@@ -57,6 +57,8 @@ CASES = [
     # 256 x 256 x 32 four-stage LDS-DMA kernel (M >= 1024 and >= 256 tiles): ragged M and N, few and many K stages, every epilogue shape
     (2048, 8192, 512, 4, False, 3), (1300, 16400, 576, 0, False, 3), (1024, 16384, 512, 3, False, 3), (5120, 4096, 640, 6, False, 3),
     (4096, 4096, 1024, 1, False, 3),
+    # ... its 320-row block variant (taken when it saves a round on 256 CUs: M = 5120, N = 4096 is 256 tiles instead of 320), ragged last block
+    (5000, 4096, 576, 3, False, 3), (5120, 4096, 512, 0, False, 3),
     # 16 < M <= 32 with LDS-staged activations (skinny32.hip): 4-tile and 2-tile workgroups, ragged tile groups, ragged K ranges
     (32, 8208, 512, 3, False, 0), (19, 1040, 4096, 0, False, 0), (32, 2064, 1408, 4, False, 0), (27, 48, 11008, 3, False, 0),
     (32, 16400, 1024, 4, True, 0),
