@@ -378,11 +378,13 @@ static void launch_dma_epi(const GemmArgs& a, float* ws, size_t ws_floats, hipSt
         const int MB2 = (a.M + 255) / 256, NB2 = (a.N + G2_BN - 1) / G2_BN;
         // (the short-K / narrow-N 1x1 convolutions of the encoder are memory-bound and do better with the small tile)
         if (big && a.M >= 1024 && a.K >= 512 && a.N >= 1024 && MB2 * NB2 >= big) {
-            // 320-row blocks when they save rounds on the 256 CUs: cost = rounds x rows per block
+            // 320-row blocks when they save rounds on the 256 CUs: cost = rounds x rows per block, with a 15 % handicap -- a 320-row tile is less
+            // efficient than its size says (24 activation sub-tiles staged for 20, 200 VGPRs): the Q-Former cross-K/V GEMM (6272 x 9216: 3 rounds of
+            // 320 rows against 4 of 256) measured 219 us against 188 us
             static const int allow320 = getenv("RDX_DMA320") ? atoi(getenv("RDX_DMA320")) : 1;
             const int MB3 = (a.M + 319) / 320;
             const long c256 = (long)((MB2 * NB2 + 255) / 256) * 256, c320 = (long)((MB3 * NB2 + 255) / 256) * 320;
-            if (allow320 && c320 < c256) {
+            if (allow320 && c320 * 115 < c256 * 100) {
                 const size_t smem3 = (size_t)G2_NS * (16 + 20) * 64 * sizeof(u4);   // 144 KiB
                 static bool attr3 = false;
                 if (!attr3) { hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3); attr3 = true; }

@@ -145,8 +145,10 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
         __syncthreads();
     }
 
-    const bool xok = r < a.M;
-    const T* xrow = xs + (size_t)(xok ? r : 0) * K + g * (W8 ? 16 : 8);
+    // MFMA columns m >= M read row 0 again (an LDS broadcast) instead of zeros: their results are never stored, and a per-lane select around the
+    // LDS read put an EXEC-masked branch inside the main loop -- the loop fell apart into basic blocks, the refill of a batch was issued before
+    // the batch's last MFMA into a spare register, and the copy back waited vmcnt(0) on every trip
+    const T* xrow = xs + (size_t)(r < a.M ? r : 0) * K + g * (W8 ? 16 : 8);
     v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
     // Main loop: loads are UNCONDITIONAL (addresses clamped into the slice) and no MFMA is guarded, so the compiler can
     // wait with counted vmcnt (one batch stays in flight); a conditional load anywhere in the loop makes it fall back
@@ -159,24 +161,42 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const u4 wd = dequant8<T>(h ? wreg[u].z : wreg[u].x, h ? wreg[u].w : wreg[u].y);
-                        const u4 xv = xok ? *reinterpret_cast<const u4*>(xrow + (size_t)(cb + u) * 64 + h * 8) : (u4){0u, 0u, 0u, 0u};
+                        const u4 xv = *reinterpret_cast<const u4*>(xrow + (size_t)(cb + u) * 64 + h * 8);
                         acc = mfma16(as_vec8<T>(wd), as_vec8<T>(xv), acc);
                     }
                 } else {
-                    const u4 xv = xok ? *reinterpret_cast<const u4*>(xrow + (size_t)(cb + u) * 32) : (u4){0u, 0u, 0u, 0u};
+                    const u4 xv = *reinterpret_cast<const u4*>(xrow + (size_t)(cb + u) * 32);
                     acc = mfma16(as_vec8<T>(wreg[u]), as_vec8<T>(xv), acc);
                 }
             }
         }
     };
+    // Main loop: a ring of 2 U fragments, every fragment refilled right after the MFMA that consumed it, the pair pinned by a scheduling barrier
+    // (the xstat32_k idiom): the waits are vmcnt(2 U - 1) and 2 U - 1 loads per wave stay in flight. As two batches ("consume U, refill U") the
+    // compiler issued the refills early into spare registers and copied them back at the loop end behind vmcnt(1..7) / vmcnt(0): one load in
+    // flight per wave at the end of every trip.
+    auto consume1 = [&](const u4& wv, int c) {
+        if (W8) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const u4 wd = dequant8<T>(h ? wv.z : wv.x, h ? wv.w : wv.y);
+                const u4 xv = *reinterpret_cast<const u4*>(xrow + (size_t)c * 64 + h * 8);
+                acc = mfma16(as_vec8<T>(wd), as_vec8<T>(xv), acc);
+            }
+        } else {
+            const u4 xv = *reinterpret_cast<const u4*>(xrow + (size_t)c * 32);
+            acc = mfma16(as_vec8<T>(wv), as_vec8<T>(xv), acc);
+        }
+    };
     int cb = c0;
     for (; cb + 2 * U < c1; cb += 2 * U) {
-        consume(wa_, cb, false);
 #pragma unroll
-        for (int u = 0; u < U; ++u) wa_[u] = ldg16_nt(wbase + (size_t)min(cb + 2 * U + u, clast) * 64);
-        consume(wb_, cb + U, false);
-#pragma unroll
-        for (int u = 0; u < U; ++u) wb_[u] = ldg16_nt(wbase + (size_t)min(cb + 3 * U + u, clast) * 64);
+        for (int u = 0; u < 2 * U; ++u) {
+            u4& wr = u < U ? wa_[u] : wb_[u - U];
+            consume1(wr, cb + u);
+            wr = ldg16_nt(wbase + (size_t)min(cb + 2 * U + u, clast) * 64);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     consume(wa_, cb, true);
     consume(wb_, cb + U, true);

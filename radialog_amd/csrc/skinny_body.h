@@ -57,15 +57,12 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
         trc[7] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));    // HW_REG_XCC_ID (id 20)
     }
     // two weight batches in flight before anything else (HBM latency overlaps the wait and the prologue)
-    u4 wv[U], wn[U];
+    // (unconditional, addresses clamped into the slice: a short slice re-reads its last KiB)
+    u4 ring[2 * U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) wv[u] = ldg16_nt(wbase + (size_t)min(c0 + u, clast) * 64);
-#pragma unroll
-    for (int u = 0; u < U; ++u) wn[u] = wv[u];
-    if (c0 + U < c1) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) wn[u] = ldg16_nt(wbase + (size_t)min(c0 + U + u, clast) * 64);
-    }
+    for (int u = 0; u < 2 * U; ++u) ring[u] = ldg16_nt(wbase + (size_t)min(c0 + u, clast) * 64);
+    u4* const wv = ring;            // the two-batch view of the direct-activation path below
+    u4* const wn = ring + U;
 
     SK_T(1);
     wait_inputs();          // fused launches: block until the producer workgroups have published X (and resid)
@@ -146,6 +143,40 @@ __device__ __forceinline__ void skinny_tile(const GemmArgs& a, const int tile, c
     };
     if (!XLDS) load_x(xr, c0);
 
+    if (XLDS) {
+        // LDS-staged activations (every decode GEMV): a ring of 2 U weight fragments, each refilled right after the MFMAs that consumed it, the pair
+        // pinned by a scheduling barrier -- the waits are vmcnt(2 U - 1), 2 U - 1 loads per wave stay in flight. (As two batches with a register
+        // copy "wv = wn" between them the loop waited vmcnt(0) on every trip.) MFMA columns of rows >= M read row 0 again (LDS broadcast, never
+        // stored): a per-lane select around the LDS read would put an EXEC-masked branch into the loop.
+        auto consume1 = [&](const u4& wreg, int c) {
+            if (W8) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u4 wd = dequant8<T>(h ? wreg.z : wreg.x, h ? wreg.w : wreg.y);
+                    const u4 xv = *reinterpret_cast<const u4*>(xrow[0] + (size_t)c * 64 + h * 8);
+                    acc[0] = mfma16(as_vec8<T>(wd), as_vec8<T>(xv), acc[0]);
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const u4 xv = *reinterpret_cast<const u4*>(xrow[mt] + (size_t)c * 32);
+                    acc[mt] = mfma16(as_vec8<T>(wreg), as_vec8<T>(xv), acc[mt]);
+                }
+            }
+        };
+        int cb = c0;
+        for (; cb + 2 * U < c1; cb += 2 * U) {
+#pragma unroll
+            for (int u = 0; u < 2 * U; ++u) {
+                consume1(ring[u], cb + u);
+                ring[u] = ldg16_nt(wbase + (size_t)min(cb + 2 * U + u, clast) * 64);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * U; ++u)
+            if (cb + u < c1) consume1(ring[u], cb + u);
+    } else
     for (int cb = c0; cb < c1; cb += U) {
         if (!XLDS && cb + U < c1) load_x(xn, cb + U);
 #pragma unroll
