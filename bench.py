@@ -310,8 +310,19 @@ def main():
     use_graph = not args.no_graph
     eng = RdxEngine(cfg, dtype=args.dtype, device=local_rank, max_batch=B, max_len=max_len, lora=True, weights_fp8=args.fp8)
     eng.load_weights(synth_getter(cfg, eng.device, lora=True))
+    comm_note = None
     if launched:
-        init_comm(eng, rank, world)                   # RCCL communicator inside librdx (rdx_comm_init)
+        try:
+            init_comm(eng, rank, world)               # RCCL communicator inside librdx (rdx_comm_init)
+        except Exception as e:                        # keep the run (and say so in the JSON line): the token gather then goes over the host group
+            comm_note = f"rdx_comm_init failed ({type(e).__name__}: {e}); token ids gathered over the torch.distributed host group instead"
+            print("warning: " + comm_note, file=sys.stderr)
+        if dist is not None and world > 1:            # all ranks take the same path: any failure switches every rank to the host group
+            ok = torch.tensor([0 if comm_note else 1], dtype=torch.int32, device=eng.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                eng.comm_off = True
+                comm_note = comm_note or "rdx_comm_init failed on another rank; token ids gathered over the torch.distributed host group instead"
 
     elapsed, out, img, ids, out_q = run_steps(eng, cfg, args, B, T, N, rank, world, dist, args.steps, args.warmup, use_graph)
     per_rank_ms = [elapsed / args.steps * 1e3]
@@ -340,7 +351,7 @@ def main():
             "encoder_ms_per_img": enc_ms,
             "tokens_per_s": args.steps * B * world * N / elapsed,
             "rccl_ranks": eng.comm_world, "per_rank_ms_per_step": per_rank_ms,
-            "collective": ("rdx_allgather_tokens (ncclAllGather inside librdx), int32[%d,%d] per rank per step" % (B, N)) if eng.comm_world else None,
+            "collective": ("rdx_allgather_tokens (ncclAllGather inside librdx), int32[%d,%d] per rank per step" % (B, N)) if eng.comm_world else comm_note,
             "roofline": roof,
         }
         eng.close()

@@ -302,7 +302,9 @@ class RdxEngine:
 
     @property
     def comm_world(self) -> int:
-        return int(self.lib.rdx_comm_world(self.ctx))
+        """Ranks of the RCCL communicator inside librdx (0: none, or switched off by the launcher with `comm_off = True` after a
+        bring-up that did not succeed on every rank)."""
+        return 0 if getattr(self, "comm_off", False) else int(self.lib.rdx_comm_world(self.ctx))
 
     def allgather_tokens(self, tokens: torch.Tensor) -> torch.Tensor:
         """int32[B_local, N] on this device -> int32[world * B_local, N], rank-major: one ncclAllGather on the engine's stream."""

@@ -44,9 +44,12 @@ def allgather_tokens(tokens: torch.Tensor, world: int, engine=None) -> torch.Ten
         return tokens
     import torch.distributed as dist
     tokens = tokens.contiguous()
+    dev = tokens.device
+    if tokens.is_cuda and dist.get_backend() == "gloo":     # host process group, device tokens (a launcher whose RCCL bring-up failed): stage through the host
+        tokens = tokens.cpu()
     out = torch.empty((world * tokens.shape[0],) + tuple(tokens.shape[1:]), dtype=tokens.dtype, device=tokens.device)
     dist.all_gather_into_tensor(out, tokens)
-    return out
+    return out.to(dev)
 
 
 def allgather_ragged(tokens: torch.Tensor, counts, world: int, pad_id: int = 0, engine=None) -> torch.Tensor:
