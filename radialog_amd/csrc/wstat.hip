@@ -10,9 +10,10 @@
 // NT = 2, K = 4096, 8 waves). The ACTIVATIONS stream past them, row tile by row tile, out of L2: they arrive fragment-packed
 // ([k / 32][row tile][lane][8] -- written so by rmsnorm_k<T, 3>, the attention kernel and this kernel's SwiGLU epilogue), so a wave's
 // B fragment is one contiguous KiB, fetched through a register ring that is refilled one load per consumed fragment (issue order =
-// consume order, the waits stay counted). Per row tile a wave does NT x CPW MFMAs and drops its 16 x 16 fp32 partials in LDS; one
-// barrier per row tile, then the threads add the WAVES partials in a fixed order (deterministic, no atomics) and run the epilogue
-// while the next row tile is landing. The same rounding points as the other GEMM kernels (skinny_body.h / gemm.hip epilogues).
+// consume order, the waits stay counted). Per row tile a wave does NT x CPW MFMAs and drops its 16 x 16 fp32 partials in one of four
+// LDS buffers; there is NO workgroup barrier in the loop (LDS counters instead, see below): every wave adds the WAVES partials of the
+// PREVIOUS row tile for its own 64 outputs in a fixed order (deterministic, no atomics on data) and runs the epilogue while its next
+// fragments are landing. The same rounding points as the other GEMM kernels (skinny_body.h / gemm.hip epilogues).
 //
 // Cost model: a workgroup loads NT x K x 32 B of weights (HBM), then streams M x K x 2 B of activations through the
 // CU's L1 (64 B/clk: 8.9 us at M = 160, K = 4096) whatever NT is -- so NT is as large as the registers allow.
