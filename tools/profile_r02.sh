@@ -41,6 +41,7 @@ if [ $what = all ] || [ $what = shapes ]; then
 fi
 du -sh $OUT
 if [ $what = prefill ]; then
+  trace prefill_b32 4 python $ROOT/tools/prefill_only.py 32 160 3
   trace prefill_b1 11 python $ROOT/tools/prefill_only.py 1 160 10
 fi
 if [ $what = prefill_pmc ]; then
