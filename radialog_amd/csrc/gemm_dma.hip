@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict_
 // 256 x 256 -- two rounds on 256 CUs, the second a quarter full -- but exactly 256 tiles of 320 x 256.
 constexpr int G2_BN = 256, G2_NS = 4;
 
-template <typename T, int EPI, int MTW>
+template <typename T, int EPI, int MTW, int SP>
 __global__ __launch_bounds__(512, 2) void gemm_dma256_k(GemmArgs a) {
     typedef typename Vec8<T>::type V8;
     constexpr int G2_BM = 32 * MTW, XS = 2 * MTW;                      // activation sub-tiles of 16 rows per stage
@@ -271,17 +271,18 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_k(GemmArgs a) {
         xst[j] = min(w * XPW + j, XS - 1);
         xsrc[j] = X + (size_t)min(M0 + xst[j] * 16 + r, a.M - 1) * a.ldx + g * 8;
     }
-    auto stage = [&](int s, int slot) {                                 // s is clamped by the caller: loads are unconditional
-        u4* base = lds + (size_t)slot * SUB * 64;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + (size_t)s * 64), (lptr_t)(base + (w * 2 + j) * 64), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < XPW; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[j] + (size_t)s * 32), (lptr_t)(base + (16 + xst[j]) * 64), 16, 0, 0);
-    };
     constexpr int LPS = 2 + XPW;                                        // loads per wave per stage
+    auto stage1 = [&](int s, int slot, int j) {                         // piece j of this wave's LPS pieces of stage s (j is a compile-time constant at every call)
+        u4* base = lds + (size_t)slot * SUB * 64;
+        if (j < 2) __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[j] + (size_t)s * 64), (lptr_t)(base + (w * 2 + j) * 64), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gptr_t)(xsrc[j - 2] + (size_t)s * 32), (lptr_t)(base + (16 + xst[j - 2]) * 64), 16, 0, 0);
+    };
+    auto stage = [&](int s, int slot) {                                 // s is clamped by the caller: loads are unconditional
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) stage1(s, slot, j);
+    };
 
+    constexpr int spread = SP;                                          // placement of the next stage's LDS-DMA pieces (see the loop)
     v4f acc[4][MTW];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -294,8 +295,12 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_k(GemmArgs a) {
         if (LPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // this wave's loads of stage s have landed (two younger stages may fly)
         else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                   // ... everyone's have, and everyone finished stage s-1
-        stage(min(s + G2_NS - 1, nsteps - 1), (s + G2_NS - 1) % G2_NS); // into the slot stage s-1 was read from (past the end:
-                                                                        // the last stage again, harmless, keeps the wait counted)
+        // stage s + 3 goes into the slot stage s-1 was read from (past the end: the last stage again, harmless, keeps the wait counted). SP: its LDS-DMA
+        // pieces are issued one by one behind the MFMAs of row tiles 1, 3, 5, ... instead of all in front of the first MFMA: an LDS-DMA instruction
+        // costs 60-185 cycles of issue, and four or five of them up front left the matrix pipe idle that long every stage (batched prefill
+        // 68.8 -> 66.5 ms; behind the even row tiles 66.2-67.4; RDX_DMA256_SPREAD=0 restores the old order)
+        const int sn = min(s + G2_NS - 1, nsteps - 1), slotn = (s + G2_NS - 1) % G2_NS;
+        if (!spread) stage(sn, slotn);
         const u4* base = lds + (size_t)(s % G2_NS) * SUB * 64;
         V8 wf[4];
 #pragma unroll
@@ -305,6 +310,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_k(GemmArgs a) {
             const V8 xf = as_vec8<T>(base[(16 + wm * MTW + mt) * 64 + lane]);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma16(wf[nt], xf, acc[nt][mt]);
+            if (spread && (mt & 1) == 1 && (mt >> 1) < LPS) { stage1(sn, slotn, mt >> 1); __builtin_amdgcn_sched_barrier(0); }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // LDS reads of this stage are done before the next barrier
     }
@@ -371,13 +377,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_k(GemmArgs a, const float* 
 }
 
 template <typename T, int EPI>
-static void launch_dma_epi(const GemmArgs& a, float* ws, size_t ws_floats, hipStream_t s) {
+static void launch_dma_epi(const GemmArgs& a_in, float* ws, size_t ws_floats, hipStream_t s) {
+    const GemmArgs& a = a_in;
     {   // large M: the 256 x 256 tile kernel with the 4-stage ring, as long as its grid still covers the chip
         const char* e256 = getenv("RDX_DMA256");
         const int big = e256 ? atoi(e256) : 256;                  // minimum number of 256 x 256 tiles (0 = never)
         const int MB2 = (a.M + 255) / 256, NB2 = (a.N + G2_BN - 1) / G2_BN;
         // (the short-K / narrow-N 1x1 convolutions of the encoder are memory-bound and do better with the small tile)
         if (big && a.M >= 1024 && a.K >= 512 && a.N >= 1024 && MB2 * NB2 >= big) {
+            static const int spread = getenv("RDX_DMA256_SPREAD") ? atoi(getenv("RDX_DMA256_SPREAD")) : 1;
             // 320-row blocks when they save rounds on the 256 CUs: cost = rounds x rows per block, with a 15 % handicap -- a 320-row tile is less
             // efficient than its size says (24 activation sub-tiles staged for 20, 200 VGPRs): the Q-Former cross-K/V GEMM (6272 x 9216: 3 rounds of
             // 320 rows against 4 of 256) measured 219 us against 188 us
@@ -387,14 +395,24 @@ static void launch_dma_epi(const GemmArgs& a, float* ws, size_t ws_floats, hipSt
             if (allow320 && c320 * 115 < c256 * 100) {
                 const size_t smem3 = (size_t)G2_NS * (16 + 20) * 64 * sizeof(u4);   // 144 KiB
                 static bool attr3 = false;
-                if (!attr3) { hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3); attr3 = true; }
-                hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 10>), dim3(MB3 * NB2), dim3(512), smem3, s, a);
+                if (!attr3) {
+                    hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 10, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+                    hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 10, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
+                    attr3 = true;
+                }
+                if (spread) hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 10, 1>), dim3(MB3 * NB2), dim3(512), smem3, s, a);
+                else hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 10, 0>), dim3(MB3 * NB2), dim3(512), smem3, s, a);
                 return;
             }
             const size_t smem2 = (size_t)G2_NS * 2 * 16 * 64 * sizeof(u4);   // 128 KiB
             static bool attr2 = false;
-            if (!attr2) { hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2); attr2 = true; }
-            hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 8>), dim3(MB2 * NB2), dim3(512), smem2, s, a);
+            if (!attr2) {
+                hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+                hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
+                attr2 = true;
+            }
+            if (spread) hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 8, 1>), dim3(MB2 * NB2), dim3(512), smem2, s, a);
+            else hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 8, 0>), dim3(MB2 * NB2), dim3(512), smem2, s, a);
             return;
         }
     }
