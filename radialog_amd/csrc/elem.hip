@@ -64,15 +64,9 @@ __global__ __launch_bounds__(256) void rmsnorm_k(const T* x, const T* __restrict
     }
 }
 
-void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s) {
-    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T, 0>), dim3(rows), dim3(256), 0, s, (const T*)x, (const T*)w,
-                                                (T*)out, H, eps, rows, (const float*)nullptr, 0, (T*)nullptr));
-}
 
-void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, int rows, int mtiles, int H, float eps, hipStream_t s) {
-    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T, 3>), dim3(mtiles * 16), dim3(256), 0, s, (const T*)x, (const T*)w,
-                                                (T*)out, H, eps, rows, (const float*)nullptr, mtiles, (T*)nullptr));
-}
+
+void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, int rows, int mtiles, int H, float eps, hipStream_t s);
 
 // One-round-trip version for H = 4096 (decode at batch 3-32: two of these per layer sit on the step's critical path): a
 // thread owns 2 x 8 elements, every load (row, slabs, norm weight) is issued up front, the row stays in registers between the
@@ -136,6 +130,26 @@ __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __rest
         for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof<T>(wv[k][j]) * rnd<T>(tof<T>(v[k][j]) * rs));
         stg16(dst(k ? i1 : i0), as_u4<T>(o));
     }
+}
+
+void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, int rows, int mtiles, int H, float eps, hipStream_t s) {
+    if (H == 4096 && w) {       // one-round-trip kernel, PACK 3: `groups` carries the row tiles
+        RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm4096_k<T, 3>), dim3(mtiles * 16), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, eps, rows,
+                                                    (const float*)nullptr, mtiles, (T*)nullptr));
+        return;
+    }
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T, 3>), dim3(mtiles * 16), dim3(256), 0, s, (const T*)x, (const T*)w,
+                                                (T*)out, H, eps, rows, (const float*)nullptr, mtiles, (T*)nullptr));
+}
+
+void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s) {
+    if (H == 4096 && w) {       // the one-round-trip kernel (row kept in registers between the statistics and the scaling): same elements per thread, same order
+        RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm4096_k<T, 0>), dim3(rows), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, eps, rows,
+                                                    (const float*)nullptr, 0, (T*)nullptr));
+        return;
+    }
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T, 0>), dim3(rows), dim3(256), 0, s, (const T*)x, (const T*)w,
+                                                (T*)out, H, eps, rows, (const float*)nullptr, 0, (T*)nullptr));
 }
 
 void launch_rmsnorm_packed32(int dtype, void* x, const void* w, void* out, int rows, int H, float eps, int pack, const float* slab,
