@@ -49,3 +49,10 @@ if [ $what = prefill_pmc ]; then
     pmc prefill $ctr python $ROOT/tools/prefill_only.py 1 160 2
   done
 fi
+if [ $what = mfma ]; then
+  rm -rf /tmp/pmc_mfma
+  (cd /tmp && rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d /tmp/pmc_mfma -o pmc --output-format rocpd -- python $ROOT/tools/gemm_bench.py > /tmp/pmc_mfma.log 2>&1)
+  db=$(find /tmp/pmc_mfma -name "*.db" 2>/dev/null | head -1)
+  if [ -n "$db" ]; then python $ROOT/tools/pmc_summary.py $db gemm_dma > $OUT/pmc_mfma.txt 2>&1; else tail -8 /tmp/pmc_mfma.log > $OUT/pmc_mfma.txt; fi
+  tail -6 /tmp/pmc_mfma.log >> $OUT/pmc_mfma.txt
+fi
