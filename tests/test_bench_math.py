@@ -1,0 +1,69 @@
+"""bench.py's roofline arithmetic (algorithmic FLOPs / bytes the fractions are computed from) against independently derived figures.
+CPU only: the helpers are pure functions of the configuration."""
+import importlib.util
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(REPO, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def test_weight_stream_bytes_of_a_decode_step_match_the_parameter_count():
+    from radialog_amd.config import full_cfg
+    b = _bench()
+    lc = full_cfg().llama
+    got = b.llama_param_bytes(lc, lambda n, k: 2)
+    H, I, V, L, r = 4096, 11008, 32001, 32, 8
+    assert (lc.hidden, lc.inter, lc.vocab, lc.layers, lc.lora_r) == (H, I, V, L, r)
+    # Vicuna-7B: q,k,v,o 4 H^2, gate/up/down 3 H I per layer, lm_head V H (the input embedding is a gather, not a stream);
+    # LoRA r = 8 on q and v: A [r, H] and B [H, r] each; two RMSNorm weights per layer + the final one
+    params = L * (4 * H * H + 3 * H * I + 2 * (r * H + H * r) + 2 * H) + V * H + H
+    assert got == 2 * params
+    assert abs(got / 1e9 - 13.22) < 0.01          # the "13.21 GB" the documents quote (13.223 GB exactly)
+
+
+def test_prefill_and_encode_flops():
+    from radialog_amd.config import full_cfg
+    b = _bench()
+    cfg = full_cfg()
+    lc = cfg.llama
+    H, I, V, L, r, T = lc.hidden, lc.inter, lc.vocab, lc.layers, lc.lora_r, 160
+    gemm = 2.0 * T * L * ((3 * H + 2 * r) * H + H * H + 3 * H * I)                 # projections incl. the 16 LoRA-A rows
+    attn = L * 2.0 * (T * T * H + T * T * H) / 2                                      # QK^T and PV, causal half
+    tail = 2.0 * V * H + 2.0 * 32 * lc.qformer_dim * H                                # lm_head on the last position, img_proj on 32 slots
+    assert abs(b.prefill_flops(lc, T, 1) - (gemm + attn + tail)) < 1e6
+    assert abs(b.prefill_flops(lc, T, 32) - 32 * b.prefill_flops(lc, T, 1)) < 1e6
+    assert abs(b.prefill_flops(lc, T, 1) / 1e12 - 2.080) < 0.002                     # the 2.08 TFLOP per prompt of the docs
+    # encoder: ResNet-50 at 448 px is 4 x the 224-px 4.09 GMAC of the torchvision model card (convolutions only; no fc) = 16.4 GMAC
+    v = cfg.vision
+    assert (v.img, tuple(v.planes), tuple(v.blocks)) == (448, (64, 128, 256, 512), (3, 4, 6, 3))
+    enc = b.encode_flops(cfg)
+    assert abs(enc / 1e9 - 45.09) < 0.05                                              # 45.09 GFLOP per image (profiles / DESIGN)
+    trunk_mac = 4 * 4.09e9
+    assert trunk_mac * 2 < enc < trunk_mac * 2 + 14e9                                 # trunk + patch-embed conv + projector + Q-Former
+
+
+def test_committed_bench_line_is_self_consistent():
+    """The round's committed driver-style line: value = 1 / step time, decode fraction recomputed from its own fields."""
+    with open(os.path.join(REPO, "profiles", "r02_bench.json")) as f:
+        d = json.loads(f.read().strip().splitlines()[-1])
+    assert d["unit"] == "reports/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert abs(d["value"] - 1000.0 / d["ms_per_step"] * d["config"]["global_batch"]) < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["achieved"] - r["bytes_per_launch"] / r["us_per_launch"] / 1e3) < 1.0            # GB/s = bytes / us / 1e3
+    assert 0.95 < r["traffic"] / r["bytes_per_launch"] < 1.05                                      # PMC traffic ~ algorithmic bytes: no re-reads
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["b32"]["value"] > d["value"]
