@@ -11,6 +11,11 @@ generated token ids are gathered with ONE RCCL all-gather issued by librdx itsel
 step -- the only collective on the path; torch.distributed (a gloo group on the host) carries the 128-byte RCCL id, the barrier and
 the max-over-ranks clock.
 
+`python bench.py --gpus N` without a launcher (no RANK / WORLD_SIZE in the environment) starts the N ranks itself: it re-executes
+under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one process per GPU, LOCAL_RANK -> device)
+and fails loudly when fewer than N GPUs are visible. Launched by torch.distributed.run directly (the driver's form) it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; WORLD_SIZE must equal --gpus.
+
 Rank 0 prints ONE JSON line. `value` = reports/s of the whole job with inputs resident in HBM. Added objects:
   roofline     bound "hbm": the kernel rocprofv3 ranks first in the decode loop -- at batch <= 2 the chained down(l) -> QKV(l+1)
                launch `decode_layers_k` (profiles/r02_bench_kernel_stats.md), at batch 3-32 the gate/up SwiGLU `xstat32_k`:
@@ -51,6 +56,7 @@ def parse():
                     "not the parity configuration: its oracle is the reference math on the fake-quantised weights")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b32", action="store_true", help="skip the configs[2] (batch 32) sub-run of a batch-1 single-GPU bench")
+    ap.add_argument("--no-fp8", action="store_true", help="skip the configs[4] (fp8 weights, batch 32) sub-run of a batch-1 bench")
     ap.add_argument("--no-graph", action="store_true")
     return ap.parse_args()
 
@@ -128,11 +134,17 @@ def _pick_threads():
     return best
 
 
-def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device):
+def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device, hip=None):
     """BASELINE configs[0], for real: the CPU oracle encodes ONE 448 px image, prefills the 160-token prompt and decodes 32 greedy
     tokens through all 32 production-width layers on the host cores (the weights are the engine's: generated on the GPU tensor by
     tensor, rounded to the model dtype, copied to the host -- not part of the timed work). The metric is quoted on 256-token
-    reports: reports/s = 1 / (encode + prefill + 256 x the measured per-token time)."""
+    reports: reports/s = 1 / (encode + prefill + 256 x the measured per-token time).
+
+    `hip` = (tokens int[32], per-step logits [32, V]) the engine produced for the SAME image and prompt (rank 0, row 0 of the
+    batch-1 run, outside the timed region): the oracle is then also the CHECKER of what was just timed -- full depth, the
+    benchmarked dtype, image -> tokens end to end (the oracle decodes from its own fp32 encoder output). Rule of tests/_parity.py:
+    tokens identical while the inputs are identical; a different token only where the oracle's top-2 margin is <= 2 x the measured
+    logit error of that step."""
     from oracle import ref_cpu
     from radialog_amd import synth
     threads = _pick_threads()
@@ -155,8 +167,9 @@ def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device):
         logits, past, _ = orc.forward(orc.embed(ids, q), km, ref_cpu.positions_from_mask(km))
         t_prefill = time.time() - t0
         E = orc.W["model.embed_tokens.weight"]
-        toks, t0 = [], time.time()
+        toks, rows, t0 = [], [], time.time()
         for s in range(n_tok):
+            rows.append(logits[0, -1].float().clone())
             nxt = logits[:, -1].argmax(-1)
             toks.append(int(nxt))
             if s == n_tok - 1:
@@ -166,7 +179,7 @@ def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device):
         t_tok = (time.time() - t0) / (n_tok - 1)
     t_cfg0 = t_enc + t_prefill + (n_tok - 1) * t_tok
     t_report = t_enc + t_prefill + new_tokens * t_tok
-    return {
+    res = {
         "value": 1.0 / t_report, "unit": "reports/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
         "sample": (f"oracle/ref_cpu.py, BASELINE configs[0] run in full on {threads} torch threads (fastest of a calibration sweep; host "
                    f"has {os.cpu_count()} cpus): 1 image 448 px full-size encode {t_enc:.2f} s + prefill T={prompt_len} through all "
@@ -175,6 +188,29 @@ def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device):
                    f"wall incl. weight generation {time.time()-t_all:.0f} s"),
         "s_per_token": t_tok, "s_encode": t_enc, "s_prefill": t_prefill, "config0_s": t_cfg0, "tokens": toks[:8],
     }
+    if hip is not None:
+        res["parity"] = oracle_check(hip[0], hip[1], toks, rows)
+    return res
+
+
+def oracle_check(hip_tokens, hip_logits, ref_tokens, ref_logits):
+    """The engine's greedy tokens / logits of the benchmarked configuration against the oracle's, step by step (tests/_parity.py's rule)."""
+    n = min(len(ref_tokens), len(hip_tokens))
+    same, worst, note, ok = 0, 0.0, None, True
+    for s in range(n):
+        err = float((hip_logits[s].float().cpu() - ref_logits[s]).abs().max())
+        worst = max(worst, err)
+        if int(hip_tokens[s]) != int(ref_tokens[s]):
+            top2 = ref_logits[s].topk(2).values
+            margin = float(top2[0] - top2[1])
+            ok = margin <= 2.0 * err + 1e-7
+            note = (f"step {s}: engine token {int(hip_tokens[s])} vs oracle {int(ref_tokens[s])}, oracle top-2 margin {margin:.4g}, logit error "
+                    f"{err:.4g} -> " + ("a near-tie the rounding-order noise can flip; later steps have different inputs and are not compared"
+                                         if ok else "NOT explained by the logit error: MISMATCH"))
+            break
+        same += 1
+    return {"checked": "image -> tokens, full depth, the benchmarked dtype, rank 0 row 0 (outside the timed region)",
+            "tokens_identical": same, "tokens_compared": n, "worst_logit_err": worst, "divergence": note, "ok": ok}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -279,8 +315,52 @@ def run_steps(eng, cfg, args, B, T, N, rank, world, dist, steps, warmup, use_gra
     return elapsed, out, img, ids, box.get("q")
 
 
+def fixture_check(dtype, B, fp8, tokens_row0):
+    """The first 8 greedy tokens of row 0 of what was just timed against tests/golden/bench_tokens.json (committed; written by
+    tools/make_bench_fixture.py on an MI355X from this engine, whose batch-1 bf16 line is itself checked against the full-depth CPU
+    oracle in every default run -- cpu_baseline.parity). The kernels are deterministic (fixed reduction orders, no atomics), so any
+    difference means a kernel now computes something else."""
+    key = f"{dtype}{'+fp8w' if fp8 else ''}_b{B}_row0"
+    try:
+        with open(os.path.join(REPO, "tests", "golden", "bench_tokens.json")) as f:
+            want = json.load(f).get(key)
+    except Exception:
+        want = None
+    if want is None:
+        return {"key": key, "tokens": tokens_row0, "expected": None, "ok": True, "note": "no committed fixture for this configuration"}
+    return {"key": key, "tokens": tokens_row0, "expected": want, "ok": list(want) == list(tokens_row0)}
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher in the environment: become `torch.distributed.run` with N local ranks (one process per
+    GPU). The reference has no inference launcher to mirror (its only one is the training DDP of model/lavis/common/dist_utils.py:57-91)."""
+    import socket
+    n = args.gpus
+    vis = torch.cuda.device_count()
+    if vis < n:
+        print(f"bench.py: --gpus {n} but only {vis} GPU(s) are visible to this process (torch.cuda.device_count()); refusing to "
+              f"benchmark fewer GPUs than asked for", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs between the ranks' processes on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: no launcher in the environment, starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr)
+    sys.stdout.flush(); sys.stderr.flush()
+    os.execvpe(sys.executable, cmd, env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        sys.exit(2)
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                          # does not return
     # ONE JSON line on stdout, whatever native libraries print: RCCL writes its version banner to fd 1 at communicator bring-up. fd 1 is
     # pointed at stderr for the whole run and the result line goes to the saved descriptor.
     sys.stdout.flush()
@@ -290,6 +370,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = world > 1 or "RANK" in os.environ      # by torch.distributed.run (also at --nproc-per-node 1)
+    if world != args.gpus:
+        # a launcher started a different number of ranks than the benchmark was asked to measure: the line would carry the wrong n_gpus
+        print(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}; start it with --nproc-per-node {args.gpus} "
+              f"(or run `python bench.py --gpus {args.gpus}` alone: it starts the ranks itself)", file=sys.stderr)
+        sys.exit(2)
+    if local_rank >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
+        sys.exit(2)
     if launched:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -302,87 +390,120 @@ def main():
             dist.init_process_group("gloo")
     else:
         dist = None
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
 
     from radialog_amd.config import full_cfg
     from radialog_amd.engine import RdxEngine, synth_getter
     from radialog_amd.shard import init_comm
 
     cfg = full_cfg()
-    B, T, N = args.batch, args.prompt_len, args.new_tokens
+    T, N = args.prompt_len, args.new_tokens
     max_len = (T + N + 64 + 31) // 32 * 32
     use_graph = not args.no_graph
-    eng = RdxEngine(cfg, dtype=args.dtype, device=local_rank, max_batch=B, max_len=max_len, lora=True, weights_fp8=args.fp8)
-    eng.load_weights(synth_getter(cfg, eng.device, lora=True))
-    comm_note = None
-    if launched:
-        try:
-            init_comm(eng, rank, world)               # RCCL communicator inside librdx (rdx_comm_init)
-        except Exception as e:                        # keep the run (and say so in the JSON line): the token gather then goes over the host group
-            comm_note = f"rdx_comm_init failed ({type(e).__name__}: {e}); token ids gathered over the torch.distributed host group instead"
-            print("warning: " + comm_note, file=sys.stderr)
-        if dist is not None and world > 1:            # all ranks take the same path: any failure switches every rank to the host group
-            ok = torch.tensor([0 if comm_note else 1], dtype=torch.int32, device=eng.device if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                eng.comm_off = True
-                comm_note = comm_note or "rdx_comm_init failed on another rank; token ids gathered over the torch.distributed host group instead"
+    host_dev = lambda e: e.device if (dist is not None and dist.get_backend() == "nccl") else "cpu"      # noqa: E731
 
-    elapsed, out, img, ids, out_q = run_steps(eng, cfg, args, B, T, N, rank, world, dist, args.steps, args.warmup, use_graph)
-    per_rank_ms = [elapsed / args.steps * 1e3]
-    if dist is not None:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=eng.device if dist.get_backend() == "nccl" else "cpu")
-        allt = [torch.zeros_like(te) for _ in range(world)]
-        dist.all_gather(allt, te)
-        per_rank_ms = [float(t.item()) / args.steps * 1e3 for t in allt]
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
-    assert out.shape[0] == B * world and out.shape[1] == N
+    def timed_run(B, fp8, steps, warmup, keep_engine=False):
+        """One engine per rank (full weight replica), RCCL communicator inside librdx, `steps` timed steps between barriers, the MAX of
+        the per-rank clocks. Every rank calls this (collectives inside); rank 0 also gets the per-phase detail."""
+        eng = RdxEngine(cfg, dtype=args.dtype, device=local_rank, max_batch=B, max_len=max_len, lora=True, weights_fp8=fp8)
+        eng.load_weights(synth_getter(cfg, eng.device, lora=True))
+        comm_note = None
+        if launched:
+            try:
+                init_comm(eng, rank, world)               # RCCL communicator inside librdx (rdx_comm_init)
+            except Exception as e:                        # keep the run (and say so in the JSON line): the token gather then goes over the host group
+                comm_note = f"rdx_comm_init failed ({type(e).__name__}: {e}); token ids gathered over the torch.distributed host group instead"
+                print("warning: " + comm_note, file=sys.stderr)
+            if world > 1:                                 # all ranks take the same path: any failure switches every rank to the host group
+                ok = torch.tensor([0 if comm_note else 1], dtype=torch.int32, device=host_dev(eng))
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    eng.comm_off = True
+                    comm_note = comm_note or "rdx_comm_init failed on another rank; token ids gathered over the torch.distributed host group instead"
+        elapsed, out, img, ids, out_q = run_steps(eng, cfg, args, B, T, N, rank, world, dist, steps, warmup, use_graph)
+        per_rank_ms = [elapsed / steps * 1e3]
+        if dist is not None:
+            te = torch.tensor([elapsed], dtype=torch.float64, device=host_dev(eng))
+            allt = [torch.zeros_like(te) for _ in range(world)]
+            dist.all_gather(allt, te)
+            per_rank_ms = [float(t.item()) / steps * 1e3 for t in allt]
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            elapsed = float(te.item())
+        assert out.shape[0] == B * world and out.shape[1] == N, f"gathered token matrix {tuple(out.shape)}, expected {(B * world, N)}"
+        r = {"B": B, "fp8": fp8, "steps": steps, "warmup": warmup, "elapsed": elapsed, "per_rank_ms": per_rank_ms, "comm_world": eng.comm_world,
+             "comm_note": comm_note, "tokens_row0": [int(t) for t in out[rank * B, :8].tolist()]}
+        if rank == 0:
+            fp8_was, args.fp8 = args.fp8, fp8
+            r["enc_ms"], r["roof"] = measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed / steps * 1e3, use_graph)
+            args.fp8 = fp8_was
+            r["token_check"] = fixture_check(args.dtype, B, fp8, r["tokens_row0"])
+            if keep_engine:       # rank 0, batch 1: 32 tokens + logits of the benchmarked configuration for the oracle's check (untimed)
+                q, _ = eng.encode_image(img, want_image_embeds=False)
+                tk, sc, _ = eng.generate(ids, q, max_new=32, eos_id=-1, pad_id=0, use_graph=use_graph, output_scores=True)
+                r["hip32"] = (tk[0, :32].cpu().tolist(), sc[:32, 0].float().cpu().clone())
+        eng.close()
+        return r
+
+    def sub_line(r, workload):
+        roof = r["roof"]
+        return {"workload": workload, "value": r["steps"] * r["B"] * world / r["elapsed"], "unit": "reports/s", "n_gpus": world,
+                "per_gpu_batch": r["B"], "global_batch": r["B"] * world, "steps": r["steps"], "warmup": r["warmup"],
+                "ms_per_step": r["elapsed"] / r["steps"] * 1e3, "tokens_per_s": r["steps"] * r["B"] * world * N / r["elapsed"],
+                "per_rank_ms_per_step": r["per_rank_ms"], "rccl_ranks": r["comm_world"],
+                "encoder_ms_per_img": r["enc_ms"], "prefill_ms": roof["prefill_ms"], "decode_avg_step_ms": roof["decode_avg_step_ms"],
+                "decode_avg_frac": roof["decode_avg_frac"], "kernel": roof["kernel"], "kernel_frac": roof["frac"],
+                "kernel_us": roof["us_per_launch"], "traffic": roof["traffic"], "mfma": roof["mfma"], "token_check": r["token_check"]}
+
+    B = args.batch
+    main_r = timed_run(B, args.fp8, args.steps, args.warmup, keep_engine=(B == 1 and world == 1 and not args.no_cpu_baseline))
+    subs = {}
+    k2 = max(2, min(args.steps, 3))
+    if B == 1 and not args.fp8 and not args.no_b32:
+        # BASELINE configs[2] (one GPU) / configs[3] (8 GPUs: global batch 256, one all-gather of int32[32,256] per rank) in the same job
+        # and JSON line: batch 32 per GPU, KV cache in HBM, hipGraph-captured decode step
+        subs["b32"] = (timed_run(32, False, k2, 1), f"configs[{2 if world == 1 else 3}]: per-GPU batch 32 (global {32 * world}), same pipeline, "
+                                                    "hipGraph-captured decode step" + (", RCCL all-gather of the token ids" if world > 1 else ""))
+    if B == 1 and not args.fp8 and not args.no_fp8:
+        # BASELINE configs[4] per-GPU load: fp8 e4m3 decoder weights + per-row scale, LoRA epilogue, batch 32 per GPU
+        subs["fp8_b32"] = (timed_run(32, True, k2, 1), f"configs[4]: fp8 e4m3 decoder GEMM weights + per-row scale + un-merged LoRA epilogue, per-GPU "
+                                                       f"batch 32 (global {32 * world})")
 
     if rank == 0:
-        enc_ms, roof = measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed / args.steps * 1e3, use_graph)
+        r, roof = main_r, main_r["roof"]
         res = {
             "metric": "reports_per_sec (448px CXR encode + 160-tok prefill + 256-tok greedy decode)",
-            "value": args.steps * B * world / elapsed, "unit": "reports/s",
+            "value": args.steps * B * world / r["elapsed"], "unit": "reports/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": r["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype + ("+fp8w" if args.fp8 else ""), "data": "synthetic",
             "config": {"workload": f"configs[{1 if B == 1 else 2}]: per-GPU batch {B} BioViL-T(ResNet-50)+Q-Former encode 448px, "
                                    f"Vicuna-7B prefill T={T}, {N}-token greedy decode (LoRA r=8 un-merged, hipGraph step={use_graph}"
                                    + (", fp8 e4m3 decoder weights + per-row scale [configs[4] weight path]" if args.fp8 else "") + ")",
                        "per_gpu_batch": B, "global_batch": B * world, "prompt_len": T, "new_tokens": N,
                        "parallelism": f"dp{world}", "weights": "random-init (deterministic generator)"},
-            "encoder_ms_per_img": enc_ms,
-            "tokens_per_s": args.steps * B * world * N / elapsed,
-            "rccl_ranks": eng.comm_world, "per_rank_ms_per_step": per_rank_ms,
-            "collective": ("rdx_allgather_tokens (ncclAllGather inside librdx), int32[%d,%d] per rank per step" % (B, N)) if eng.comm_world else comm_note,
-            "roofline": roof,
+            "encoder_ms_per_img": r["enc_ms"],
+            "tokens_per_s": args.steps * B * world * N / r["elapsed"],
+            "rccl_ranks": r["comm_world"], "per_rank_ms_per_step": r["per_rank_ms"],
+            "collective": ("rdx_allgather_tokens (ncclAllGather inside librdx), int32[%d,%d] per rank per step" % (B, N)) if r["comm_world"] else r["comm_note"],
+            "roofline": roof, "token_check": r["token_check"],
         }
-        eng.close()
-        if world == 1 and B == 1 and not args.fp8 and not args.no_b32:
-            # BASELINE configs[2] in the same process and JSON line: batch 32, KV cache in HBM, hipGraph-captured decode step
-            B2 = 32
-            eng2 = RdxEngine(cfg, dtype=args.dtype, device=local_rank, max_batch=B2, max_len=max_len, lora=True)
-            eng2.load_weights(synth_getter(cfg, eng2.device, lora=True))
-            k2 = max(2, min(args.steps, 3))
-            el2, out2, img2, ids2, q2 = run_steps(eng2, cfg, args, B2, T, N, rank, 1, None, k2, 1, use_graph)
-            enc2, roof2 = measure_detail(eng2, cfg, args, B2, T, N, img2, ids2, q2, el2 / k2 * 1e3, use_graph)
-            res["b32"] = {"workload": "configs[2]: per-GPU batch 32, same pipeline, hipGraph-captured decode step", "value": k2 * B2 / el2,
-                          "unit": "reports/s", "steps": k2, "warmup": 1, "ms_per_step": el2 / k2 * 1e3, "tokens_per_s": k2 * B2 * N / el2,
-                          "encoder_ms_per_img": enc2, "prefill_ms": roof2["prefill_ms"], "decode_avg_step_ms": roof2["decode_avg_step_ms"],
-                          "decode_avg_frac": roof2["decode_avg_frac"], "kernel": roof2["kernel"], "kernel_frac": roof2["frac"],
-                          "kernel_us": roof2["us_per_launch"], "traffic": roof2["traffic"], "mfma": roof2["mfma"]}
-            eng2.close()
+        for key, (sr, wl) in subs.items():
+            res[key] = sub_line(sr, wl)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg, args.dtype, T, N, torch.device("cuda", local_rank))
+            res["cpu_baseline"] = cpu_baseline(cfg, args.dtype, T, N, torch.device("cuda", local_rank), hip=r.get("hip32"))
+        checks = [res["token_check"]] + [res[k]["token_check"] for k in subs] + [res.get("cpu_baseline", {}).get("parity", {"ok": True})]
+        res["results_verified"] = all(c.get("ok", True) for c in checks)
         sys.stdout.flush()
         os.write(out_fd, (json.dumps(res) + "\n").encode())
+        rc = 0 if res["results_verified"] else 3
     else:
-        eng.close()
+        rc = 0
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rc:
+        print("bench.py: the timed configuration's tokens do not match the committed fixture / the oracle (see token_check, cpu_baseline.parity)",
+              file=sys.stderr)
+        sys.exit(rc)
 
 
 if __name__ == "__main__":

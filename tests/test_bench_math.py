@@ -67,3 +67,49 @@ def test_committed_bench_line_is_self_consistent():
     assert 0.95 < r["traffic"] / r["bytes_per_launch"] < 1.05                                      # PMC traffic ~ algorithmic bytes: no re-reads
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
     assert d["b32"]["value"] > d["value"]
+
+
+def test_oracle_check_rule_of_the_bench_line():
+    """cpu_baseline.parity: identical tokens are counted; a flip is accepted only inside 2 x the measured logit error of that step."""
+    import torch
+    b = _bench()
+    V = 50
+    ref = [torch.zeros(V) for _ in range(4)]
+    for s, t in enumerate((7, 9, 11, 13)):
+        ref[s][t] = 1.0
+        ref[s][t + 1] = 0.5                  # oracle margin 0.5 everywhere
+    hip = torch.stack(ref) + 0.01
+    r = b.oracle_check([7, 9, 11, 13], hip, [7, 9, 11, 13], ref)
+    assert r["ok"] and r["tokens_identical"] == 4 and r["divergence"] is None and abs(r["worst_logit_err"] - 0.01) < 1e-6
+    r = b.oracle_check([7, 9, 12, 13], hip, [7, 9, 11, 13], ref)               # flip at a margin of 0.5 with a logit error of 0.01
+    assert not r["ok"] and r["tokens_identical"] == 2 and "MISMATCH" in r["divergence"]
+    near = [x.clone() for x in ref]
+    near[2][12] = 0.99                                                          # margin 0.01 <= 2 x 0.01
+    r = b.oracle_check([7, 9, 12, 13], torch.stack(near) + 0.01, [7, 9, 11, 13], near)
+    assert r["ok"] and r["tokens_identical"] == 2
+
+
+def test_fixture_check_compares_row0_tokens_with_the_committed_file():
+    b = _bench()
+    with open(os.path.join(REPO, "tests", "golden", "bench_tokens.json")) as f:
+        fx = json.load(f)
+    key = "bf16_b1_row0"
+    assert key in fx and len(fx[key]) == 8
+    assert b.fixture_check("bf16", 1, False, list(fx[key]))["ok"]
+    bad = list(fx[key]); bad[3] += 1
+    assert not b.fixture_check("bf16", 1, False, bad)["ok"]
+    assert b.fixture_check("f16", 7, False, [1] * 8)["expected"] is None       # unprofiled configuration: reported, not failed
+
+
+def test_gpus_n_without_a_launcher_fails_loudly_when_the_gpus_are_not_there():
+    """`python bench.py --gpus N` must start N ranks itself or refuse -- never benchmark one GPU and print n_gpus 1."""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        return
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and p.stdout.strip() == "" and "only" in p.stderr and "GPU" in p.stderr
+    env.update(RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")                          # a launcher with the wrong rank count
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 2 and p.stdout.strip() == "" and "WORLD_SIZE" in p.stderr
