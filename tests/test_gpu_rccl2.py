@@ -1,0 +1,88 @@
+"""rdx_comm_init / rdx_allgather_tokens with TWO ranks (two processes, each with its own librdx context and RCCL communicator rank),
+through the C ABI: the rank-major layout of the gathered token matrix, the by-value 128-byte unique id, and the engine= branch of
+radialog_amd.shard.allgather_tokens. With two or more GPUs visible the ranks take devices 0 and 1 (the real xGMI path); on a one-GPU
+box both ranks are placed on device 0 -- RCCL refuses two ranks of one communicator on the same device, which is recorded verbatim in the
+skip reason (the test still proves that both processes reach ncclCommInitRank with the same id and that the refusal surfaces as an
+RdxError on every rank instead of a hang). SURVEY.md 8(e); no reference counterpart (the reference has no inference-time collective)."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, devices, rows, n, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from radialog_amd import shard
+        from radialog_amd.config import small_cfg
+        from radialog_amd.engine import RdxEngine
+        eng = RdxEngine(small_cfg(), dtype="bf16", device=devices[rank], max_batch=2, max_len=64, vision=False)
+        try:
+            shard.init_comm(eng, rank, world)
+        except Exception as e:                       # same-device refusal (one-GPU box): report, do not hang the peer
+            q.put((rank, "init_error", f"{type(e).__name__}: {e}"))
+            eng.close()
+            return
+        assert eng.comm_world == world
+        toks = (torch.arange(rows * n, dtype=torch.int32, device=eng.device).view(rows, n) + 100000 * (rank + 1))
+        out = shard.allgather_tokens(toks, world, engine=eng)           # librdx's ncclAllGather on the engine's stream
+        out2 = eng.allgather_tokens(toks)                               # twice: the communicator is reusable
+        q.put((rank, "ok", (out.cpu().tolist(), torch.equal(out, out2))))
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_allgather_two_ranks_through_the_c_abi_is_rank_major():
+    import torch.multiprocessing as mp
+    world, rows, n = 2, 3, 5
+    ndev = torch.cuda.device_count()
+    devices = [0, 1] if ndev >= 2 else [0, 0]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, devices, rows, n, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    import queue
+    got = {}
+    try:
+        for _ in ps:
+            rank, status, payload = q.get(timeout=240)
+            got[rank] = (status, payload)
+    except queue.Empty:
+        for p in ps:                      # never leave a rank spinning in a bootstrap on the GPU box
+            if p.is_alive():
+                p.kill()
+        pytest.fail(f"a rank did not report within 240 s (communicator bring-up hung); reported so far: {got}")
+    for p in ps:
+        p.join(timeout=120)
+        if p.is_alive():
+            p.kill()
+            pytest.fail("a rank process did not exit")
+        assert p.exitcode == 0, f"rank process exit code {p.exitcode}"
+    errs = {r: v[1] for r, v in got.items() if v[0] == "init_error"}
+    if errs:
+        assert ndev < 2, f"two GPUs are visible and rdx_comm_init still failed: {errs}"
+        assert len(errs) == world, f"only some ranks failed to initialise: {got}"
+        assert all("rdx_comm_init" in e or "ncclCommInitRank" in e for e in errs.values()), errs
+        pytest.skip(f"one GPU visible: RCCL refuses two ranks of one communicator on the same device -- {errs[0]}")
+    base = torch.arange(rows * n, dtype=torch.int32).view(rows, n)
+    want = torch.cat([base + 100000, base + 200000], 0).tolist()        # rank 0's rows first, then rank 1's
+    for r in range(world):
+        status, (mat, same) = got[r]
+        assert status == "ok" and same
+        assert mat == want, f"rank {r}: gathered matrix is not rank-major"
