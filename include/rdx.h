@@ -62,6 +62,12 @@ void* rdx_stream(rdx_ctx* ctx);                    /* hipStream_t of the context
  * demo.py:224-234). `name` is an engine tensor name (radialog_amd/weights.py maps reference state_dict keys to them);
  * `data` is a device fp32 tensor, copied/converted into library-owned storage (the caller may free it afterwards). */
 int rdx_set_weight(rdx_ctx* ctx, const char* name, const float* data, int64_t rows, int64_t cols, int kind);
+/* The same from a source tensor of another element type: src_dtype RDX_SRC_F32 / RDX_SRC_F16 / RDX_SRC_BF16 (`data` is then a device
+ * tensor of that type). A real Vicuna-7B checkpoint is stored in fp16 (from_pretrained(torch_dtype=float16), demo.py:224-226): its
+ * tensors go to the library as they are instead of being inflated to fp32 on the host first. fp16 / bf16 sources are widened
+ * exactly; the result is bit-identical to rdx_set_weight on the widened tensor. */
+enum { RDX_SRC_F32 = 0, RDX_SRC_F16 = 1, RDX_SRC_BF16 = 2 };
+int rdx_set_weight_typed(rdx_ctx* ctx, const char* name, const void* data, int src_dtype, int64_t rows, int64_t cols, int kind);
 int rdx_finalize_weights(rdx_ctx* ctx);            /* resolves names, checks completeness, allocates workspaces    */
 
 /* Blip2Qformer.forward_image (blip2_qformer.py:467-484): image float32[B,3,S,S] ->
@@ -98,6 +104,9 @@ int rdx_generate(rdx_ctx* ctx, const int32_t* ids, const int32_t* mask, int batc
 int rdx_prefill(rdx_ctx* ctx, const int32_t* ids, const int32_t* mask, int batch, int T, const float* qformer_embs,
                 int max_new, int eos_id, int pad_id, int32_t* out_tokens, void* logits);
 int rdx_decode_step(rdx_ctx* ctx, void* logits);
+/* The same step on caller-supplied input ids int32[B] (device) instead of the token the previous step selected: the loop-driving
+ * caller's forward(input_ids=[B,1], past_key_values) (modeling_llama_imgemb.py:705-836) -- teacher forcing, constrained decoding. */
+int rdx_decode_step_ids(rdx_ctx* ctx, const int32_t* ids, void* logits);
 
 /* Multi-turn re-prompting (test.py:440-674, demo.py:277-305: the reference re-runs the whole conversation each turn). The
  * next turn's prompt usually starts with the previous prompt + answer; its KV rows are still in the cache. These calls keep the
@@ -147,15 +156,12 @@ int rdx_hidden_read(rdx_ctx* ctx, void* dst /*model dtype [B][hidden]: decoder o
  *   what = 0: one decode step (whole graph) at the current state, `iters` replays
  *   what = 1: the gate/up SwiGLU weight-streaming GEMV of every layer in turn, `iters` sweeps -> ms per launch
  *   what = 2: ... the QKV GEMV, 3: o_proj, 4: down_proj, 5: lm_head, 6: decode attention (re-appends the current KV row);
- *   what = 7: the chained down(l) -> QKV(l+1) launch (decode_layers_k, the batch <= 2 default), measured in situ: `iters` eager
+ *   what = 7: the chained down(l) -> QKV(l+1) launch (decode_chain_k, the batch <= 2 default), measured in situ: `iters` eager
  *             decode steps with an event pair around each of its launches (bracket = launch gap + kernel) -> ms per launch
  *   what + 10: the same unit on layer 0 only (weights stay cache resident)
  *   At batch >= 3 the RMSNorm in front of QKV / gate-up / lm_head is a launch of its own: it runs once, outside the timed region, and
  *   units 1, 2, 5 time the GEMM launches alone. */
 int rdx_time(rdx_ctx* ctx, int what, int iters, float* ms_host);
-/* debug (RDX_MEGA only): one eager decode step of the chained decode-layer kernel with per-workgroup timestamps,
- * host[wg*4 + 0..3] = {start, inputs ready, end (100 MHz ticks), role}; the caller sizes `host` for max_wgs entries */
-int rdx_mega_trace(rdx_ctx* ctx, long long* host, int max_wgs);
 /* debug: 8 timestamps (100 MHz ticks) of workgroup (0,0) of the stand-alone decode-attention kernel of `layer` */
 int rdx_attn_trace(rdx_ctx* ctx, int layer, long long* host);
 /* debug: per-workgroup timestamps of one stand-alone decode GEMV (what: 1 gate/up, 2 qkv, 4 down), host[tile*8 + 0..5]; the

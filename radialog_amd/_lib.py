@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(HERE, "librdx.so")
 
 RDX_DTYPE_F16, RDX_DTYPE_BF16 = 0, 1
 RDX_W_GEMM, RDX_W_TENSOR, RDX_W_F32, RDX_W_GEMM_FP8 = 0, 1, 2, 3
+RDX_SRC_F32, RDX_SRC_F16, RDX_SRC_BF16 = 0, 1, 2
 
 
 class RdxLibraryError(RuntimeError):
@@ -54,6 +55,7 @@ SYMBOLS = {
     "rdx_sync": (C.c_int, [_P]),
     "rdx_stream": (_P, [_P]),
     "rdx_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.c_int64, C.c_int]),
+    "rdx_set_weight_typed": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int64, C.c_int64, C.c_int]),
     "rdx_finalize_weights": (C.c_int, [_P]),
     "rdx_encode_image": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "rdx_encode_image2": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
@@ -62,6 +64,7 @@ SYMBOLS = {
                                C.POINTER(C.c_int), C.c_int]),
     "rdx_prefill": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rdx_decode_step": (C.c_int, [_P, _P]),
+    "rdx_decode_step_ids": (C.c_int, [_P, _P, _P]),
     "rdx_prefill_append": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "rdx_generate_append": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,
                                       C.POINTER(C.c_int), C.c_int]),
@@ -74,7 +77,6 @@ SYMBOLS = {
     "rdx_kv_read": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "rdx_hidden_read": (C.c_int, [_P, _P]),
     "rdx_time": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
-    "rdx_mega_trace": (C.c_int, [_P, _P, C.c_int]),
     "rdx_attn_trace": (C.c_int, [_P, C.c_int, _P]),
     "rdx_gemv_trace": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int]),
     "rdx_gemm_test": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_int]),

@@ -1,0 +1,411 @@
+// librdx C ABI, part 5: introspection, timing and kernel-test hooks (tests / bench.py / tools).
+#include "rdx_ctx.h"
+
+// Debug: the stand-alone decode-attention kernel of layer `layer` at the current state, 8 timestamps of workgroup (0,0):
+// host[0..6] = after slot load, inputs ready, new token done, barrier 1, scores + barrier, softmax, PV + barrier; [7] = entry.
+extern "C" int rdx_attn_trace(rdx_ctx* c, int layer, long long* host) {
+    if (!c || !c->finalized || c->cur_B <= 0 || !host) return fail(c, -1, "rdx_attn_trace: run a prefill first");
+    HIPCHK(c, hipSetDevice(c->device));
+    long long* dtr = nullptr;
+    HIPCHK(c, hipMalloc(&dtr, 8 * sizeof(long long)));
+    HIPCHK(c, hipMemsetAsync(dtr, 0, 8 * sizeof(long long), c->stream));
+    const LlamaLayer& L = c->ll[layer];
+    DecAttnArgs at;
+    at.d = c->ld; at.qkv = c->dqkv; at.lbq = L.lora_bq; at.lbv = L.lora_bv; at.cos_t = c->rope_cos; at.sin_t = c->rope_sin;
+    at.pos = c->d_pos; at.slot_b = c->d_slot; at.key_mask = c->key_mask; at.cur_rope = c->d_cur_rope;
+    at.kcache = kv_ptr(c, c->kcache, layer); at.vcache = kv_ptr(c, c->vcache, layer); at.out = c->datt;
+    at.trace = dtr;
+    launch_decode_attention(c->cfg.dtype, at, c->cur_B, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(host, dtr, 8 * sizeof(long long), hipMemcpyDeviceToHost);
+    hipFree(dtr);
+    HIPCHK(c, e);
+    return 0;
+}
+
+// Debug: one stand-alone decode GEMV (what = 1 gate/up, 2 qkv, 4 down, as in rdx_time) of `layer` with per-workgroup
+// timestamps: host[tile*8 + {0 entry, 1 weights issued, 2 activations staged, 3 K loop done, 4 all waves done, 5 end}].
+extern "C" int rdx_gemv_trace(rdx_ctx* c, int what, int layer, long long* host, int max_tiles) {
+    if (!c || !c->finalized || c->cur_B <= 0 || !host) return fail(c, -1, "rdx_gemv_trace: run a prefill first");
+    HIPCHK(c, hipSetDevice(c->device));
+    const rdx_config& f = c->cfg;
+    const int H = f.hidden, B = c->cur_B;
+    const LlamaLayer& L = c->ll[layer];
+    long long* dtr = nullptr;
+    const size_t bytes = (size_t)max_tiles * 8 * sizeof(long long);
+    HIPCHK(c, hipMalloc(&dtr, bytes));
+    HIPCHK(c, hipMemsetAsync(dtr, 0, bytes, c->stream));
+    GemmArgs a;
+    if (what == 1) { a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; }
+    else if (what == 2) { a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps; }
+    else { a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); }
+    if ((a.N + 15) / 16 > max_tiles) { hipFree(dtr); return fail(c, -1, "rdx_gemv_trace: need room for %d tiles", (a.N + 15) / 16); }
+    a.trace = dtr;
+    skinny(c, a, what == 1 ? EPI_SILU_MUL : EPI_NONE);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = hipMemcpy(host, dtr, bytes, hipMemcpyDeviceToHost);
+    hipFree(dtr);
+    HIPCHK(c, e);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// introspection
+// ------------------------------------------------------------------------------------------------------------------
+extern "C" int rdx_kv_read(rdx_ctx* c, int layer, int which, void* dst) {
+    if (!c || !c->finalized || !c->cfg.enable_llama) return fail(c, -1, "rdx_kv_read: no llama state");
+    if (layer < 0 || layer >= c->cfg.layers || !dst) return fail(c, -1, "rdx_kv_read: bad arguments");
+    if (which) HIPCHK(c, hipMemcpyAsync(dst, kv_ptr(c, c->vcache, layer), c->kv_layer_elems * 2, hipMemcpyDeviceToDevice, c->stream));
+    else launch_k_unperm(kv_ptr(c, c->kcache, layer), dst, c->kv_layer_elems / ((size_t)c->cfg.max_len * 128), c->cfg.max_len, c->ld.k_perm, c->stream);   // K: back from the fragment order
+    return 0;
+}
+
+extern "C" int rdx_hidden_read(rdx_ctx* c, void* dst) {
+    if (!c || !c->finalized || !c->cfg.enable_llama || c->cur_B <= 0) return fail(c, -1, "rdx_hidden_read: no llama state");
+    HIPCHK(c, hipMemcpyAsync(dst, c->datt, (size_t)c->cur_B * c->cfg.hidden * 2, hipMemcpyDeviceToDevice, c->stream));
+    return 0;
+}
+
+extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
+    if (!c || !c->finalized || !c->cfg.enable_llama || c->cur_B <= 0) return fail(c, -1, "rdx_time: run a prefill first");
+    if (!ms_host || iters <= 0) return fail(c, -1, "rdx_time: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const rdx_config& f = c->cfg;
+    const int dt = f.dtype, H = f.hidden, B = c->cur_B;
+    const bool same_layer = what >= 10;   // what = 10 + k: unit k on layer 0 only (weights stay cache resident)
+    if (same_layer) what -= 10;
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0));
+    HIPCHK(c, hipEventCreate(&e1));
+    int launches = 0;
+    if (what == 7) {
+        // the chained down(l) -> QKV(l+1) launch (decode_layers_k, batch <= 2), IN SITU: `iters` eager decode steps with an event pair
+        // around each of its launches (the hand-off counters are only valid inside a real step, so it cannot be looped alone)
+        std::vector<int> slot(B);
+        HIPCHK(c, hipMemcpyAsync(slot.data(), c->d_slot, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (slot[0] + iters >= f.max_len) return fail(c, -1, "rdx_time: %d steps would overflow the KV cache (slot %d, max_len %d)", iters, slot[0], f.max_len);
+        std::vector<hipEvent_t> evs, nul;
+        bool chained = true;
+        for (int i = 0; i < iters && chained; ++i) {
+            chained = decode_step_launch(c, nullptr, nullptr, 0, &evs);
+            // calibration: an EMPTY bracket (two event records back to back) costs stream time of its own; it is measured in the same
+            // stream, once per step, and subtracted from every bracket below
+            hipEvent_t a0, a1; hipEventCreate(&a0); hipEventCreate(&a1);
+            hipEventRecord(a0, c->stream); hipEventRecord(a1, c->stream);
+            nul.push_back(a0); nul.push_back(a1);
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->cur_steps = std::max(c->cur_steps, c->cur_max_new);
+        double tot = 0.0, empty = 0.0;
+        for (size_t i = 0; i + 1 < evs.size(); i += 2) { float m = 0.f; hipEventElapsedTime(&m, evs[i], evs[i + 1]); tot += m; }
+        for (size_t i = 0; i + 1 < nul.size(); i += 2) { float m = 0.f; hipEventElapsedTime(&m, nul[i], nul[i + 1]); empty += m; }
+        const size_t n = evs.size() / 2;
+        // (the empty bracket costs MORE than what an event adds around a kernel -- subtracting it put the result 6 % under rocprof's
+        // kernel duration -- so it is measured but NOT subtracted: the bracket = launch gap + kernel, 7 % over rocprof, conservative)
+        (void)empty;
+        for (hipEvent_t e : evs) hipEventDestroy(e);
+        for (hipEvent_t e : nul) hipEventDestroy(e);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        if (!chained || n == 0) return fail(c, -1, "rdx_time(7): the chained down -> QKV launch is not active in this configuration (batch > 2, RDX_CHAIN != 2)");
+        *ms_host = (float)(tot / (double)n);
+        return 0;
+    }
+    if (what == 0) {
+        int rc = build_graph(c, nullptr);
+        if (rc) return rc;
+        // state advances with every replay: keep the KV slot inside the cache
+        std::vector<int> slot(B);
+        HIPCHK(c, hipMemcpyAsync(slot.data(), c->d_slot, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (slot[0] + iters >= f.max_len) return fail(c, -1, "rdx_time: %d replays would overflow the KV cache (slot %d, max_len %d)", iters, slot[0], f.max_len);
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        for (int i = 0; i < iters; ++i) HIPCHK(c, hipGraphLaunch(c->graph, c->stream));
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+        launches = iters;
+        c->cur_steps = std::max(c->cur_steps, c->cur_max_new);
+    } else {
+        // projections whose RMSNorm is a launch of its own (rows beyond the GEMV's LDS stage: batch > 4): normalise once,
+        // outside the timed region, and time the GEMM launches alone
+        int xpk = -1;
+        auto pre = [&](GemmArgs a, int epi) {
+            if (xpk < 0) { const GemmArgs p = skinny_prenorm(c, a, epi); xpk = p.norm_w ? 0 : (p.X == c->dxn ? 1 + p.xpacked : 0); }
+            if (xpk > 0) { a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr; a.xpacked = xpk - 1; }
+            return a;
+        };
+        if (what == 1) { GemmArgs a = gargs(c->dx, H, c->ll[0].wgu, nullptr, c->dgu, f.inter, B); a.norm_w = c->ll[0].mlp_norm; a.eps = f.rms_eps; pre(a, EPI_SILU_MUL); }
+        if (what == 2) { GemmArgs a = gargs(c->dx, H, c->ll[0].wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = c->ll[0].wqkv.Npad; a.norm_w = c->ll[0].attn_norm; a.eps = f.rms_eps; pre(a, EPI_NONE); }
+        if (what == 5) { GemmArgs a = gargs(c->dx, H, c->lm_head, nullptr, nullptr, f.vocab, B); a.N = c->lm_head.Npad; a.n_valid = f.vocab; a.norm_w = c->final_norm; a.eps = f.rms_eps; pre(a, EPI_LOGITS); }
+        HIPCHK(c, hipEventRecord(e0, c->stream));
+        for (int i = 0; i < iters; ++i) {
+            if (what == 5) {
+                GemmArgs a = gargs(c->dx, H, c->lm_head, nullptr, nullptr, f.vocab, B);
+                a.N = c->lm_head.Npad; a.n_valid = f.vocab; a.norm_w = c->final_norm; a.eps = f.rms_eps;
+                a.part_val = c->part_val; a.part_idx = c->part_idx;
+                launch_skinny_gemm(f.dtype, pre(a, EPI_LOGITS), EPI_LOGITS, c->stream);
+                ++launches;
+                continue;
+            }
+            for (int l = 0; l < f.layers; ++l) {
+                const LlamaLayer& L = c->ll[same_layer ? 0 : l];
+                if (what == 1) { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; launch_skinny_gemm(f.dtype, pre(a, EPI_SILU_MUL), EPI_SILU_MUL, c->stream); }
+                else if (what == 2) { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps; launch_skinny_gemm(f.dtype, pre(a, EPI_NONE), EPI_NONE, c->stream); }
+                else if (what == 3) {
+                    GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dqkv, H, B);
+                    GemmArgs ap = a; ap.xpacked = (a.W8 && a.wscale) ? 2 : 1;
+                    if (B >= xs_min_rows() && c->kslab && xsplit32_groups(ap)) launch_xsplit32(f.dtype, ap, c->kslab, c->stream);
+                    else skinny(c, a, EPI_NONE);
+                }
+                else if (what == 4) {
+                    if (down_split_ok(c, L, B)) { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); a.xpacked = (a.W8 && a.wscale) ? 2 : 1; launch_xsplit32(f.dtype, a, c->kslab, c->stream); }
+                    else { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dqkv, H, B); skinny(c, a, EPI_NONE); }
+                }
+                else if (what == 6) {   // decode attention at the current slot (re-appends the same KV row: idempotent)
+                    DecAttnArgs at;
+                    at.d = c->ld; at.qkv = c->dqkv; at.lbq = L.lora_bq; at.lbv = L.lora_bv; at.cos_t = c->rope_cos; at.sin_t = c->rope_sin;
+                    at.pos = c->d_pos; at.slot_b = c->d_slot; at.key_mask = c->key_mask; at.cur_rope = c->d_cur_rope;
+                    at.kcache = kv_ptr(c, c->kcache, same_layer ? 0 : l); at.vcache = kv_ptr(c, c->vcache, same_layer ? 0 : l); at.out = c->datt;
+                    launch_decode_attention(dt, at, B, c->stream);
+                }
+                else return fail(c, -1, "rdx_time: unknown unit %d", what);
+                ++launches;
+            }
+        }
+        HIPCHK(c, hipEventRecord(e1, c->stream));
+    }
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms_host = ms / (float)launches;
+    return 0;
+}
+
+
+// Kernel benchmark hook: `iters` launches of one GEMM (ksize = 0: out[M][N] = epi(X[M][K] W^T), M = rows) or one NHWC convolution
+// (ksize = 1 / 3: batch `rows` images of H x H x K channels -> N channels, `stride`, pad = ksize / 2) through the SAME dispatch
+// the encoder / prefill use (run_gemm / conv_gemm), timed with HIP events on the context's stream. Contents are zeros; epi 3 / 6
+// read a residual. Returns ms per launch.
+extern "C" int rdx_kernel_bench(rdx_ctx* c, int rows, int N, int K, int H, int ksize, int stride, int epi, int iters, float* ms_host,
+                                long long* trace_host, int trace_wgs) {
+    if (!c || !ms_host || iters <= 0 || rows <= 0) return fail(c, -1, "rdx_kernel_bench: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int Kg = ksize ? ksize * ksize * K : K;
+    if (Kg % 32 || N % 16) return fail(c, -1, "rdx_kernel_bench: need K %% 32 == 0 and N %% 16 == 0");
+    const int Ho = ksize ? (H + 2 * (ksize / 2) - ksize) / stride + 1 : 0;
+    const size_t M = ksize ? (size_t)rows * Ho * Ho : (size_t)rows, Min = ksize ? (size_t)rows * H * H : (size_t)rows;
+    char* buf = nullptr;
+    const bool kb_wstat = getenv("RDX_KB_WSTAT") && atoi(getenv("RDX_KB_WSTAT")) && !ksize;
+    const size_t xb = ((Min + 15) & ~(size_t)15) * K * 2 + 64, wb = (size_t)N * Kg * 2, ob = M * N * 2 + 64, bb = (size_t)N * 4;
+    HIPCHK(c, hipMalloc((void**)&buf, xb + wb + 2 * ob + bb));
+    HIPCHK(c, hipMemsetAsync(buf, 0, xb + wb + 2 * ob + bb, c->stream));
+    GemmW w; w.N = N; w.K = Kg; w.Npad = N; w.w = buf + xb;
+    void *out = buf + xb + wb, *res = buf + xb + wb + ob;
+    const float* bias = (const float*)(buf + xb + wb + 2 * ob);
+    const bool need_res = epi == EPI_RESID || epi == EPI_RESID_RELU;
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    struct WsScope { rdx_ctx* c; ~WsScope() { c->ws_ok = false; } } ws_scope{c};
+    c->ws_ok = true;
+    long long* dtr = nullptr;
+    if (trace_host && trace_wgs > 0) { HIPCHK(c, hipMalloc((void**)&dtr, (size_t)trace_wgs * 8 * sizeof(long long))); HIPCHK(c, hipMemset(dtr, 0, (size_t)trace_wgs * 64)); }
+    auto once = [&]() {
+        if (ksize) conv_gemm(c, buf, w, bias, need_res ? res : nullptr, out, rows, H, H, K, ksize, ksize, stride, ksize / 2, Ho, Ho, epi);
+        else {
+            GemmArgs a = gargs(buf, K, w, bias, out, N, (int)M); a.resid = need_res ? res : nullptr; a.ldr = N; a.trace = dtr;
+            if (kb_wstat) {       // RDX_KB_WSTAT=1: the single prompt's weight-stationary kernel on (zero) fragment-packed activations
+                a.xpacked = 3; a.mtiles = (int)((M + 15) / 16); a.bias = nullptr;
+                if (wstat_supported(a, epi)) { launch_wstat(c->cfg.dtype, a, epi, c->stream); return; }
+            }
+            run_gemm(c, a, epi);
+        }
+    };
+    once();
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; ++i) once();
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (dtr) { hipMemcpy(trace_host, dtr, (size_t)trace_wgs * 64, hipMemcpyDeviceToHost); hipFree(dtr); }
+    hipFree(buf);
+    HIPCHK(c, hipGetLastError());
+    *ms_host = ms / (float)iters;
+    return 0;
+}
+
+// Microbenchmark: GB/s that `wgs` workgroups (256 threads) pull from a cache-resident buffer, `bytes_per_wg` each (shared = 1: all
+// read the same region), read `reps` times; mode 0 = global_load_dwordx4, 1 = global_load_lds_dwordx4. Returns the aggregate GB/s.
+extern "C" int rdx_l2_bench(rdx_ctx* c, int mode, long long bytes_per_wg, int shared, int reps, int wgs, float* gbps_host) {
+    if (!c || !gbps_host || bytes_per_wg < 65536 || wgs <= 0 || reps <= 0) return fail(c, -1, "rdx_l2_bench: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    char* buf = nullptr;
+    const size_t total = shared ? (size_t)bytes_per_wg : (size_t)bytes_per_wg * wgs;
+    HIPCHK(c, hipMalloc((void**)&buf, total + 64));
+    HIPCHK(c, hipMemsetAsync(buf, 1, total + 64, c->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    launch_l2_bench(mode, buf, (size_t)bytes_per_wg, shared, 1, wgs, (unsigned*)(buf + total), c->stream);        // warm the caches
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    launch_l2_bench(mode, buf, (size_t)bytes_per_wg, shared, reps, wgs, (unsigned*)(buf + total), c->stream);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(buf);
+    HIPCHK(c, hipGetLastError());
+    *gbps_host = (float)((double)bytes_per_wg * wgs * reps / (ms * 1e-3) / 1e9);
+    return 0;
+}
+
+// One bare GEMM through the production kernels (unit tests / kernel benchmarks): out = epilogue(X . W^T).
+// X, resid, norm_w, out are model-dtype device tensors; W [N][K] and bias [N] are fp32 device tensors (W is packed here).
+extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const float* bias, const void* resid, void* out,
+                             int M, int N, int K, int epi, const void* norm_w, float eps, int force) {
+    if (!c || !X || !W || !out) return fail(c, -1, "rdx_gemm_test: null argument");
+    if (K % 32 || N % 16) return fail(c, -1, "rdx_gemm_test: need K %% 32 == 0 and N %% 16 == 0");
+    HIPCHK(c, hipSetDevice(c->device));
+    GemmW w;
+    w.N = N; w.K = K; w.Npad = N;
+    void* wp = nullptr;
+    HIPCHK(c, hipMalloc(&wp, (size_t)N * K * 2 + (force == 4 ? (size_t)N * K + (size_t)N * 4 : 0)));
+    w.w = wp;
+    if (force == 4) {                     // fp8 weights: quantise here, stream the e4m3 bytes
+        if (K % 64) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: fp8 needs K %% 64 == 0"); }
+        w.w8 = (char*)wp + (size_t)N * K * 2;
+        w.scale = (float*)((char*)wp + (size_t)N * K * 3);
+        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, wp, N, K, N, c->stream);
+        force = 1;
+    } else
+    launch_pack_weight(c->cfg.dtype, W, wp, N, K, N, nullptr, c->stream);
+    GemmArgs a = gargs(X, K, w, bias, out, epi == EPI_SILU_MUL ? N / 2 : N, M);
+    a.resid = resid; a.ldr = N;
+    a.norm_w = norm_w; a.eps = eps;
+    void* xn = nullptr;
+    bool split8 = false;
+    if (force == 6) {       // force 5 with fp8 weights
+        if (K % 64) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: fp8 needs K %% 64 == 0"); }
+        hipFree(wp);
+        HIPCHK(c, hipMalloc(&wp, (size_t)N * K * 3 + (size_t)N * 4));
+        w.w = wp; w.w8 = (char*)wp + (size_t)N * K * 2; w.scale = (float*)((char*)wp + (size_t)N * K * 3);
+        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, wp, N, K, N, c->stream);
+        a = gargs(X, K, w, bias, out, N, M);
+        a.resid = resid; a.ldr = N; a.eps = eps;
+        split8 = true; force = 5;
+    }
+    if (force == 5) {       // K-split slab path: pack X -> xsplit32_k -> slab combine (+ residual) at the launch boundary; out = resid + T(X W^T)
+        if (epi != EPI_RESID || !resid || M <= 16 || M > 32) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: force 5 needs epi 3 and 16 < M <= 32"); }
+        char* tmp = nullptr;
+        const size_t xb = (size_t)32 * K * 2, sb = (size_t)4 * 32 * N * 4;
+        HIPCHK(c, hipMalloc((void**)&tmp, 2 * xb + sb));
+        launch_rmsnorm_packed32(c->cfg.dtype, const_cast<void*>(X), nullptr, tmp, M, K, eps, split8 ? 2 : 1, nullptr, 0, c->stream);   // w = null: re-layout only
+        a.X = tmp; a.xpacked = split8 ? 2 : 1; a.norm_w = nullptr;
+        const int kg = xsplit32_groups(a);
+        if (!kg) { hipFree(wp); hipFree(tmp); return fail(c, -1, "rdx_gemm_test: shape not supported by xsplit32_k"); }
+        launch_xsplit32(c->cfg.dtype, a, (float*)(tmp + 2 * xb), c->stream);
+        HIPCHK(c, hipMemcpyAsync(out, resid, (size_t)M * N * 2, hipMemcpyDeviceToDevice, c->stream));
+        launch_rmsnorm_packed32(c->cfg.dtype, out, nullptr, tmp + xb, M, N, eps, 0, (const float*)(tmp + 2 * xb), kg, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        hipFree(wp); hipFree(tmp);
+        return 0;
+    }
+    if (force == 8) {         // the single prompt's weight-stationary kernel (wstat.hip): RMSNorm / re-layout into the fragment-packed order, then the GEMM
+        const int mtl = (M + 15) / 16;
+        char* tmp = nullptr;
+        HIPCHK(c, hipMalloc((void**)&tmp, (size_t)mtl * 16 * K * 2));
+        launch_rmsnorm_packed(c->cfg.dtype, X, norm_w, tmp, M, mtl, K, eps, c->stream);        // norm_w == null: re-layout only
+        a.X = tmp; a.xpacked = 3; a.mtiles = mtl; a.norm_w = nullptr;
+        if (!wstat_supported(a, epi)) { hipFree(wp); hipFree(tmp); return fail(c, -1, "rdx_gemm_test: shape not supported by wstat_k"); }
+        launch_wstat(c->cfg.dtype, a, epi, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        hipFree(wp); hipFree(tmp);
+        return 0;
+    }
+    if (force == 7) {         // the encoder's many-row kernel (wsgemm.hip), tile shape via RDX_WS_CFG
+        ConvGeom cg0;
+        memset(&cg0, 0, sizeof(cg0));
+        a.norm_w = nullptr;
+        if (!c->zero16 || a.K % 64 || a.N % 16) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: shape not supported by wsgemm_k"); }
+        launch_wsgemm(c->cfg.dtype, a, cg0, epi, c->zero16, c->stream);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipGetLastError());
+        hipFree(wp);
+        return 0;
+    }
+    const bool use_skinny = force == 1 || (force == 0 && M <= 32);
+    if (use_skinny) {
+        if (M > 32) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: skinny path needs M <= 32"); }
+        void* keep = c->dxn;                       // skinny() pre-normalises into c->dxn when the rows do not fit the LDS
+        if (a.norm_w && !skinny_fits_lds(M, K)) {
+            HIPCHK(c, hipMalloc(&xn, (size_t)32 * K * 2));
+            c->dxn = xn;
+        }
+        skinny(c, a, epi == EPI_RESID_RELU ? EPI_RESID : epi);
+        c->dxn = keep;
+    } else {
+        if (a.norm_w) {
+            HIPCHK(c, hipMalloc(&xn, (size_t)M * K * 2));
+            launch_rmsnorm(c->cfg.dtype, X, norm_w, xn, M, K, eps, c->stream);
+            a.X = xn; a.norm_w = nullptr;
+        }
+        ConvGeom cg;
+        memset(&cg, 0, sizeof(cg));
+        if (force == 3 || (force == 0 && c->use_dma_gemm && gemm_dma_supported(a))) {
+            if (!gemm_dma_supported(a)) { hipFree(wp); if (xn) hipFree(xn); return fail(c, -1, "rdx_gemm_test: shape not supported by gemm_dma_k"); }
+            launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
+        } else {
+            launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
+        }
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    hipFree(wp);
+    if (xn) hipFree(xn);
+    return 0;
+}
+
+// the lm_head epilogue (logits + per-tile argmax partials) of the weight-streaming kernels on a bare GEMM: what the decode
+// step runs before greedy_step_k; the partials are reduced here on the host with the same tie rule (lowest index)
+extern "C" int rdx_logits_test(rdx_ctx* c, const void* X, const float* W, int M, int N, int n_valid, int K, void* out_logits,
+                               int32_t* argmax_host, int fp8) {
+    if (!c || !X || !W || !out_logits || !argmax_host) return fail(c, -1, "rdx_logits_test: null argument");
+    if (K % 32 || N % 16 || M > 32 || n_valid > N || (fp8 && K % 64)) return fail(c, -1, "rdx_logits_test: bad shape");
+    HIPCHK(c, hipSetDevice(c->device));
+    GemmW w;
+    w.N = N; w.K = K; w.Npad = N;
+    const int nt = N / 16;
+    char* wp = nullptr;
+    const size_t wb = (size_t)N * K * 2, qb = fp8 ? (size_t)N * K + (size_t)N * 4 : 0, pb = (size_t)M * nt * 4;
+    HIPCHK(c, hipMalloc((void**)&wp, wb + qb + 2 * pb + (size_t)M * K * 2));
+    w.w = wp;
+    if (fp8) {
+        w.w8 = wp + wb; w.scale = (float*)(wp + wb + (size_t)N * K);
+        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, wp, N, K, N, c->stream);
+    } else {
+        launch_pack_weight(c->cfg.dtype, W, wp, N, K, N, nullptr, c->stream);
+    }
+    GemmArgs a = gargs(X, K, w, nullptr, out_logits, N, M);
+    a.n_valid = n_valid;
+    a.part_val = (float*)(wp + wb + qb); a.part_idx = (int*)(wp + wb + qb + pb);
+    launch_skinny_gemm(c->cfg.dtype, a, EPI_LOGITS, c->stream);
+    std::vector<float> pv((size_t)M * nt);
+    std::vector<int> pi((size_t)M * nt);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpy(pv.data(), a.part_val, pb, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(pi.data(), a.part_idx, pb, hipMemcpyDeviceToHost));
+    hipFree(wp);
+    for (int m = 0; m < M; ++m) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int t = 0; t < nt; ++t) {
+            const float v = pv[(size_t)m * nt + t]; const int ix = pi[(size_t)m * nt + t];
+            if (v > bv || (v == bv && ix < bi)) { bv = v; bi = ix; }
+        }
+        argmax_host[m] = bi;
+    }
+    return 0;
+}

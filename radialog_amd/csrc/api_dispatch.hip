@@ -1,0 +1,112 @@
+// Host-side GEMM dispatch shared by the encoder and the decoder: which kernel family a shape goes to.
+#include "rdx_ctx.h"
+
+GemmArgs gargs(const void* X, int ldx, const GemmW& W, const float* bias, void* out, int ldo, int M) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.X = X; a.ldx = ldx; a.W = W.w; a.bias = bias; a.out = out; a.ldo = ldo;
+    a.M = M; a.N = W.N; a.K = W.K; a.n_valid = W.N;
+    a.W8 = W.w8; a.wscale = W.scale;
+    return a;
+}
+
+// Skinny GEMM with an optional fused RMSNorm: fused when the activations fit the kernel's LDS staging path, otherwise
+// the rows are normalised once by rmsnorm_k into a scratch buffer (batch-32 decode).
+// The RMSNorm of a projection whose rows do not fit the GEMV's LDS stage runs as its own launch in front of it; returns the
+// arguments of the GEMM proper (activations = c->dxn)
+GemmArgs skinny_prenorm(rdx_ctx* c, GemmArgs a, int epi) {
+    // (batch 3-4 rows would fit the GEMV's LDS stage with the norm fused, but the activation-stationary kernel behind a
+    // stand-alone RMSNorm is faster there too: gate/up 41.7 -> 31 + 5 us at batch 4)
+    bool standalone = a.norm_w && !skinny_fits_lds(a.M, a.K);
+    if (a.norm_w && !standalone && a.M >= xs_min_rows() && c->kslab) {
+        GemmArgs t = a;
+        t.X = c->dxn; t.ldx = a.K; t.norm_w = nullptr;
+        standalone = xstat32_supported(t, epi);
+    }
+    if (standalone) {
+        const void* x = a.X; const void* nw = a.norm_w;
+        a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr;
+        // a K-split projection before this one left its residual epilogue to this RMSNorm (xsplit32_k): x += T(sum of slabs)
+        const int pend = (x == c->dx) ? c->pend_groups : 0;
+        if (pend) c->pend_groups = 0;
+        if (xstat32_supported(a, epi)) {       // the normalised rows go straight into the consumer's register-fragment order
+            a.xpacked = (a.W8 && a.wscale) ? 2 : 1;
+            launch_rmsnorm_packed32(c->cfg.dtype, const_cast<void*>(x), nw, c->dxn, a.M, a.K, a.eps, a.xpacked, pend ? c->kslab : nullptr, pend, c->stream);
+        } else if (pend) {
+            launch_rmsnorm_packed32(c->cfg.dtype, const_cast<void*>(x), nw, c->dxn, a.M, a.K, a.eps, 0, c->kslab, pend, c->stream);
+        } else {
+            launch_rmsnorm(c->cfg.dtype, x, nw, c->dxn, a.M, a.K, a.eps, c->stream);
+        }
+    }
+    return a;
+}
+
+void skinny(rdx_ctx* c, GemmArgs a, int epi) {
+    launch_skinny_gemm(c->cfg.dtype, skinny_prenorm(c, a, epi), epi, c->stream);
+}
+
+// batch 3-32 decode: gate/up (xstat32_k) can hand its SwiGLU output to down_proj fragment-packed, and down_proj then runs
+// K-split over 4 workgroups per tile (xsplit32_k), its residual epilogue deferred to the next RMSNorm
+bool down_split_ok(rdx_ctx* c, const LlamaLayer& L, int B) {
+    if (B < xs_min_rows() || !c->kslab) return false;
+    GemmArgs gu = gargs(c->dxn, c->cfg.hidden, L.wgu, nullptr, c->dgu, c->cfg.inter, B);
+    if (!xstat32_supported(gu, EPI_SILU_MUL)) return false;
+    GemmArgs dn = gargs(c->dgu, c->cfg.inter, L.wdown, nullptr, c->dx, c->cfg.hidden, B);
+    dn.xpacked = (dn.W8 && dn.wscale) ? 2 : 1;       // fp8 weights: the 64-deep fragment order
+    return xsplit32_groups(dn) > 0;
+}
+
+// A K-split projection (o_proj, down_proj at batch 3-32): its fp32 slabs stay pending for the stand-alone RMSNorm of the
+// projection that follows (skinny_prenorm), which adds them, rounds and applies the residual.
+void launch_ksplit(rdx_ctx* c, const GemmArgs& a) {
+    launch_xsplit32(c->cfg.dtype, a, c->kslab, c->stream);
+    c->pend_groups = xsplit32_groups(a);
+}
+
+void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split) {
+    const rdx_config& f = c->cfg;
+    GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, f.hidden, B);
+    a.resid = c->dx; a.ldr = f.hidden;
+    if (split) {
+        a.xpacked = (a.W8 && a.wscale) ? 2 : 1;
+        launch_ksplit(c, a);
+    } else {
+        skinny(c, a, EPI_RESID);
+    }
+}
+
+void run_gemm(rdx_ctx* c, GemmArgs a, int epi) {
+    ConvGeom cg;
+    memset(&cg, 0, sizeof(cg));
+    if (a.M <= 32) skinny(c, a, epi == EPI_RESID_RELU ? EPI_RESID : epi);
+    else if ((c->ws_ok || (a.M > 128 && a.M <= 256 && a.N >= 2048)) && c->zero16 && wsgemm_supported(a, cg, epi))
+        launch_wsgemm(c->cfg.dtype, a, cg, epi, c->zero16, c->stream);       // the encoder's GEMMs; a single prompt's prefill GEMMs
+    else if (c->use_dma_gemm && gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
+    else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
+}
+
+// side of the trunk's output grid: conv1 /2, maxpool /2, then three stride-2 stages of (g - 1) / 2 + 1 (3x3 pad 1 and the
+// 1x1 downsample agree): 448 -> 14, 488 -> 16
+int v_grid(const rdx_config& f) {
+    int g = f.v_img / 4;
+    for (int i = 0; i < 3; ++i) g = (g - 1) / 2 + 1;
+    return g;
+}
+
+void conv_gemm(rdx_ctx* c, const void* X, const GemmW& W, const float* bias, const void* resid, void* out, int B,
+                      int Hin, int Win, int Cin, int KH, int KW, int stride, int pad, int Hout, int Wout, int epi) {
+    GemmArgs a = gargs(X, Cin, W, bias, out, W.N, B * Hout * Wout);
+    a.resid = resid; a.ldr = W.N;
+    ConvGeom cg;
+    cg.mode = 1; cg.Hin = Hin; cg.Win = Win; cg.Cin = Cin; cg.Hout = Hout; cg.Wout = Wout;
+    cg.KH = KH; cg.KW = KW; cg.stride = stride; cg.pad = pad;
+    if (KH == 1 && KW == 1 && stride == 1 && pad == 0) cg.mode = 0;
+    // memory-bound 1x1 convolutions (K <= 256, tens of thousands of rows): weight-stationary streaming kernel
+    if (conv1x1_stream_supported(a, cg, epi)) { launch_conv1x1_stream(c->cfg.dtype, a, cg, epi, c->stream); return; }
+    if (c->ws_ok && c->zero16 && wsgemm_supported(a, cg, epi)) { launch_wsgemm(c->cfg.dtype, a, cg, epi, c->zero16, c->stream); return; }
+    // 1x1 stride-1 convolutions are plain GEMMs; everything else needs the gather path of the tiled kernel
+    if (cg.mode == 0 && c->use_dma_gemm && gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
+    else if (c->use_dma_gemm && c->zero16 && !resid && gemm_dma_conv_supported(a, cg, epi)) launch_gemm_dma_conv(c->cfg.dtype, a, cg, epi, c->zero16, c->gemm_ws, c->gemm_ws_floats, c->stream);
+    else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
+}
+

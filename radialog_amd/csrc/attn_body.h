@@ -1,6 +1,6 @@
 // Body of decode attention (one new token per batch row) as a device function: runs as its own kernel
 // (attn.hip: decode_attention_k, 16 or 4 waves), as the producer role of the fused attention + o_proj launch
-// (fused.hip, 8 waves) or as a role of the chained decode-layer kernel (mega.hip). head_dim 128: one K/V cache row =
+// (chain.hip: attn_oproj16_k, 16 waves). head_dim 128: one K/V cache row =
 // 256 B.
 //
 // One workgroup owns one (batch row, head). The cache is small (L x 256 B for K and for V), so the work is latency- and

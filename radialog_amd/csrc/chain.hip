@@ -1,20 +1,16 @@
-// Chained decode-layer kernel (gfx950): every per-layer unit of the batch-1 decode step -- QKV GEMV, attention,
-// o_proj, gate/up SwiGLU GEMV, down_proj -- for a RANGE of layers in ONE launch.
+// Chained decode launches of the batch-1/2 step (gfx950): units of consecutive decode layers run as ROLES of one launch, the dependency
+// between them is a counter hand-off (handoff.h) instead of a kernel boundary -- a consumer workgroup first puts two register batches
+// of ITS weight tile in flight, then waits until the producer role has published the activations, so HBM stays busy across the seam.
 //
-// Why: at batch 1 a decode step is 160 dependent launches of 8-30 us each, and every launch boundary leaves HBM idle for
-// ~3-5 us (drain, dispatch ramp, first-load latency). Here the units are "roles" of one grid, ordered by blockIdx
-// (layer-major, then qkv | attention | o_proj | gate/up | down), and the dependency between consecutive units is a
-// counter hand-off (handoff.h) instead of a kernel boundary: a workgroup first puts two register batches of ITS weight
-// tile in flight, then waits until the producer role has published the activations. While one unit drains, the
-// workgroups of the next units are already resident with their weights streaming, so HBM stays busy.
-//
-// All roles are 1024-thread workgroups (<= 64 VGPRs: two per CU, 512 resident):
-//   * qkv, gate/up (769 / 1376 output tiles): 4 tiles per workgroup, 4 waves split K of each tile (the shape of the
-//     stand-alone 4-wave kernel); the RMS-normalised activation row is staged ONCE per workgroup in LDS for all 4 tiles;
-//   * o_proj, down (256 tiles): one tile per workgroup, 16 waves split K;
-//   * attention: attn_body.h, 16 waves (cached K rows go in flight before the wait).
-// Arithmetic, rounding points and the fixed-order LDS reduction are those of skinny_body.h (same oracle parity).
+//   decode_chain_k   down_proj(l) (+ residual)  ->  RMSNorm + QKV(l + 1): one launch per layer, one 1024-thread workgroup per CU
+//                    (two resident 16-wave workgroups per CU run every unit ~25 % slower, so the launch reserves > half of the LDS);
+//   attn_oproj16_k   decode attention (attn_body.h) -> o_proj (+ residual): 32 attention workgroups + 128 two-tile o_proj workgroups
+//                    whose whole K slice sits in registers while attention runs.
+// Payloads are written write-through (8-byte agent-scope stores) and read with agent-scope loads: no cache fences. Arithmetic,
+// rounding points and the fixed-order LDS reduction are those of skinny_body.h (same oracle parity).
 // Liveness: a workgroup only waits on counters fed by lower-indexed workgroups; spins are bounded (handoff.h).
+// (Round 3: the all-roles chained kernel RDX_MEGA, the gate/up -> down -> QKV chain RDX_CHAIN=1 and the 8-wave fused attention of
+// fused.hip were measured slower in rounds 1-2 and have been removed; DESIGN.md 4 keeps the measurements.)
 #include "rdx_common.h"
 #include "rdx_kernels.h"
 #include "attn_body.h"
@@ -23,14 +19,11 @@
 
 namespace rdx {
 
-constexpr int MG_WAVES = 16;
-constexpr int MG_THREADS = MG_WAVES * 64;
-constexpr int MG_MAXM = 2;                       // batch rows supported (LDS staging of [M][inter] activations)
+constexpr int CH_WAVES = 16;
+constexpr int CH_THREADS = CH_WAVES * 64;
+constexpr int CH_MAXM = 2;                       // batch rows supported (LDS staging of [M][inter] activations)
 
-enum { MG_QKV = 0, MG_ATT = 1, MG_O = 2, MG_GU = 3, MG_DOWN = 4, MG_NROLE = 5 };
-constexpr int MG_CTR_STRIDE = HO_CTR_INTS;       // 8 shards x one 64-byte line per role counter
-
-struct MegaGemm {                                // one weight-streaming unit
+struct ChainGemm {                                // one weight-streaming unit
     const void* X; int ldx;
     const void* W;
     const void* resid; int ldr;
@@ -41,13 +34,13 @@ struct MegaGemm {                                // one weight-streaming unit
 };
 
 template <typename T, int EPI, bool NORM, int SUB, int XL, typename WaitFn, int U = 4, bool RESID_EARLY = false, bool W8 = false>
-__device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const int ntiles, unsigned char* smem, WaitFn wait_inputs) {
+__device__ __forceinline__ void chain_tile(const ChainGemm& a, const int wg, const int ntiles, unsigned char* smem, WaitFn wait_inputs) {
     typedef typename Vec8<T>::type V8;
-    constexpr int WPS = MG_WAVES / SUB;           // waves per tile
+    constexpr int WPS = CH_WAVES / SUB;           // waves per tile
     // U chunks per register batch, two batches in flight: U = 4 keeps every role of the chained kernel <= 64 VGPRs
-    float* red = reinterpret_cast<float*>(smem);                        // [MG_WAVES][256]
-    float* ssq = red + MG_WAVES * 256;                                  // [MG_WAVES][MG_MAXM]
-    float* rstd_s = ssq + MG_WAVES * MG_MAXM;                           // [MG_MAXM] (+pad)
+    float* red = reinterpret_cast<float*>(smem);                        // [CH_WAVES][256]
+    float* ssq = red + CH_WAVES * 256;                                  // [CH_WAVES][CH_MAXM]
+    float* rstd_s = ssq + CH_WAVES * CH_MAXM;                           // [CH_MAXM] (+pad)
     T* xs = reinterpret_cast<T*>(rstd_s + 16);                          // [M][K] x-hat
 
     const int lane = threadIdx.x & 63, wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -83,39 +76,39 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
 
     // activations: published write-through by other workgroups of this launch -> agent-scope 8-byte loads (L1 bypass),
     // each chunk loaded ONCE and kept in registers across the RMSNorm statistics
-    // XL = chunks of 4 elements per thread: M*K/4 <= XL*1024 (checked by mega_supported)
+    // XL = chunks of 4 elements per thread: M*K/4 <= XL*1024 (checked by chain_supported)
     const int K4 = K >> 2, total4 = a.M * K4;
     unsigned long long xr[XL];
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
-        const int c = threadIdx.x + i * MG_THREADS;
+        const int c = threadIdx.x + i * CH_THREADS;
         xr[i] = 0ull;
         if (c < total4) { const int m = c / K4, k4 = c - m * K4; xr[i] = ld8_agent(X + (size_t)m * a.ldx + (size_t)k4 * 4); }
     }
     if (NORM) {
-        float ss[MG_MAXM];
+        float ss[CH_MAXM];
 #pragma unroll
-        for (int m = 0; m < MG_MAXM; ++m) ss[m] = 0.f;
+        for (int m = 0; m < CH_MAXM; ++m) ss[m] = 0.f;
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
-            const int c = threadIdx.x + i * MG_THREADS;
+            const int c = threadIdx.x + i * CH_THREADS;
             float t = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const float f = tof<T>(from_bits16<T>((unsigned short)(xr[i] >> (16 * j)))); t += f * f; }
             const int m = c < total4 ? c / K4 : 0;                       // padding chunks are zero
 #pragma unroll
-            for (int mm = 0; mm < MG_MAXM; ++mm) ss[mm] += (m == mm) ? t : 0.f;
+            for (int mm = 0; mm < CH_MAXM; ++mm) ss[mm] += (m == mm) ? t : 0.f;
         }
 #pragma unroll
-        for (int m = 0; m < MG_MAXM; ++m) {
+        for (int m = 0; m < CH_MAXM; ++m) {
             const float t = wave_sum(ss[m]);
-            if (lane == 0) ssq[wa * MG_MAXM + m] = t;
+            if (lane == 0) ssq[wa * CH_MAXM + m] = t;
         }
         __syncthreads();
-        if (threadIdx.x < MG_MAXM) {
+        if (threadIdx.x < CH_MAXM) {
             float t = 0.f;
 #pragma unroll
-            for (int i = 0; i < MG_WAVES; ++i) t += ssq[i * MG_MAXM + threadIdx.x];
+            for (int i = 0; i < CH_WAVES; ++i) t += ssq[i * CH_MAXM + threadIdx.x];
             rstd_s[threadIdx.x] = rsqrtf(t / (float)K + a.eps);
         }
         __syncthreads();
@@ -124,7 +117,7 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
         const T* NW = reinterpret_cast<const T*>(a.norm_w);
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
-            const int c = threadIdx.x + i * MG_THREADS;
+            const int c = threadIdx.x + i * CH_THREADS;
             if (c < total4) {
                 const int m = c / K4, k4 = c - m * K4;
                 unsigned long long v = xr[i];
@@ -251,70 +244,25 @@ __device__ __forceinline__ void mega_tile(const MegaGemm& a, const int wg, const
     }
 }
 
-// OCC = waves per SIMD the register budget is sized for: 8 -> <= 64 VGPRs, two workgroups per CU (attention keeps a
-// small K window and loads V late); 4 -> <= 128 VGPRs, one workgroup per CU (attention as in the stand-alone kernel)
-template <typename T, int OCC, bool WITH_ATT, bool W8 = false>
-__global__ __launch_bounds__(MG_THREADS, OCC) void decode_layers_k(MegaArgs ma) {
+// down_proj(l) then RMSNorm + QKV(l + 1): blocks [0, nwg_down) are down_proj tiles (one tile per workgroup, 16 waves split K; their
+// input predates the launch), blocks [nwg_down, +nwg_qkv) are QKV workgroups of the NEXT layer (4 tiles each, 4 waves per tile, the
+// normalised row staged once per workgroup) that wait for all down_proj tiles on the layer's sharded counter
+template <typename T, bool W8>
+__global__ __launch_bounds__(CH_THREADS, 4) void decode_chain_k(ChainArgs ca) {
     extern __shared__ __attribute__((aligned(16))) unsigned char msm[];
-    const int per_layer = ma.nwg[0] + ma.nwg[1] + ma.nwg[2] + ma.nwg[3] + ma.nwg[4];
-    const int bid = blockIdx.x + ma.blk_offset;             // the launch may start in the middle of its first layer
-    const int li = bid / per_layer;                         // layer index inside this launch
-    int rb = bid - li * per_layer;
-    const int l = ma.layer0 + li;
-    const MegaLayer& L = ma.layers[l];
-    int* ctr = ma.ctr + (size_t)l * MG_NROLE * MG_CTR_STRIDE;
-    int* prev_down = ctr - MG_NROLE * MG_CTR_STRIDE + MG_DOWN * MG_CTR_STRIDE;
-    const int H = ma.d.hidden, B = ma.B;
-    long long* tr = ma.trace ? ma.trace + (size_t)blockIdx.x * 4 : nullptr;
-    if (tr && threadIdx.x == 0) tr[0] = (long long)__builtin_amdgcn_s_memrealtime();
-#define MG_DONE(role) do { if (tr && threadIdx.x == 0) { tr[2] = (long long)__builtin_amdgcn_s_memrealtime(); tr[3] = (role); } } while (0)
-
-    if (rb < ma.nwg[MG_QKV]) {
-        MegaGemm g = {ma.dx, H, L.wqkv, nullptr, 0, ma.dqkv, ma.d.qkv_ld, B, ma.qkv_n, H, L.attn_norm, ma.eps, L.wqkv8, L.sqkv};
-        // first layer of the launch: the kernel boundary already ordered it after the previous launch
-        mega_tile<T, EPI_NONE, true, 4, 2, WaitSharded, 4, false, W8>(g, rb, ma.tiles[MG_QKV], msm,
-                                           WaitSharded{prev_down, li ? ma.nwg[MG_DOWN] : 0, ma.err, ma.naps, tr});
-        publish_sc1(ctr + MG_QKV * MG_CTR_STRIDE, rb);
-        MG_DONE(MG_QKV);
+    const ChainLayer& L = ca.layers[ca.layer];
+    int* ctr = ca.ctr + (size_t)ca.layer * HO_CTR_INTS;
+    const int H = ca.hidden, B = ca.B;
+    if ((int)blockIdx.x < ca.nwg_down) {
+        ChainGemm g = {ca.dgu, ca.inter, L.wdown, ca.dx, H, ca.dx, H, B, H, ca.inter, nullptr, 0.f, L.wdown8, L.sdown};
+        chain_tile<T, EPI_RESID, false, 1, 6, WaitSharded, 4, false, W8>(g, blockIdx.x, ca.nwg_down, msm, WaitSharded{ctr, 0, ca.err, ca.naps, nullptr});
+        publish_sc1(ctr, blockIdx.x);
         return;
     }
-    rb -= ma.nwg[MG_QKV];
-    if (WITH_ATT && rb < ma.nwg[MG_ATT]) {
-        DecAttnArgs at;
-        at.d = ma.d; at.qkv = ma.dqkv; at.lbq = L.lbq; at.lbv = L.lbv; at.cos_t = ma.cos_t; at.sin_t = ma.sin_t; at.cur_rope = ma.cur_rope;
-        at.pos = ma.pos; at.slot_b = ma.slot_b; at.key_mask = ma.key_mask; at.kcache = L.kcache; at.vcache = L.vcache; at.out = ma.datt;
-        at.trace = ma.trace ? ma.trace + (size_t)gridDim.x * 4 + (size_t)l * 8 : nullptr;
-        const int b = rb / ma.d.heads, h = rb - b * ma.d.heads;
-        const WaitSharded wq{ctr + MG_QKV * MG_CTR_STRIDE, (li || ma.r_begin != MG_ATT) ? ma.nwg[MG_QKV] : 0, ma.err, ma.naps, tr};
-        if (OCC == 8) decode_attention_body<T, MG_WAVES, true, WaitSharded, false, 1, true>(at, h, b, reinterpret_cast<float*>(msm), wq);
-        else decode_attention_body<T, MG_WAVES, true, WaitSharded, true, 0, true>(at, h, b, reinterpret_cast<float*>(msm), wq);
-        publish_sc1(ctr + MG_ATT * MG_CTR_STRIDE, rb);
-        MG_DONE(MG_ATT);
-        return;
-    }
-    rb -= ma.nwg[MG_ATT];
-    if (rb < ma.nwg[MG_O]) {
-        MegaGemm g = {ma.datt, H, L.wo, ma.dx, H, ma.dx, H, B, H, H, nullptr, 0.f, L.wo8, L.so};
-        mega_tile<T, EPI_RESID, false, 1, 2, WaitSharded, 4, false, W8>(g, rb, ma.tiles[MG_O], msm, WaitSharded{ctr + MG_ATT * MG_CTR_STRIDE, (li || ma.r_begin != MG_O) ? ma.nwg[MG_ATT] : 0, ma.err, ma.naps, tr});
-        publish_sc1(ctr + MG_O * MG_CTR_STRIDE, rb);
-        MG_DONE(MG_O);
-        return;
-    }
-    rb -= ma.nwg[MG_O];
-    if (rb < ma.nwg[MG_GU]) {
-        MegaGemm g = {ma.dx, H, L.wgu, nullptr, 0, ma.dgu, ma.inter, B, 2 * ma.inter, H, L.mlp_norm, ma.eps, L.wgu8, L.sgu};
-        mega_tile<T, EPI_SILU_MUL, true, 4, 2, WaitSharded, 4, false, W8>(g, rb, ma.tiles[MG_GU], msm, WaitSharded{ctr + MG_O * MG_CTR_STRIDE, (li || ma.r_begin != MG_GU) ? ma.nwg[MG_O] : 0, ma.err, ma.naps, tr});
-        publish_sc1(ctr + MG_GU * MG_CTR_STRIDE, rb);
-        MG_DONE(MG_GU);
-        return;
-    }
-    rb -= ma.nwg[MG_GU];
-    {
-        MegaGemm g = {ma.dgu, ma.inter, L.wdown, ma.dx, H, ma.dx, H, B, H, ma.inter, nullptr, 0.f, L.wdown8, L.sdown};
-        mega_tile<T, EPI_RESID, false, 1, 6, WaitSharded, 4, false, W8>(g, rb, ma.tiles[MG_DOWN], msm, WaitSharded{ctr + MG_GU * MG_CTR_STRIDE, (li || ma.r_begin != MG_DOWN) ? ma.nwg[MG_GU] : 0, ma.err, ma.naps, tr});
-        publish_sc1(ctr + MG_DOWN * MG_CTR_STRIDE, rb);
-        MG_DONE(MG_DOWN);
-    }
+    const ChainLayer& Ln = ca.layers[ca.layer + 1];
+    ChainGemm g = {ca.dx, H, Ln.wqkv, nullptr, 0, ca.dqkv, ca.qkv_ld, B, ca.qkv_n, H, Ln.attn_norm, ca.eps, Ln.wqkv8, Ln.sqkv};
+    chain_tile<T, EPI_NONE, true, 4, 2, WaitSharded, 4, false, W8>(g, blockIdx.x - ca.nwg_down, (ca.qkv_n + 15) / 16, msm,
+                                                                    WaitSharded{ctr, ca.nwg_down, ca.err, ca.naps, nullptr});
 }
 
 // ---- decode attention + o_proj(+residual) in ONE launch, 16-wave workgroups -------------------------------------------------
@@ -323,92 +271,64 @@ __global__ __launch_bounds__(MG_THREADS, OCC) void decode_layers_k(MegaArgs ma) 
 // K slice (16 chunks per wave) goes in flight at entry and sits in registers while attention runs; then the fence-free
 // hand-off (handoff.h) and ~2 us of work. heads*B + ntiles/2 <= 256 workgroups of <= 128 VGPRs: all resident, one per CU.
 template <typename T, bool W8>
-__global__ __launch_bounds__(MG_THREADS, 4) void attn_oproj16_k(DecAttnArgs at, MegaGemm g, int n_attn, int ntiles, int* counter, int* err) {
+__global__ __launch_bounds__(CH_THREADS, 4) void attn_oproj16_k(DecAttnArgs at, ChainGemm g, int n_attn, int ntiles, int* counter, int* err) {
     extern __shared__ __attribute__((aligned(16))) unsigned char msm[];
     if ((int)blockIdx.x < n_attn) {
         const int b = blockIdx.x / at.d.heads, h = blockIdx.x - b * at.d.heads;
-        decode_attention_body<T, MG_WAVES, true, NoWait, true, 0, true>(at, h, b, reinterpret_cast<float*>(msm));
+        decode_attention_body<T, CH_WAVES, true, NoWait, true, 0, true>(at, h, b, reinterpret_cast<float*>(msm));
         publish_sc1(counter, blockIdx.x);
     } else {
-        mega_tile<T, EPI_RESID, false, 2, 2, WaitSharded, W8 ? 4 : 8, true, W8>(g, blockIdx.x - n_attn, ntiles, msm, WaitSharded{counter, n_attn, err, 1, nullptr});
+        chain_tile<T, EPI_RESID, false, 2, 2, WaitSharded, W8 ? 4 : 8, true, W8>(g, blockIdx.x - n_attn, ntiles, msm, WaitSharded{counter, n_attn, err, 1, nullptr});
     }
 }
 
 bool attn_oproj16_supported(const LlamaDims& d, int N, int K, int B) {
     const int ntiles = (N + 15) / 16;
-    return B <= MG_MAXM && d.head_dim == 128 && K % 32 == 0 && N % 4 == 0 && (size_t)B * K <= 8192 &&
+    return B <= CH_MAXM && d.head_dim == 128 && K % 32 == 0 && N % 4 == 0 && (size_t)B * K <= 8192 &&
            d.heads * B + (ntiles + 1) / 2 <= 256;
 }
 
 void launch_attn_oproj16(int dtype, const DecAttnArgs& a, const GemmArgs& ga, int B, int* counter, int* err, hipStream_t s) {
     const int n_attn = a.d.heads * B, ntiles = (ga.N + 15) / 16;
     const bool w8 = ga.W8 && ga.wscale && ga.K % 64 == 0;
-    MegaGemm g = {ga.X, ga.ldx, ga.W, ga.resid, ga.ldr, ga.out, ga.ldo, ga.M, ga.N, ga.K, nullptr, 0.f, ga.W8, ga.wscale};
-    const size_t sm_gemm = (size_t)(MG_WAVES * 256 + MG_WAVES * MG_MAXM + 16) * 4 + (size_t)B * ga.K * 2;
-    const size_t sm_att = decode_attention_smem_floats(MG_WAVES, a.d.max_len) * sizeof(float);
+    ChainGemm g = {ga.X, ga.ldx, ga.W, ga.resid, ga.ldr, ga.out, ga.ldo, ga.M, ga.N, ga.K, nullptr, 0.f, ga.W8, ga.wscale};
+    const size_t sm_gemm = (size_t)(CH_WAVES * 256 + CH_WAVES * CH_MAXM + 16) * 4 + (size_t)B * ga.K * 2;
+    const size_t sm_att = decode_attention_smem_floats(CH_WAVES, a.d.max_len) * sizeof(float);
     const size_t smem = sm_gemm > sm_att ? sm_gemm : sm_att;
-    dim3 grid(n_attn + (ntiles + 1) / 2), block(MG_THREADS);
+    dim3 grid(n_attn + (ntiles + 1) / 2), block(CH_THREADS);
     RDX_DISPATCH_T(dtype, T, {
         if (w8) hipLaunchKernelGGL((attn_oproj16_k<T, true>), grid, block, smem, s, a, g, n_attn, ntiles, counter, err);
         else hipLaunchKernelGGL((attn_oproj16_k<T, false>), grid, block, smem, s, a, g, n_attn, ntiles, counter, err);
     });
 }
 
-bool mega_supported(const LlamaDims& d, int inter, int B) {
-    if (B > MG_MAXM || d.head_dim != 128 || d.hidden % 32 || inter % 32 || d.hidden % 16) return false;
+bool chain_supported(const LlamaDims& d, int inter, int B) {
+    if (B > CH_MAXM || d.head_dim != 128 || d.hidden % 32 || inter % 32 || d.hidden % 16) return false;
     const size_t stage = (size_t)B * (inter > d.hidden ? inter : d.hidden) * 2;
-    // staged activations: <= 2 x 1024 chunks of 4 elements for the K = hidden units, <= 6 x 1024 for down_proj (K = inter)
+    // staged activations: <= 2 x 1024 chunks of 4 elements for the K = hidden unit, <= 6 x 1024 for down_proj (K = inter)
     return stage <= 48 * 1024 && inter % 4 == 0 && (size_t)B * d.hidden <= 8192 && (size_t)B * inter <= 24576;
 }
 
-size_t mega_ctr_ints(int layers) { return (size_t)layers * MG_NROLE * MG_CTR_STRIDE; }
+size_t chain_ctr_ints(int layers) { return (size_t)layers * HO_CTR_INTS; }
 
-static void mega_fill(MegaArgs& ma) {
-    ma.tiles[MG_QKV] = (ma.qkv_n + 15) / 16;  ma.nwg[MG_QKV] = (ma.tiles[MG_QKV] + 3) / 4;
-    ma.tiles[MG_ATT] = ma.d.heads * ma.B;     ma.nwg[MG_ATT] = ma.tiles[MG_ATT];
-    ma.tiles[MG_O] = ma.d.hidden / 16;        ma.nwg[MG_O] = ma.tiles[MG_O];
-    ma.tiles[MG_GU] = (2 * ma.inter) / 16;    ma.nwg[MG_GU] = (ma.tiles[MG_GU] + 3) / 4;
-    ma.tiles[MG_DOWN] = ma.d.hidden / 16;     ma.nwg[MG_DOWN] = ma.tiles[MG_DOWN];
-}
-
-void launch_decode_roles(int dtype, MegaArgs ma, int R0, int R1, int occ, hipStream_t s) {
-    mega_fill(ma);
-    const int l0 = R0 / MG_NROLE, r0 = R0 % MG_NROLE, l1 = (R1 - 1) / MG_NROLE, r1 = (R1 - 1) % MG_NROLE;
-    bool with_att = false;
-    for (int R = R0; R < R1; ++R) with_att |= (R % MG_NROLE) == MG_ATT;
-    const int per_layer = ma.nwg[0] + ma.nwg[1] + ma.nwg[2] + ma.nwg[3] + ma.nwg[4];
-    int off = 0, tail = 0;
-    for (int r = 0; r < r0; ++r) off += ma.nwg[r];
-    for (int r = r1 + 1; r < MG_NROLE; ++r) tail += ma.nwg[r];
-    ma.layer0 = l0; ma.r_begin = r0; ma.blk_offset = off;
-    const int kmax = ma.inter > ma.d.hidden ? ma.inter : ma.d.hidden;
-    const size_t sm_gemm = (size_t)(MG_WAVES * 256 + MG_WAVES * MG_MAXM + 16) * 4 + (size_t)ma.B * kmax * 2;
-    const size_t sm_att = with_att ? decode_attention_smem_floats(MG_WAVES, ma.d.max_len) * sizeof(float) : 0;
-    const size_t smem = sm_gemm > sm_att ? sm_gemm : sm_att;
-    dim3 grid((l1 - l0 + 1) * per_layer - off - tail), block(MG_THREADS);
+void launch_decode_chain(int dtype, ChainArgs ca, bool with_next_qkv, hipStream_t s) {
+    ca.nwg_down = ca.hidden / 16;
+    const int nwg_qkv = with_next_qkv ? ((ca.qkv_n + 15) / 16 + 3) / 4 : 0;
+    const int kmax = ca.inter > ca.hidden ? ca.inter : ca.hidden;
+    const size_t sm_gemm = (size_t)(CH_WAVES * 256 + CH_WAVES * CH_MAXM + 16) * 4 + (size_t)ca.B * kmax * 2;
+    // ONE workgroup per CU: the register budget alone (62 VGPRs) would admit two, so reserve more than half of the LDS
+    const size_t smem = sm_gemm > (size_t)84 * 1024 ? sm_gemm : (size_t)84 * 1024;
+    dim3 grid(ca.nwg_down + nwg_qkv), block(CH_THREADS);
     RDX_DISPATCH_T(dtype, T, {
-        if (!with_att && occ == 8) hipLaunchKernelGGL((decode_layers_k<T, 8, false>), grid, block, smem, s, ma);
-        else if (!with_att) {
-            // ONE workgroup per CU: two resident 1024-thread workgroups per CU measured ~25 % slower in every unit, and the
-            // register budget alone (62 VGPRs) would admit two, so reserve more than half of the LDS
-            const size_t big = smem > (size_t)84 * 1024 ? smem : (size_t)84 * 1024;
-            static bool attr_set[2] = {false, false};
-            if (!attr_set[dtype & 1]) {
-                hipFuncSetAttribute((const void*)decode_layers_k<T, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-                hipFuncSetAttribute((const void*)decode_layers_k<T, 4, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-                attr_set[dtype & 1] = true;
-            }
-            if (ma.w8) hipLaunchKernelGGL((decode_layers_k<T, 4, false, true>), grid, block, big, s, ma);
-            else hipLaunchKernelGGL((decode_layers_k<T, 4, false>), grid, block, big, s, ma);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipFuncSetAttribute((const void*)decode_chain_k<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+            hipFuncSetAttribute((const void*)decode_chain_k<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+            attr_set = true;
         }
-        else if (occ == 8) hipLaunchKernelGGL((decode_layers_k<T, 8, true>), grid, block, smem, s, ma);
-        else hipLaunchKernelGGL((decode_layers_k<T, 4, true>), grid, block, smem, s, ma);
+        if (ca.w8) hipLaunchKernelGGL((decode_chain_k<T, true>), grid, block, smem, s, ca);
+        else hipLaunchKernelGGL((decode_chain_k<T, false>), grid, block, smem, s, ca);
     });
 }
-
-void launch_decode_layers(int dtype, MegaArgs ma, int nlayers, int occ, hipStream_t s) {
-    launch_decode_roles(dtype, ma, ma.layer0 * MG_NROLE, (ma.layer0 + nlayers) * MG_NROLE, occ, s);
-}
-
 
 }  // namespace rdx

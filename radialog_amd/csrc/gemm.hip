@@ -173,9 +173,7 @@ static void launch_skinny_T(const GemmArgs& a, int epi, hipStream_t s) {
 }
 
 void launch_skinny_gemm(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
-    static const int s32 = getenv("RDX_SK32") ? atoi(getenv("RDX_SK32")) : 1;
     if (xstat32_supported(a, epi)) { launch_xstat32(dtype, a, epi, s); return; }
-    if (s32 && skinny32_supported(a, epi)) { launch_skinny32(dtype, a, epi, s); return; }
     RDX_DISPATCH_T(dtype, T, launch_skinny_T<T>(a, epi, s));
 }
 

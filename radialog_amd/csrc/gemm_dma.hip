@@ -57,14 +57,13 @@ __device__ __forceinline__ void store4(const GemmArgs& a, int m, int n, float v[
 // CONV: the activation operand is an implicit-GEMM gather from an NHWC tensor (K ordered (kh, kw, c), Cin % 8 == 0, so a lane's
 // 16-byte piece lies inside one filter tap): every lane hands global_load_lds its own source address; taps that fall
 // into the zero padding read a 16-byte zero block instead.
-// NS = LDS stages of 32 KiB: 2 (64 KiB, two workgroups per CU: grids of several rounds hide the DMA latency by occupancy) or 4
-// (128 KiB, one workgroup per CU, three steps in flight: grids that do not even fill the chip once -- the Q-Former's M = 32 x batch
-// GEMMs, 48-192 tiles -- were running one 1.3-us DMA round trip per 0.2-us k-step).
-template <typename T, int EPI, bool SPLIT, bool CONV = false, int NS = 2>
+// Two LDS stages of 32 KiB (64 KiB: two workgroups per CU; a four-stage ring for grids that do not fill the chip was measured in round 2
+// and removed -- no gain).
+template <typename T, int EPI, bool SPLIT, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict__ partial, int steps_per_split, ConvGeom cg = ConvGeom(),
                                                   const void* zero16 = nullptr) {
     typedef typename Vec8<T>::type V8;
-    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [stage NS][operand 2][block 16][lane 64]
+    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [stage 2][operand 2][block 16][lane 64]
     const int MB = (a.M + DG_BM - 1) / DG_BM, NB = (a.N + DG_BN - 1) / DG_BN;
     const int nwg = MB * NB;
     int tile;
@@ -150,7 +149,7 @@ __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict_
                 for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma16(wf[nt], xf[mt], acc[nt][mt]);
         }
     };
-    if (NS == 2) {
+    {
         if (s0 < s1) stage(s0, 0);
         for (int s = s0; s < s1; ++s) {
             const int buf = (s - s0) & 1;
@@ -166,25 +165,8 @@ __global__ __launch_bounds__(256) void gemm_dma_k(GemmArgs a, float* __restrict_
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                               // everyone is done reading buf before it is re-staged
         }
-    } else {
-        // stages s0 .. s0+NS-2 in flight; every step: wait for ITS 8 loads per wave (the younger stages stay in flight), one barrier
-        // (publishes stage s and frees the slot stage s-1 was read from), refill that slot, multiply. Past the end the last stage is
-        // re-loaded (harmless) so that the wait counts stay uniform.
-        const int nst = s1 - s0;
-        if (nst > 0) {
-#pragma unroll
-            for (int p = 0; p < NS - 1; ++p) stage(s0 + min(p, nst - 1), p);
-        }
-        for (int i = 0; i < nst; ++i) {
-            if (NS == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            stage(s0 + min(i + NS - 1, nst - 1), (i + NS - 1) % NS);
-            multiply(lds + (size_t)(i % NS) * 2 * 16 * 64);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's LDS reads of the stage are done before its next barrier
-        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the re-loaded tail stages must land before the LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (trc) { trc[2] = (long long)__builtin_amdgcn_s_memrealtime(); trc[4] = s1 - s0; trc[5] = (long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); }
 
     // epilogue: lane (r = m_local, g) holds out[m][n0 + g*4 + 0..3]
@@ -427,31 +409,22 @@ static void launch_dma_epi(const GemmArgs& a_in, float* ws, size_t ws_floats, hi
     splits = (nsteps + per - 1) / per;
     const size_t smem = (size_t)2 * 2 * 16 * 64 * sizeof(u4);       // 64 KiB
     dim3 grid(blocks, 1, splits), block(256);
-    // RDX_DMA_NS4=1: four stages, one workgroup per CU, for grids that do not fill the chip. Measured: NO gain (q.qkv M = 1024:
-    // 16.8 -> 17.6 us; B = 1 encode 1.47 -> 1.50 ms) -- the k-step is not latency- but operand-bandwidth-bound, so it
-    // stays off.
-    const char* e4 = getenv("RDX_DMA_NS4");
-    const bool deep = (e4 ? atoi(e4) != 0 : false) && blocks * splits <= 256 && per >= 4;
     if (splits > 1) {
         static bool attr = false;
         if (!attr) {
             hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, true, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * smem));
             attr = true;
         }
-        if (deep) hipLaunchKernelGGL((gemm_dma_k<T, EPI, true, false, 4>), grid, block, 2 * smem, s, a, ws, per, ConvGeom(), nullptr);
-        else hipLaunchKernelGGL((gemm_dma_k<T, EPI, true>), grid, block, smem, s, a, ws, per, ConvGeom(), nullptr);
+        hipLaunchKernelGGL((gemm_dma_k<T, EPI, true>), grid, block, smem, s, a, ws, per, ConvGeom(), nullptr);
         const size_t total = (size_t)a.M * (a.N >> 2);
         hipLaunchKernelGGL((splitk_reduce_k<T, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, ws, splits);
     } else {
         static bool attr = false;
         if (!attr) {
             hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * smem));
             attr = true;
         }
-        if (deep) hipLaunchKernelGGL((gemm_dma_k<T, EPI, false, false, 4>), grid, block, 2 * smem, s, a, nullptr, nsteps, ConvGeom(), nullptr);
-        else hipLaunchKernelGGL((gemm_dma_k<T, EPI, false>), grid, block, smem, s, a, nullptr, nsteps, ConvGeom(), nullptr);
+        hipLaunchKernelGGL((gemm_dma_k<T, EPI, false>), grid, block, smem, s, a, nullptr, nsteps, ConvGeom(), nullptr);
     }
 }
 

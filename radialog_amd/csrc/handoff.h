@@ -1,5 +1,5 @@
 // Workgroup-to-workgroup hand-off inside ONE launch (cdna_hip_programming.md G16, counter form), used by the fused
-// attention + o_proj launch (fused.hip) and by the chained decode-layer kernel (mega.hip).
+// attention + o_proj launch and the chained down -> QKV launch (chain.hip).
 //
 // Producer workgroup: plain stores -> every wave drains vmcnt -> __syncthreads -> ONE lane does an agent-scope release
 // fence (L2 write-back: the 8 XCD L2s are not coherent with each other), drains again, then a relaxed agent-scope
@@ -47,7 +47,7 @@ __device__ __forceinline__ void publish(int* counter) {
     }
 }
 
-// ---- fence-free form (write-through payload): used by mega.hip ---------------------------------------------------------
+// ---- fence-free form (write-through payload): used by chain.hip ---------------------------------------------------------
 // Payload words are written with relaxed agent-scope 8-byte stores (sc1: write-through, the line leaves the writer's
 // L2) and read with relaxed agent-scope 8-byte loads (sc1: bypass the reader's L1), so neither side needs a cache
 // fence (a release fence costs 1.7-6.5 us per workgroup, an acquire 1.7 us and more with several workgroups per CU).

@@ -37,7 +37,7 @@ __device__ __forceinline__ v4f mfma16(v8h a, v8h b, v4f c) { return __builtin_am
 __device__ __forceinline__ v4f mfma16(v8b a, v8b b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 // 16-byte GLOBAL-memory loads/stores. `ldg_nt` = streamed-once data (decode weights): non-temporal policy.
-// The explicit address_space(1) cast matters: a pointer fetched from a device-memory table (mega.hip) is generic, and
+// The explicit address_space(1) cast matters: a pointer fetched from a device-memory table (chain.hip) is generic, and
 // generic accesses become FLAT instructions, whose completion order is not guaranteed -- the compiler then falls back
 // to s_waitcnt vmcnt(0) everywhere and a software-pipelined weight stream collapses to one batch in flight.
 typedef __attribute__((address_space(1))) u4 g_u4;

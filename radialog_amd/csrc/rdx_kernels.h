@@ -74,10 +74,6 @@ void launch_pack_weight_fp8(int dtype, const float* src, void* dst8, float* scal
 // must normalise first (launch_rmsnorm) and pass norm_w = null.
 bool skinny_fits_lds(int M, int K);
 void launch_skinny_gemm(int dtype, const GemmArgs& a, int epi, hipStream_t s);
-// 16 < M <= 32 weight-streaming GEMM with the activations staged through LDS and shared by several tiles (skinny32.hip);
-// no fused RMSNorm (a.norm_w must be null)
-bool skinny32_supported(const GemmArgs& a, int epi);
-void launch_skinny32(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 bool xstat32_supported(const GemmArgs& a, int epi);
 void launch_xstat32(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 // K-split activation-stationary GEMM for the 256-tile projections at 16 < M <= 32: fp32 partial slabs [groups][32][N], combined
@@ -134,45 +130,32 @@ struct DecAttnArgs {
     int out_packed = 0;              // stand-alone launches, batch 3-32: write `out` fragment-packed for xsplit32_k (attn_body.h)
 };
 void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s);
-// decode attention + o_proj(+residual) in ONE launch: the o_proj tile workgroups put their weights in flight
-// immediately and wait on `counter` (agent-scope release/acquire hand-off) for the heads*B attention workgroups.
-// `counter` must be zero at launch; `err` is set to 1 if a wait ever times out (never hangs).
-void launch_attn_oproj(int dtype, const DecAttnArgs& a, const GemmArgs& g, int B, int* counter, int* err, hipStream_t s);
-
-// Chained decode-layer kernel (mega.hip): QKV GEMV -> attention -> o_proj -> gate/up -> down of `nlayers` consecutive
-// layers in ONE launch, units chained by counter hand-offs instead of kernel boundaries (batch <= 2).
-struct MegaLayer { const void *wqkv, *wo, *wgu, *wdown, *attn_norm, *mlp_norm, *lbq, *lbv; void *kcache, *vcache;
-                   // fp8 weights (e4m3, 64-deep fragment order) + per-row scales, null when the model dtype copy is streamed
-                   const void *wqkv8, *wo8, *wgu8, *wdown8; const float *sqkv, *so, *sgu, *sdown; };
-struct MegaArgs {
-    const MegaLayer* layers;         // device table, one entry per decoder layer
-    int layer0;                      // first layer of this launch
-    LlamaDims d;
-    int inter, qkv_n, B;
-    int w8;                          // chained roles without attention: stream the fp8 weights (every projection quantised)
+// Chained decode launches of the batch <= 2 step (chain.hip): units run as roles of one launch, chained by a fence-free counter
+// hand-off (handoff.h) instead of a kernel boundary.
+struct ChainLayer { const void *wqkv, *wdown, *attn_norm;
+                    // fp8 weights (e4m3, 64-deep fragment order) + per-row scales, null when the model dtype copy is streamed
+                    const void *wqkv8, *wdown8; const float *sqkv, *sdown; };
+struct ChainArgs {
+    const ChainLayer* layers;        // device table, one entry per decoder layer
+    int layer;                       // down_proj of this layer, QKV of the next
+    int hidden, inter, qkv_n, qkv_ld, B;
+    int w8;                          // stream the fp8 weights (every projection quantised)
     float eps;
-    void *dx, *dqkv, *datt, *dgu;    // [B][hidden] residual stream, [B][qkv_ld], [B][hidden], [B][inter]
-    const void *cos_t, *sin_t, *cur_rope;
-    const int *pos, *slot_b;
-    const uint8_t* key_mask;
-    int* ctr;                        // mega_ctr_ints(layers) ints, zero at the start of every step
+    void *dx, *dqkv, *dgu;           // [B][hidden] residual stream, [B][qkv_ld], [B][inter]
+    int* ctr;                        // chain_ctr_ints(layers) ints, zero at the start of every step
     int* err;
-    long long* trace;                // nullable: [grid][4] = {start, inputs ready, end (100 MHz ticks), role}
     int naps;                        // poll back-off (x s_sleep(8) between polls)
-    int tiles[5], nwg[5];            // filled by the launcher
-    int r_begin, blk_offset;         // filled by the launcher: first role of the launch (it does not wait), blocks skipped before it
+    int nwg_down;                    // filled by the launcher
 };
-// 16-wave variant of the fused attention + o_proj launch (mega.hip): fast attention body, two o_proj tiles per workgroup with
-// their whole K slice in registers, fence-free hand-off. `counter` = 128 ints (8 shards), zero at launch.
+bool chain_supported(const LlamaDims& d, int inter, int B);
+size_t chain_ctr_ints(int layers);
+// down_proj(l) (+ residual) -> RMSNorm + QKV(l + 1) in ONE launch, one workgroup per CU; with_next_qkv = false for the last layer
+void launch_decode_chain(int dtype, ChainArgs ca, bool with_next_qkv, hipStream_t s);
+// decode attention + o_proj (+ residual) in ONE launch of 16-wave workgroups: fast attention body, two o_proj tiles per workgroup with
+// their whole K slice in registers, fence-free hand-off. `counter` = 128 ints (8 shards), zero at launch; `err` is set to 1 if a wait
+// ever times out (never hangs).
 bool attn_oproj16_supported(const LlamaDims& d, int N, int K, int B);
 void launch_attn_oproj16(int dtype, const DecAttnArgs& a, const GemmArgs& g, int B, int* counter, int* err, hipStream_t s);
-bool mega_supported(const LlamaDims& d, int inter, int B);
-size_t mega_ctr_ints(int layers);
-// occ: 8 = two workgroups per CU (<= 64 VGPRs), 4 = one per CU (<= 128 VGPRs)
-void launch_decode_layers(int dtype, MegaArgs ma, int nlayers, int occ, hipStream_t s);
-// any contiguous range [R0, R1) of the role sequence R = layer*5 + {0 qkv, 1 attention, 2 o_proj, 3 gate/up, 4 down}
-// (ma.layer0 is ignored); ranges without an attention role use a <= 64-VGPR build (two workgroups per CU)
-void launch_decode_roles(int dtype, MegaArgs ma, int R0, int R1, int occ, hipStream_t s);
 
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s);
 // rows <= 32 normalised into the 32-row fragment-packed block xstat32_k reads (pack 1: 32-deep fragments, 2: fp8 64-deep order)

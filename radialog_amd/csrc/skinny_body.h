@@ -1,5 +1,5 @@
 // Body of the skinny (M <= 32) weight-streaming GEMM, as a device function so that it can run either as its own kernel
-// (gemm.hip: skinny_gemm_k) or as the consumer role of a fused launch (fused.hip: attention + o_proj, where the tile's
+// (gemm.hip: skinny_gemm_k) or as the consumer role of a fused launch (chain.hip: attention + o_proj, where the tile's
 // weights are already in flight while the producer workgroups are still computing the activations).
 //
 // One workgroup = one 16-column output tile; its WAVES waves split K. Each wave streams its K slice of the packed tile

@@ -1,7 +1,8 @@
 // Activation-stationary weight-streaming GEMM for 2 < M <= 32 rows and K = 4096 (batch 3-32 decode: QKV, gate/up, lm_head), gfx950.
 //
-// skinny32_k re-stages the [32][K] activation block through LDS for every group of four output tiles, one workgroup
-// barrier per 512-deep stage, and its weight stream ran at ~3.9 TB/s. Here the activations never move after start-up:
+// The first version of this path (skinny32_k, round 1; removed in round 3) re-staged the [32][K] activation block through LDS for
+// every group of four output tiles, one workgroup barrier per 512-deep stage, and streamed weights at ~3.9 TB/s. Here the
+// activations never move after start-up:
 // 256 persistent 8-wave workgroups (one per CU), wave w owns the K range [512 w, 512 w + 512) and keeps the MFMA B-operand
 // fragments of all 32 rows for that range in registers (2 x 16 fragments = 128 VGPRs, read once per workgroup = 256 KiB
 // per CU from L2). The workgroup then walks output tiles t = blockIdx, blockIdx + grid, ...: per tile every wave streams its 16
@@ -9,7 +10,7 @@
 // one barrier per tile, after which all 512 threads reduce the 8 partials in a fixed order and run the epilogue while the
 // next tile's fragments are already landing (the ring is refilled fragment by fragment as the MFMAs consume it: 16 KiB
 // per wave = 128 KiB per CU in flight, no load ever waits for a barrier). fp8 weights (W8): 8 loads of 64-deep fragments per
-// tile, two tiles per trip so the same 16 KiB stay in flight. Same rounding points / epilogues as skinny32_k.
+// tile, two tiles per trip so the same 16 KiB stay in flight. Same rounding points / epilogues as the GEMV family (skinny_body.h).
 #include <type_traits>
 #include <algorithm>
 #include "rdx_common.h"

@@ -81,13 +81,19 @@ class RdxEngine:
 
     # ------------------------------------------------------------------------------------------------------------
     def _upload(self, items):
+        src = {torch.float32: _lib.RDX_SRC_F32, torch.float16: _lib.RDX_SRC_F16, torch.bfloat16: _lib.RDX_SRC_BF16}
         for name, t, kind in items:
-            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            # fp16 / bf16 tensors (a released checkpoint is stored that way) go to the library as they are: widened on the device,
+            # tensor by tensor (rdx_set_weight_typed), instead of through an fp32 copy made here
+            t = t.to(device=self.device).contiguous()
+            if t.dtype not in src:
+                t = t.to(torch.float32)
             if t.dim() == 1:
                 t = t.view(1, -1)
             rows, cols = t.shape[0], t.numel() // t.shape[0]
             torch.cuda.synchronize(self.device)
-            check(self.ctx, self.lib.rdx_set_weight(self.ctx, name.encode(), _ptr(t), rows, cols, kind), f"rdx_set_weight({name})")
+            check(self.ctx, self.lib.rdx_set_weight_typed(self.ctx, name.encode(), _ptr(t), src[t.dtype], rows, cols, kind),
+                  f"rdx_set_weight({name})")
             del t
 
     def load_weights(self, get: Callable[[str], torch.Tensor], vision: bool = True, llama: bool = True):
@@ -231,11 +237,19 @@ class RdxEngine:
         self.sync()
         return toks, logits
 
-    def decode_step(self, want_logits=True):
+    def decode_step(self, want_logits=True, input_ids: Optional[torch.Tensor] = None):
+        """One decode step on the token the previous step selected, or on caller-supplied `input_ids` int[B] (rdx_decode_step_ids)."""
         ids32, m32, qf, toks = self._keep["prefill"]
         B = ids32.shape[0]
         logits = torch.empty(B, self.cfg.llama.vocab, dtype=self.tdtype, device=self.device) if want_logits else None
-        check(self.ctx, self.lib.rdx_decode_step(self.ctx, _ptr(logits)), "rdx_decode_step")
+        if input_ids is None:
+            check(self.ctx, self.lib.rdx_decode_step(self.ctx, _ptr(logits)), "rdx_decode_step")
+        else:
+            forced = input_ids.to(device=self.device, dtype=torch.int32).contiguous().view(-1)
+            if forced.numel() != B:
+                raise ValueError(f"input_ids must hold one id per row ({B}), got {forced.numel()}")
+            torch.cuda.synchronize(self.device)
+            check(self.ctx, self.lib.rdx_decode_step_ids(self.ctx, _ptr(forced), _ptr(logits)), "rdx_decode_step_ids")
         self.sync()
         return toks, logits
 
@@ -345,12 +359,6 @@ class RdxEngine:
         """Debug: per-workgroup timestamps [tiles, 8] of one stand-alone decode GEMV (1 gate/up, 2 qkv, 4 down)."""
         buf = torch.zeros(max_tiles, 8, dtype=torch.int64)
         check(self.ctx, self.lib.rdx_gemv_trace(self.ctx, what, layer, buf.data_ptr(), max_tiles), "rdx_gemv_trace")
-        return buf
-
-    def mega_trace(self, max_wgs: int):
-        """Debug: per-workgroup {start, inputs ready, end, role} of one chained decode step (RDX_MEGA), int64 [max_wgs, 4]."""
-        buf = torch.zeros(max_wgs, 4, dtype=torch.int64)
-        check(self.ctx, self.lib.rdx_mega_trace(self.ctx, buf.data_ptr(), max_wgs), "rdx_mega_trace")
         return buf
 
 

@@ -67,7 +67,7 @@ class LlamaForCausalLM:
         self.max_batch, self.max_len = max_batch, max_len
         self.device = torch.device("cuda", device)
         self._engine = None
-        self._state = None            # reference-named fp32 tensors (dict); with _synthetic they overlay the random-init generator
+        self._state = None            # reference-named tensors (dict, stored dtype); with _synthetic they overlay the random-init generator
         self._synthetic = False       # only from_pretrained(synthetic=True) turns the deterministic random-init weights on
         self.training = False
 
@@ -124,6 +124,8 @@ class LlamaForCausalLM:
             self._state[k] = v.float()
             self._adapter_keys.add(k)
         self.lora = True
+        if self._engine is not None:               # an engine built before the adapter arrived: release its weight replica and KV cache
+            self._engine.close()
         self._engine = None
         return self
 
@@ -172,7 +174,13 @@ class LlamaForCausalLM:
             def get(name):
                 t = st[name].to(eng.device)
                 if name in ("model.embed_tokens.weight", "lm_head.weight") and t.shape[0] < V:   # resize_token_embeddings
-                    t = torch.cat([t, t.mean(0, keepdim=True).expand(V - t.shape[0], -1)], 0)
+                    # transformers 4.28.1 `_get_resized_embeddings` / `_get_resized_lm_head` -> `_init_weights`: the new rows are drawn
+                    # from normal(0, initializer_range = 0.02) (modeling_llama_imgemb.py:349-358). Drawn from a fixed-seed generator
+                    # here so that two loads agree; the <IMG> embedding row is never read (the splice replaces it), its lm_head row
+                    # gets a near-zero random logit like in the reference.
+                    g = torch.Generator().manual_seed(32000 + (0 if name.startswith("model.") else 1))
+                    new = torch.randn(V - t.shape[0], t.shape[1], generator=g) * 0.02
+                    t = torch.cat([t, new.to(t)], 0)
                 return t
         eng.load_weights(get, vision=False, llama=True)
         self._engine = eng
@@ -273,6 +281,14 @@ class PeftModelForCausalLM:
     def __getattr__(self, name):
         return getattr(self.base_model.model, name)
 
+    def __setattr__(self, name, value):
+        # peft's wrapper is an nn.Module whose attributes callers set on the wrapper (demo.py sets `reuse_prefix_kv`); everything but the
+        # wrapper's own `base_model` belongs to the wrapped LlamaForCausalLM, where generate() reads it
+        if name == "base_model":
+            object.__setattr__(self, name, value)
+        else:
+            setattr(self.base_model.model, name, value)
+
     def half(self):
         return self
 
@@ -285,17 +301,18 @@ class PeftModelForCausalLM:
 
 
 def _load_hf_dir(path: str):
-    """Read a local HF checkpoint directory (safetensors or .bin shards) into reference-named fp32 tensors."""
+    """Read a local HF checkpoint directory (safetensors or .bin shards) into reference-named tensors IN THE STORED DTYPE (Vicuna-7B:
+    fp16, 13.5 GB): nothing is inflated to fp32 on the host -- the engine widens tensor by tensor on the device (rdx_set_weight_typed)."""
     import glob
     out = {}
     files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
     if files:
         from safetensors.torch import load_file
         for f in files:
-            out.update({k: v.float() for k, v in load_file(f).items()})
+            out.update(load_file(f))
     else:
         for f in sorted(glob.glob(os.path.join(path, "pytorch_model*.bin"))):
-            out.update({k: v.float() for k, v in torch.load(f, map_location="cpu").items()})
+            out.update(torch.load(f, map_location="cpu"))
     if not out:
         raise OSError(f"no weights found under {path}")
     return out

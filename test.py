@@ -52,7 +52,18 @@ def main():
     dicoms = [f"synthetic-{i:05d}" for i in range(lo, hi)]
     tok = load_tokenizer(args.vicuna)
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
-    lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=dt, device_map="auto", max_batch=max(args.batch_size, 14 if args.do_cp_bin_qa else 1) * max(args.num_beams, 1),
+    # rows the engine must hold at once: the report loop runs batch_size prompts x num_beams beam rows; the binary QA pass is greedy
+    # (14 questions per study, test.py:548-590); the findings QA runs batches of 5 with beams (test.py:610-650). librdx holds <= 32 rows.
+    beams = max(args.num_beams, 1)
+    if beams > 8:
+        p.error(f"--num_beams {beams}: rdx_beam_search supports at most 8 beams")
+    if args.batch_size * beams > 32:
+        chunk = max(1, 32 // beams)
+        print(f"note: --batch_size {args.batch_size} x --num_beams {beams} exceeds the engine's 32 rows; the report loop runs in chunks of {chunk}")
+        args.batch_size = chunk
+    qa_batch = max(1, min(5, 32 // beams))
+    max_batch = max(args.batch_size * beams, 14 if args.do_cp_bin_qa else 0, qa_batch * beams if args.do_cp_all_qa else 0, beams, 1)
+    lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=dt, device_map="auto", max_batch=max_batch,
                                                   max_len=1024, device=local, synthetic=args.synthetic)
     if args.lora_model:
         lang_model = PeftModelForCausalLM.from_pretrained(lang_model, args.lora_model, torch_dtype=dt, use_ram_optimized_load=False).half()
@@ -101,7 +112,7 @@ def main():
             print(f"rank {rank}: binary QA label matrix {yn.shape}, positives {int(yn.sum())}")
         if args.do_cp_all_qa:
             oh = D.run_findings_qa(lang_model, tok, D.get_chexpert_prompts_all(list(preds_history), CHEXPERT_COLS), CHEXPERT_COLS, dc,
-                                   num_beams=args.num_beams)
+                                   batch_size=qa_batch, num_beams=args.num_beams)
             print(f"rank {rank}: findings QA label matrix {oh.shape}, positives {int(oh.sum())}")
     if rank == 0:
         print(f"generated {ids.shape[0]} reports x {ids.shape[1]} token slots on {world} GPU(s); first: {all_preds[0][:120]!r}")

@@ -23,6 +23,10 @@ ENC_TOL = {"f16": 5e-3, "bf16": 3e-2}
 # dtype (torch_dtype=float16, demo.py:225) and the parity dtype; bf16 (the bench dtype) rounds 8x coarser, so oracle near-ties
 # within two ulps -- the only place a token may legitimately differ -- are 8x more frequent and end a row's comparison earlier.
 MIN_COVER = {"f16": 0.9, "bf16": 0.75}
+# Legs of fewer than 48 (row, step) pairs (production-width batch 1: 5 pairs) cannot carry a percentage bar on their own: ONE legitimate
+# near-tie flip at an early step ends the row. Their logit tolerance and margin rule are asserted per leg; their identical-token counts
+# are summed here per dtype and the bar is applied to the sum by test_small_leg_token_identity_coverage at the end of this module.
+SMALL_LEGS = {"f16": Cover(), "bf16": Cover()}
 
 
 def _cpu_weights(cfg, lora=True):
@@ -120,8 +124,7 @@ def test_prefill_logits_and_kv_match_oracle(engine, cfg, cpu_w):
         assert int(t0[b]) == int(am[b]) or float(gaps[b]) <= 2 * float(err), f"row {b}: first token differs at margin {float(gaps[b])}"
 
 
-@pytest.mark.parametrize("use_graph", [False, True])
-def test_greedy_tokens_identical_to_oracle(engine, cfg, cpu_w, use_graph):
+def test_greedy_tokens_identical_to_oracle(engine, cfg, cpu_w):
     from oracle import ref_cpu
     dt = DT[engine.dtype]
     B, T, N = 3, 72, 12
@@ -130,9 +133,12 @@ def test_greedy_tokens_identical_to_oracle(engine, cfg, cpu_w, use_graph):
     orc = ref_cpu.LlamaOracle(cpu_w, cfg.llama, dt, lora=True)
     with torch.no_grad():
         ref = orc.generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
-    toks, scores, n = engine.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=use_graph)
-    assert n == N
-    check_greedy(toks, scores, ref, LOGIT_TOL[engine.dtype], MIN_COVER[engine.dtype], f"{engine.dtype} graph={use_graph}")
+    cover = Cover()
+    for use_graph in (False, True):
+        toks, scores, n = engine.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=use_graph)
+        assert n == N
+        cover.add(check_greedy(toks, scores, ref, LOGIT_TOL[engine.dtype], 0.0, f"{engine.dtype} graph={use_graph}"))
+    cover.check(MIN_COVER[engine.dtype], f"{engine.dtype} eager + graph")
 
 
 def test_eos_and_padding_rule(engine, cfg, cpu_w):
@@ -153,42 +159,41 @@ def test_eos_and_padding_rule(engine, cfg, cpu_w):
     nref = ref["tokens"].shape[1]
     # the engine checks for "all finished" every 16 steps, so it may run past the reference; extra tokens are pad
     assert n >= nref
-    check_greedy(toks, None, ref, LOGIT_TOL[engine.dtype], MIN_COVER[engine.dtype], f"{engine.dtype} eos")
+    # the subject here is the EOS / pad rule; the few pairs in front of the stop feed the per-dtype aggregate
+    SMALL_LEGS[engine.dtype].add(check_greedy(toks, None, ref, LOGIT_TOL[engine.dtype], 0.0, f"{engine.dtype} eos"))
     if torch.equal(toks[0, :3], ref["tokens"][0, :3]):
         assert int(toks[0, 3:].abs().sum()) == 0      # row 0 finished at step 2 -> pads afterwards
     assert int(toks[:, nref:].abs().sum()) == 0       # everything behind the reference's stop is padding
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-def test_fused_attention_oproj_launch_matches_oracle(cfg, cpu_w, monkeypatch, mode):
-    """RDX_FUSE_AO: decode attention and o_proj in ONE launch with a fence-free workgroup hand-off (write-through stores,
-    sharded arrival counter): 1 = 8-wave workgroups (csrc/fused.hip), 2 = 16-wave workgroups, two o_proj tiles each
-    (csrc/mega.hip). Must be exactly as accurate as the kernel-per-unit path."""
+@pytest.mark.parametrize("fused", [1, 0])
+def test_fused_attention_oproj_launch_matches_oracle(cfg, cpu_w, monkeypatch, fused):
+    """Batch <= 2: decode attention and o_proj in ONE launch of 16-wave workgroups with a fence-free hand-off (write-through stores,
+    sharded arrival counter; csrc/chain.hip: attn_oproj16_k) -- the default -- against RDX_FUSE_AO=0, one kernel per unit. Both must
+    be exactly as accurate."""
     from oracle import ref_cpu
     from radialog_amd.engine import RdxEngine, synth_getter
-    monkeypatch.setenv("RDX_FUSE_AO", str(mode))
+    monkeypatch.setenv("RDX_FUSE_AO", str(fused))
     eng = RdxEngine(cfg, dtype="f16", device=0, max_batch=4, max_len=256, lora=True, vision=False)
     eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
-    B, T, N = (3 if mode == 1 else 2), 72, 24
+    B, T, N = 2, 72, 24
     ids = _prompt(cfg, B, T, seed=33)
     qf = synth.synth("t.qf2", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
     with torch.no_grad():
         ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, torch.float16, lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1)
     for use_graph in (False, True):
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, use_graph=use_graph, output_scores=True)
-        check_greedy(toks, scores, ref, LOGIT_TOL["f16"], MIN_COVER["f16"], f"fused attention+o_proj mode {mode} graph={use_graph}")
+        check_greedy(toks, scores, ref, LOGIT_TOL["f16"], MIN_COVER["f16"], f"fused attention+o_proj {fused} graph={use_graph}")
     eng.close()
 
 
-@pytest.mark.parametrize("layers_per_launch,occ,B", [(-1, 8, 1), (-1, 4, 2), (1, 8, 2)])
-def test_chained_decode_layer_kernel_matches_oracle(cfg, cpu_w, monkeypatch, layers_per_launch, occ, B):
-    """RDX_MEGA: QKV GEMV -> attention -> o_proj -> gate/up -> down of all layers in one launch, units chained by
-    counter hand-offs instead of kernel boundaries (csrc/mega.hip). Tokens and logits must match the oracle exactly as
-    the kernel-per-unit path does."""
+@pytest.mark.parametrize("B,chain", [(1, 1), (2, 1), (1, 0), (2, 0)])
+def test_chained_down_qkv_launch_matches_oracle(cfg, cpu_w, monkeypatch, B, chain):
+    """Batch <= 2: down_proj(l) -> RMSNorm + QKV(l+1) as one chained launch per layer (csrc/chain.hip: decode_chain_k, fence-free
+    hand-off; the default) against RDX_CHAIN=0, one kernel per unit; attention + o_proj in the fused 16-wave launch."""
     from oracle import ref_cpu
     from radialog_amd.engine import RdxEngine, synth_getter
-    monkeypatch.setenv("RDX_MEGA", str(layers_per_launch))
-    monkeypatch.setenv("RDX_MEGA_OCC", str(occ))
+    monkeypatch.setenv("RDX_CHAIN", str(chain))
     T, N = 72, 24
     ids = _prompt(cfg, B, T, seed=33)
     qf = synth.synth("t.qf2", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
@@ -198,31 +203,11 @@ def test_chained_decode_layer_kernel_matches_oracle(cfg, cpu_w, monkeypatch, lay
         with torch.no_grad():
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1)
         tol = LOGIT_TOL[dtype]
+        cover = Cover()
         for use_graph in (False, True):
             toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, output_scores=True, use_graph=use_graph)
-            check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"{dtype}")
-        eng.close()
-
-
-@pytest.mark.parametrize("B,mode", [(1, 1), (2, 1), (2, 2), (1, 0)])
-def test_chained_mlp_qkv_launch_matches_oracle(cfg, cpu_w, monkeypatch, B, mode):
-    """RDX_CHAIN: 1 = gate/up(l) -> down(l) -> qkv(l+1), 2 (the default at batch <= 2) = down(l) -> qkv(l+1) as one chained
-    launch per layer (roles of csrc/mega.hip with the fence-free hand-off), 0 = one kernel per unit; attention + o_proj in
-    the fused 16-wave launch."""
-    from oracle import ref_cpu
-    from radialog_amd.engine import RdxEngine, synth_getter
-    monkeypatch.setenv("RDX_CHAIN", str(mode))
-    T, N = 72, 24
-    ids = _prompt(cfg, B, T, seed=33)
-    qf = synth.synth("t.qf2", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
-    for dtype in ("f16", "bf16"):
-        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=2, max_len=256, lora=True, vision=False)
-        eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
-        with torch.no_grad():
-            ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1)
-        tol = LOGIT_TOL[dtype]
-        toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, output_scores=True, use_graph=True)
-        check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"{dtype}")
+            cover.add(check_greedy(toks, scores, ref, tol, 0.0, f"{dtype} chain={chain} graph={use_graph}"))
+        cover.check(MIN_COVER[dtype], f"{dtype} chain={chain}")
         eng.close()
 
 
@@ -247,8 +232,9 @@ def test_step_graph_replays_after_generate_keep_the_handoff_sound(engine, cfg):
 
 @pytest.mark.parametrize("kperm", [1, 0])
 def test_batch18_greedy_tokens_match_oracle(cfg, cpu_w, kperm, monkeypatch):
-    """16 < batch <= 32 takes the LDS-staged weight-streaming GEMM (csrc/skinny32.hip) for every decode projection and
-    the lm_head, and the 4-wave throughput attention; tokens and logits must match the oracle row by row."""
+    """16 < batch <= 32 at widths the activation-stationary kernels do not cover (they are built for K = 4096): the generic two-row-tile
+    GEMV family for every decode projection and the lm_head, and the 4-wave throughput attention; tokens and logits must match the
+    oracle row by row."""
     from oracle import ref_cpu
     from radialog_amd.engine import RdxEngine, synth_getter
     # K cache layout (read at rdx_create): 16-position fragment order (small contexts) / row-major (what batch * heads > 256 gets)
@@ -332,7 +318,10 @@ off the exact value where torch's CPU FMA chain leaves 0.03 %, tests/diag/mfma_r
         tol = PROD_TOL[dtype] * layers ** 0.5        # accumulation-order noise adds up layer by layer (two layers: 1.4e-2 in fp16)
         if fp8:     # the streaming kernels scale the fp32 sum of e4m3 products; the oracle's weights are T(q * scale), each rounded to the model dtype
             tol *= 2.0
-        cmp_, tot, e_ho = check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"B={B} {dtype} fp8={fp8} layers={layers}")
+        leg = check_greedy(toks, scores, ref, tol, MIN_COVER[dtype] if B * N >= 48 else 0.0, f"B={B} {dtype} fp8={fp8} layers={layers}")
+        if B * N < 48:
+            SMALL_LEGS[dtype].add(leg)
+        cmp_, tot, e_ho = leg
         tk = toks.cpu().long()
         if truth is None:
             print(f"production width B={B} {dtype} fp8={fp8} layers={layers}: compared {cmp_}/{tot}, |hip-oracle| {e_ho:.4g}")
@@ -348,6 +337,88 @@ off the exact value where torch's CPU FMA chain leaves 0.03 %, tests/diag/mfma_r
         eng.close()
 
 
+def test_unplanted_lm_head_teacher_forced_margin_rule(cfg, cpu_w):
+    """The identity legs above run on synth.py's planted lm_head (64 decisive rows, so that identical tokens can be DEMANDED). This leg
+    uses an ordinary random-init head -- every row std 0.02 like transformers' `_init_weights` (modeling_llama_imgemb.py:349-358), top-2
+    gaps of a few 1e-2 -- so that the claim is not tied to the planted margin distribution: teacher-forced through 24 steps, every
+    step's logits within the tolerance, and every step whose oracle margin exceeds twice the measured error must pick the oracle's
+    token. How many steps that decides is printed, not demanded."""
+    from oracle import ref_cpu
+    from radialog_amd.engine import RdxEngine, synth_getter
+    H = cfg.llama.hidden
+    plain = synth.synth("t.plain_lm_head", (cfg.llama.vocab, H), -0.02 * 3 ** 0.5, 0.02 * 3 ** 0.5)
+    W = dict(cpu_w)
+    W["lm_head.weight"] = plain
+    B, T, N = 3, 72, 24
+    ids = _prompt(cfg, B, T, seed=61)
+    qf = synth.synth("t.qfplain", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    for dtype in ("f16", "bf16"):
+        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=128, lora=True, vision=False)
+        base = synth_getter(cfg, eng.device, lora=True)
+        eng.load_weights(lambda name: plain.to(eng.device) if name == "lm_head.weight" else base(name), vision=False)
+        with torch.no_grad():
+            ref = ref_cpu.LlamaOracle(W, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
+        same, total, worst = _teacher_forced(eng, ref, ids, qf, N, LOGIT_TOL[dtype], f"plain head {dtype}")
+        decided = int((ref["margins"] > 2 * worst).sum())
+        print(f"unplanted lm_head {dtype}: {same}/{total} argmax tokens identical, {decided}/{total} steps have a margin above 2 x the worst "
+              f"logit error {worst:.4g} (median oracle margin {float(ref['margins'].median()):.4g})")
+        assert same >= decided                       # every decided step was identical (the helper asserted it step by step)
+        eng.close()
+
+
+def _teacher_forced(eng, ref, ids, qf, N, tol, label):
+    """Decode N steps feeding the ORACLE's tokens (rdx_decode_step_ids), so that every step's inputs are the oracle's and every
+    (row, step) pair is compared -- a free-running comparison ends a row at its first near-tie flip, long before position 416.
+    Per step: logits within tol; the engine's own argmax equals the oracle's token unless the oracle's margin is <= 2 x the measured
+    logit error of that step. Returns (identical, total, worst error)."""
+    rt = ref["tokens"]
+    B = rt.shape[0]
+    toks, lg = eng.prefill(ids, qf, max_new=N, eos_id=-1)
+    same, worst = 0, 0.0
+    for s in range(N):
+        if s > 0:
+            _, lg = eng.decode_step(input_ids=rt[:, s - 1])
+        lgc = lg.float().cpu()
+        assert not torch.isnan(lgc).any(), f"{label} step {s}: NaN logits"
+        err = (lgc - ref["scores"][s].float()).abs().amax(dim=1)
+        worst = max(worst, float(err.max()))
+        assert float(err.max()) < tol, f"{label} step {s} (position {ids.shape[1] + s}): logits differ by {float(err.max()):.4g} (tolerance {tol})"
+        am = lgc.argmax(dim=1)
+        for b in range(B):
+            if int(am[b]) == int(rt[b, s]):
+                same += 1
+            else:
+                margin = float(ref["margins"][s, b])
+                assert margin <= 2.0 * float(err[b]) + 1e-7, (f"{label} row {b} step {s}: token {int(am[b])} != oracle {int(rt[b, s])} at margin "
+                                                              f"{margin:.4g}, which a logit error of {float(err[b]):.4g} cannot flip")
+    return same, B * N, worst
+
+
+@pytest.mark.parametrize("B,N,dtypes", [(1, 256, ("f16", "bf16")), (32, 64, ("f16", "bf16")), (4, 64, ("bf16",))])
+def test_production_width_decode_over_the_bench_positions_teacher_forced(B, N, dtypes):
+    """The positions bench.py decodes through -- 160 -> 416 at batch 1 (256 steps), 160 -> 224 at batch 32 and 4 -- at production
+    width (hidden 4096, inter 11008, vocab 32001; one layer so that the oracle finishes in seconds), every step compared
+    (teacher forcing through rdx_decode_step_ids; modeling_llama_imgemb.py:187-250,:705-793): decode attention's register window and
+    tail loops, the RoPE rows and the KV appends at every one of those positions, the batch-1 chained launches / batch 3-32
+    activation-stationary kernels in eager mode."""
+    from oracle import ref_cpu
+    from radialog_amd.engine import RdxEngine, synth_getter
+    cfg, cpu_w = _production_width_weights(1)
+    T = 160
+    ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, pad_rows=(B > 1), seed=7)
+    qf = synth.synth("t.qftf", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    for dtype in dtypes:
+        with torch.no_grad():
+            ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
+        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=(T + N + 31) // 32 * 32, lora=True, vision=False)
+        eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+        same, total, worst = _teacher_forced(eng, ref, ids, qf, N, PROD_TOL[dtype], f"B={B} {dtype}")
+        eng.close()
+        print(f"teacher-forced production width B={B} {dtype}: {same}/{total} argmax tokens identical over positions {T}..{T + N - 1}, "
+              f"worst logit error {worst:.4g}")
+        assert same >= MIN_COVER[dtype] * total, f"B={B} {dtype}: only {same}/{total} steps chose the oracle's token"
+
+
 @pytest.mark.parametrize("B,tp", [(1, 0), (3, 0), (3, 1)])
 def test_long_context_decode_streams_past_the_register_window(cfg, cpu_w, B, tp, monkeypatch):
     """Multi-turn prompts (test.py:440-674: report + follow-up question, 400-700 tokens) put the context beyond the 480
@@ -360,7 +431,6 @@ def test_long_context_decode_streams_past_the_register_window(cfg, cpu_w, B, tp,
     T, N = 600, 6
     ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, pad_rows=False, seed=11)
     qf = synth.synth("t.qfL", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
-    cover = Cover()
     for dtype in ("f16", "bf16"):
         eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=640, lora=True, vision=False)
         eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
@@ -368,7 +438,7 @@ def test_long_context_decode_streams_past_the_register_window(cfg, cpu_w, B, tp,
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
         tol = LOGIT_TOL[dtype]
-        check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"{dtype}")
+        SMALL_LEGS[dtype].add(check_greedy(toks, scores, ref, tol, 0.0, f"{dtype} T={T} B={B}"))
         eng.close()
 
 
@@ -431,8 +501,8 @@ def test_multi_turn_prefix_kv_reuse_matches_full_recompute_and_oracle(cfg, cpu_w
         with torch.no_grad():
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True).generate_greedy(ids2, qf, max_new=N2, eos_id=-1, pad_id=0)
         tol = LOGIT_TOL[dtype]
-        check_greedy(t2, s2, ref, tol, MIN_COVER[dtype], f"{dtype} reuse path vs oracle")
-        check_greedy(t2f, s2f, ref, tol, MIN_COVER[dtype], f"{dtype} full prefill vs oracle")
+        SMALL_LEGS[dtype].add(check_greedy(t2, s2, ref, tol, 0.0, f"{dtype} reuse path vs oracle"))
+        SMALL_LEGS[dtype].add(check_greedy(t2f, s2f, ref, tol, 0.0, f"{dtype} full prefill vs oracle"))
         same = (t2 == t2f.cpu().long()).long().cumprod(1).bool()           # steps up to the first difference share their inputs
         assert float(((s2 - s2f.float().cpu()).abs().amax(-1).T * same).max()) < tol, f"{dtype}: reuse path vs full prefill"
         # a third turn whose prompt diverges inside the cached part keeps only the common prefix
@@ -496,7 +566,7 @@ def test_fp8_weight_decode_matches_fake_quantised_oracle(cfg, cpu_w, B):
             ref = ref_cpu.LlamaOracle(Wq, cfg.llama, DT[dtype], lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
         tol = LOGIT_TOL[dtype]
-        check_greedy(toks, scores, ref, tol, MIN_COVER[dtype], f"{dtype}")
+        SMALL_LEGS[dtype].add(check_greedy(toks, scores, ref, tol, 0.0, f"{dtype} fp8 B={B}"))
         eng.close()
 
 
@@ -517,3 +587,14 @@ def test_decode_step_refuses_to_walk_past_the_reserved_slots(cfg):
     eng.generate(ids, None, max_new=4, eos_id=-1)
     assert eng.lib.rdx_decode_step(eng.ctx, None) != 0          # a completed generate leaves nothing to step through
     eng.close()
+
+
+def test_small_leg_token_identity_coverage():
+    """Runs last in this module: the identical-token counts of every leg too short for a percentage bar of its own (SMALL_LEGS), summed per
+    dtype, against the same bars as the long legs -- 90 % fp16, 75 % bf16. (Running this test alone finds nothing to check and skips.)"""
+    if SMALL_LEGS["f16"].total + SMALL_LEGS["bf16"].total == 0:
+        pytest.skip("no short legs ran in this session")
+    for dtype, cover in SMALL_LEGS.items():
+        if cover.total:
+            print(f"short legs {dtype}: {cover.compared}/{cover.total} pairs identical")
+            cover.check(MIN_COVER[dtype], f"{dtype} short legs")

@@ -138,3 +138,42 @@ def test_reusable_prefix_rules_for_multi_turn_kv_reuse():
     assert f(g) == 0                                             # diverges before the <IMG> block ends -> <IMG> in the remainder
     eng._conv = None
     assert f(torch.cat([seq, tail], 1)) == 0
+
+
+def test_peft_wrapper_forwards_attribute_writes_to_the_wrapped_model():
+    """demo.py sets `lang_model.reuse_prefix_kv = True` on whatever init_vicuna returned -- with --lora_model that is the
+    PeftModelForCausalLM wrapper, and generate() reads the flag on the inner LlamaForCausalLM."""
+    from radialog_amd.config import small_cfg
+    from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM, PeftModelForCausalLM
+    inner = LlamaForCausalLM(cfg=small_cfg().llama, dtype="f16", max_batch=1, max_len=64)
+    w = PeftModelForCausalLM(inner)
+    assert not getattr(inner, "reuse_prefix_kv", False)
+    w.reuse_prefix_kv = True
+    assert inner.reuse_prefix_kv is True and w.reuse_prefix_kv is True
+    assert "reuse_prefix_kv" not in w.__dict__ and w.base_model.model is inner
+    w.half().eval()
+    assert w.base_model.model is inner
+
+
+def test_test_py_sizes_the_engine_for_beams_and_downstream_passes():
+    """test.py's max_batch arithmetic: rows = batch x beams for the report loop, 14 greedy rows for the binary QA, 5 x
+    beams for the findings QA, never more than librdx's 32 rows -- the report loop is chunked instead."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "test.py")).read()
+    body = src[src.index("    beams = max(args.num_beams, 1)"): src.index("    lang_model = LlamaForCausalLM.from_pretrained(")]
+    body = re.sub(r"^    ", "", body, flags=re.M)
+
+    def size(batch_size, num_beams, bin_qa=False, all_qa=False):
+        from types import SimpleNamespace
+        ns = {"args": SimpleNamespace(batch_size=batch_size, num_beams=num_beams, do_cp_bin_qa=bin_qa, do_cp_all_qa=all_qa),
+              "p": SimpleNamespace(error=lambda m: (_ for _ in ()).throw(SystemExit(m))), "print": lambda *a, **k: None}
+        exec(body, ns)
+        return ns["max_batch"], ns["args"].batch_size, ns["qa_batch"]
+
+    assert size(12, 1) == (12, 12, 5)
+    assert size(12, 3) == (30, 10, 5)                       # 36 rows would not fit: chunks of 10 prompts x 3 beams
+    assert size(12, 3, bin_qa=True) == (30, 10, 5)          # the greedy binary QA needs 14 rows, not 14 x 3
+    assert size(2, 1, bin_qa=True) == (14, 2, 5)
+    assert size(1, 8, all_qa=True) == (32, 1, 4)            # findings QA: 4 prompts x 8 beams
+    for args_ in ((12, 1), (12, 3, True, True), (32, 2), (5, 8, True, True)):
+        assert size(*args_)[0] <= 32
