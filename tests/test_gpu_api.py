@@ -135,3 +135,46 @@ def test_rccl_allgather_inside_the_c_abi_single_rank():
     with pytest.raises(RdxError):
         eng.comm_init(eng.comm_unique_id(), 0, 1)                 # already initialised
     eng.close()
+
+
+def test_peft_wrapper_chat_turns_take_the_append_path():
+    """demo.py sets `reuse_prefix_kv` on what init_vicuna returned; with --lora_model that is the PeftModelForCausalLM wrapper. The flag
+    must reach the wrapped model: the second turn keeps the cached prefix (rdx_generate_append) instead of re-prefilling the whole
+    conversation."""
+    from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM, PeftModelForCausalLM
+    cfg = small_cfg()
+    inner = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.float16, cfg=cfg.llama, max_batch=1, max_len=256, synthetic=True)
+    lm = PeftModelForCausalLM(inner).eval()
+    lm.reuse_prefix_kv = True
+    qf = synth.synth("t.peftwrap", (1, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    ids1 = synth.synth_prompt_ids(1, 48, vocab=cfg.llama.vocab, img_offset=4)
+    o1 = lm.generate(input_ids=ids1, qformer_embs=qf, return_dict_in_generate=True, max_new_tokens=5, eos_token_id=-1)
+    assert inner._engine.last_kept_prefix == 0
+    follow = torch.randint(3, 31999, (1, 9), generator=torch.Generator().manual_seed(3))
+    ids2 = torch.cat([o1.sequences.cpu(), follow], dim=1)
+    o2 = lm.generate(input_ids=ids2, qformer_embs=qf, return_dict_in_generate=True, max_new_tokens=4, eos_token_id=-1)
+    assert inner._engine.last_kept_prefix == o1.sequences.shape[1] - 1
+    fresh = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.float16, cfg=cfg.llama, max_batch=1, max_len=256, synthetic=True).eval()
+    f2 = fresh.generate(input_ids=ids2, qformer_embs=qf, return_dict_in_generate=True, max_new_tokens=4, eos_token_id=-1)
+    assert torch.equal(o2.sequences, f2.sequences)
+    inner._engine.close(); fresh._engine.close()
+
+
+def test_set_weight_typed_is_bit_identical_to_the_widened_fp32_upload():
+    """rdx_set_weight_typed (include/rdx.h): a checkpoint stored in fp16 goes to the library as it is. Same tokens and the same logit
+    BITS as uploading the fp32-widened tensors (which is what round 2 did after inflating the whole checkpoint on the host)."""
+    from radialog_amd.engine import RdxEngine, synth_getter
+    cfg = small_cfg()
+    ids = synth.synth_prompt_ids(2, 48, vocab=cfg.llama.vocab, img_offset=4)
+    qf = synth.synth("t.typed", (2, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    outs = []
+    for stored in (torch.float16, torch.bfloat16):
+        for as_typed in (True, False):
+            eng = RdxEngine(cfg, dtype="bf16", device=0, max_batch=2, max_len=128, vision=False)
+            base = synth_getter(cfg, eng.device)
+            get = (lambda n: base(n).to(stored)) if as_typed else (lambda n: base(n).to(stored).float())
+            eng.load_weights(get, vision=False)
+            toks, sc, n = eng.generate(ids, qf, max_new=6, eos_id=-1, output_scores=True)
+            outs.append((toks.cpu().clone(), sc.cpu().clone()))
+            eng.close()
+        assert torch.equal(outs[-2][0], outs[-1][0]) and torch.equal(outs[-2][1].view(torch.int16), outs[-1][1].view(torch.int16))
