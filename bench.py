@@ -224,14 +224,8 @@ def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms
         eng.encode_image(img, want_image_embeds=False)
     enc_ms = (time.perf_counter() - t1) / 5 / B * 1e3
 
-    def wbytes(n_rows, k):        # bytes per streamed weight element of a decode projection (mirrors the library's dispatch)
-        if not args.fp8:
-            return 2
-        tiles = (n_rows + 15) // 16
-        lds = B <= 16 and B * k * 2 <= 32 * 1024                     # batch-1..4 GEMV with LDS-staged activations
-        s32 = 16 < B <= 32 and tiles > 512 and k % 512 == 0          # skinny32.hip
-        xs = 3 <= B <= 32 and ((tiles >= 512 and k == 4096) or (128 <= tiles <= 512 and k in (4096, 11008)))   # xstat32.hip
-        return 1 if (lds or s32 or xs) else 2
+    def wbytes(n_rows, k):        # bytes per streamed weight element of a decode projection: the fp8 engine holds (and streams) e4m3 only
+        return 1 if args.fp8 else 2
 
     torch.cuda.synchronize()
     t2 = time.perf_counter()
@@ -250,15 +244,15 @@ def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms
         try:
             ms = eng.time_unit(7, 8)               # in situ: 8 eager decode steps, an event pair around each of the 32 chained launches
             nb = H_ * I_ * wbytes(H_, I_) + (3 * H_ + 2 * lc.lora_r) * H_ * wbytes(3 * H_ + 16, H_) + B * (I_ + 2 * H_ + 3 * H_ + 16) * 2 + H_ * 2
-            dom = (f"decode_layers_k<{args.dtype}{',W8' if wbytes(H_, I_) == 1 else ''}> (chained down_proj(l) -> RMSNorm+QKV(l+1) launch, fence-free hand-off)",
+            dom = (f"decode_chain_k<{args.dtype}{',W8' if wbytes(H_, I_) == 1 else ''}> (chained down_proj(l) -> RMSNorm+QKV(l+1) launch, fence-free hand-off)",
                    ms, nb, f"decode_layers_k B={B} {args.dtype}{' fp8' if args.fp8 else ''}")
         except Exception:
             dom = None
     if dom is None:
         ms = eng.time_unit(1, 10)
         wb = wbytes(2 * I_, H_)
-        nb = 2 * I_ * H_ * wb + B * H_ * 2 + H_ * 2 + B * I_ * 2
-        nm = (f"xstat32_k<{args.dtype},EPI_SILU_MUL{',W8' if wb == 1 else ''}> (gate/up SwiGLU, activation-stationary batch 3-32 GEMM)" if B > 2 else
+        nb = 2 * I_ * H_ * wb + B * H_ * wb + H_ * 2 + B * I_ * 2
+        nm = (f"xstat32_k<{args.dtype},EPI_SILU_MUL{',W8,A8 (fp8 x fp8 MFMA)' if wb == 1 else ''}> (gate/up SwiGLU, activation-stationary batch 3-32 GEMM)" if B > 2 else
               f"skinny_gemm_k<{args.dtype},MT,EPI_SILU_MUL,NORM{',W8' if wb == 1 else ''}> (gate/up SwiGLU GEMV)")
         dom = (nm, ms, nb, f"gate_up B={B} {args.dtype}{' fp8' if args.fp8 else ''}")
     name, k_ms, k_bytes, key = dom

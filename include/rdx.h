@@ -175,7 +175,9 @@ int rdx_gemv_trace(rdx_ctx* ctx, int what, int layer, long long* host, int max_t
  * 2 = tiled_gemm_k, 3 = gemm_dma_k, 4 = skinny with fp8 (e4m3 + per-row scale) weights, 5 = the batch 3-32 K-split path (epi 3 only:
  * pack X, xsplit32_k, slab combine + residual), 6 = 5 with fp8 weights, 7 = the encoder's many-row kernel wsgemm_k (K % 64 == 0, epi 0-3 / 6;
  * RDX_WS_CFG=A..H forces a tile shape), 8 = the single prompt's weight-stationary kernel wstat_k (K = 4096 / 11008, epi 0 / 3 / 4: the rows are
- * RMS-normalised or just re-laid into the fragment-packed order by rmsnorm_k<T, 3>, then streamed past the register-resident weights).
+ * RMS-normalised or just re-laid into the fragment-packed order by rmsnorm_k<T, 3>, then streamed past the register-resident weights),
+ * 9 / 10 / 11 = the fp8 path's prefill GEMM gemm8 (e4m3 weights x e4m3 activations with 1 / 2 / 4 K groups; K % 64 == 0, epi 0 / 3 / 4).
+ * force 4 / 6 hold the fp8 weights as the engine does (e4m3 bytes + scales only): batch >= 3 shapes multiply fp8 x fp8.
  * Test / benchmark hook. */
 int rdx_gemm_test(rdx_ctx* ctx, const void* X, const float* W, const float* bias, const void* resid, void* out, int M, int N,
                   int K, int epi, const void* norm_w, float eps, int force);

@@ -238,16 +238,48 @@ def positions_from_mask(mask: torch.Tensor) -> torch.Tensor:
     return pos.masked_fill(mask == 0, 1)
 
 
+def fake_quant_e4m3(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
+    """fp32 values of x after OCP e4m3 quantisation along the last dim: one absmax / 448 scale per row and K group, group q = 64-deep
+    chunks [KC q / G, KC (q + 1) / G) -- q = RNE((x * (448 / absmax))), value = q * (absmax / 448); an all-zero range keeps scale 1.
+    The arithmetic of librdx's pack_weight_fp8_k / quant_rows_k / rmsnorm -> fp8 (the fp8 weight path of BASELINE configs[4])."""
+    xf = x.float()
+    K = xf.shape[-1]
+    KC = K // 64
+    out = torch.empty_like(xf)
+    for q in range(groups):
+        a = (KC * q // groups) * 64
+        b = K if q == groups - 1 else (KC * (q + 1) // groups) * 64
+        seg = xf[..., a:b]
+        am = seg.abs().amax(dim=-1, keepdim=True)
+        inv = torch.where(am > 0, 448.0 / am, torch.ones_like(am))
+        sc = torch.where(am > 0, am / 448.0, torch.ones_like(am))
+        out[..., a:b] = (seg * inv).to(torch.float8_e4m3fn).float() * sc
+    return out
+
+
 class LlamaOracle:
-    def __init__(self, W: Dict[str, torch.Tensor], cfg, dtype=torch.float16, lora: bool = True, exact: bool = False):
+    def __init__(self, W: Dict[str, torch.Tensor], cfg, dtype=torch.float16, lora: bool = True, exact: bool = False, fp8: bool = False):
         """W: fp32 (or already-rounded) tensors keyed by reference state_dict names; cast to `dtype` here
         the way `.half()` does for every floating parameter/buffer (demo.py:234).
         exact=True: the same op sequence and the same rounding points, but every contraction (linear layers, Q.K^T, P.V)
         is accumulated in fp64 before its single rounding to `dtype` -- the order-independent value both torch's CPU
         kernels (fp32 accumulation in their blocking order) and the HIP kernels (fp32 MFMA accumulation in theirs)
-        approximate. Used by the parity tests to bound each side's accumulation-order noise."""
-        self.cfg, self.dtype, self.exact = cfg, dtype, exact
+        approximate. Used by the parity tests to bound each side's accumulation-order noise.
+        fp8=True: the reference math on the engine's fp8 weight path (RdxEngine(weights_fp8=True), BASELINE configs[4]; the reference itself
+        has no fp8 mode -- this is the fake-quantised restatement its parity is defined against): the seven decoder projections
+        (+ LoRA-A, fused into QKV by the engine) and lm_head use e4m3 weights with one scale per output row; their INPUT activations are
+        e4m3 too -- one scale per row and K group (1 group behind an RMSNorm, 2 for o_proj, 4 for down_proj) -- wherever the engine multiplies
+        fp8 x fp8: every projection of a prefill, and decode / lm_head at batch >= 3 (batch <= 2 expands the weights in registers and keeps
+        model-dtype activations). Products of the quantised values are accumulated in fp32 and rounded once to `dtype`."""
+        self.cfg, self.dtype, self.exact, self.fp8 = cfg, dtype, exact, fp8
         self.W = {k: v.to(dtype) for k, v in W.items()}
+        self.W8 = {}
+        if fp8:
+            for k, v in W.items():
+                if k == "lm_head.weight" or (k.startswith("model.layers.") and v.dim() == 2 and
+                                             (k.endswith("_proj.weight") or k.endswith("lora_A.weight"))):
+                    self.W8[k] = fake_quant_e4m3(v)
+        self._a8 = False                       # set per forward() call: are this pass's projections fp8 x fp8?
         self.lora = lora and any("lora_A" in k for k in W)
         self.cos, self.sin = rope_tables(cfg.head_dim, cfg.max_pos, cfg.rope_base, dtype)
 
@@ -262,12 +294,23 @@ class LlamaOracle:
             return torch.matmul(a, b)
         return torch.matmul(a.double(), b.double()).to(a.dtype)
 
+    def _lin(self, x, key, groups=1, a8=None):
+        """Linear layer `key`: plain in the model dtype, or -- fp8 mode, quantised layer -- e4m3 weights (and e4m3 activations when this
+        pass multiplies fp8 x fp8), fp32 (exact: fp64) accumulation, one rounding."""
+        if key not in self.W8:
+            return self._linear(x, self.W[key])
+        a8 = self._a8 if a8 is None else a8
+        xin = fake_quant_e4m3(x, groups) if a8 else x.float()
+        w = self.W8[key]
+        y = F.linear(xin.double(), w.double()) if self.exact else F.linear(xin, w)
+        return y.to(x.dtype)
+
     def _proj(self, x, L, nm):
         W = self.W
-        y = self._linear(x, W[L + f"self_attn.{nm}.weight"])
+        y = self._lin(x, L + f"self_attn.{nm}.weight")
         a_key = L + f"self_attn.{nm}.lora_A.weight"
         if self.lora and a_key in W:
-            y = y + self._linear(self._linear(x, W[a_key]), W[L + f"self_attn.{nm}.lora_B.weight"]) * self.cfg.lora_scale
+            y = y + self._linear(self._lin(x, a_key), W[L + f"self_attn.{nm}.lora_B.weight"]) * self.cfg.lora_scale
         return y
 
     def embed(self, ids: torch.Tensor, qformer_embs: Optional[torch.Tensor]) -> torch.Tensor:
@@ -322,10 +365,10 @@ class LlamaOracle:
         s = torch.max(s, torch.tensor(torch.finfo(s.dtype).min))
         p = F.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
         o = self._mm(p, v).transpose(1, 2).reshape(B, T, H)
-        x = x + self._linear(o, W[L + "self_attn.o_proj.weight"])
+        x = x + self._lin(o, L + "self_attn.o_proj.weight", groups=2)
         h = rmsnorm(x, W[L + "post_attention_layernorm.weight"], c.rms_eps)
-        g = F.silu(self._linear(h, W[L + "mlp.gate_proj.weight"])) * self._linear(h, W[L + "mlp.up_proj.weight"])
-        x = x + self._linear(g, W[L + "mlp.down_proj.weight"])
+        g = F.silu(self._lin(h, L + "mlp.gate_proj.weight")) * self._lin(h, L + "mlp.up_proj.weight")
+        x = x + self._lin(g, L + "mlp.down_proj.weight", groups=4)
         return x, (k, v)
 
     def forward(self, x, key_mask, pos_ids, past=None, all_logits=False, n_layers=None):
@@ -334,6 +377,8 @@ class LlamaOracle:
         T = x.shape[1]
         pl = 0 if past is None else past[0][0].shape[2]
         mask = self._mask(key_mask, T, pl)
+        # fp8 mode: a prefill (more than one token per row, or nothing cached) runs every projection fp8 x fp8; a decode step from batch 3
+        self._a8 = self.fp8 and (past is None or T > 1 or x.shape[0] >= 3)
         new_past = []
         nl = self.cfg.layers if n_layers is None else n_layers
         for l in range(nl):
@@ -342,7 +387,8 @@ class LlamaOracle:
         self.last_hidden = x                                   # decoder output before the final norm (diagnostics)
         h = rmsnorm(x, self.W["model.norm.weight"], self.cfg.rms_eps)
         hl = h if all_logits else h[:, -1:]
-        logits = self._linear(hl, self.W["lm_head.weight"])
+        # lm_head runs on the [B][H] last-position rows in prefill and decode alike: fp8 x fp8 from batch 3
+        logits = self._lin(hl, "lm_head.weight", a8=self.fp8 and x.shape[0] >= 3)
         return logits, new_past, h
 
     # -- greedy loop (transformers==4.28.1 GenerationMixin.greedy_search, restated) --------------------

@@ -122,10 +122,9 @@ extern "C" int rdx_set_weight(rdx_ctx* c, const char* name, const float* data, i
         if (c->gemm.count(key)) return fail(c, -1, "rdx_set_weight(%s): duplicate", name);
         GemmW w;
         w.N = (int)rows; w.K = (int)cols; w.Npad = (int)((rows + 15) / 16 * 16);
-        ALLOC(c, w.w, (size_t)w.Npad * w.K * esz(c));            // dequantised copy (prefill, batch > 4)
-        ALLOC(c, w.w8, (size_t)w.Npad * w.K);
+        ALLOC(c, w.w8, (size_t)w.Npad * w.K);                     // the ONLY copy: e4m3 bytes + one scale per row (w.w stays null)
         ALLOC(c, w.scale, (size_t)w.Npad * sizeof(float));
-        launch_pack_weight_fp8(c->cfg.dtype, data, w.w8, w.scale, w.w, w.N, w.K, w.Npad, c->stream);
+        launch_pack_weight_fp8(c->cfg.dtype, data, w.w8, w.scale, nullptr, w.N, w.K, w.Npad, c->stream);
         c->gemm[key] = w;
     } else if (kind == RDX_W_TENSOR) {
         if (c->tens.count(key)) return fail(c, -1, "rdx_set_weight(%s): duplicate", name);
@@ -265,6 +264,7 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         ALLOC(c, c->part_idx, (size_t)B * c->n_vtiles * sizeof(int));
         ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)(B > 2 ? std::max(B, 32) : B) * H * 2);
         if (B > 2) ALLOC(c, c->kslab, (size_t)4 * 32 * H * sizeof(float)); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
+        ALLOC(c, c->dxs, 32 * sizeof(float));
         ALLOC(c, c->datt, (size_t)(B > 2 ? std::max(B, 32) : B) * H * 2); ALLOC(c, c->dgu, (size_t)(B > 2 ? std::max(B, 32) : B) * I * 2);
         ALLOC(c, c->pqe, (size_t)B * 32 * f.qformer_dim * 2); ALLOC(c, c->pimg, (size_t)B * 32 * H * 2);      // image splice rows
     }

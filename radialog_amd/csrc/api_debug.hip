@@ -128,9 +128,10 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
         // projections whose RMSNorm is a launch of its own (rows beyond the GEMV's LDS stage: batch > 4): normalise once,
         // outside the timed region, and time the GEMM launches alone
         int xpk = -1;
+        GemmArgs pn;
         auto pre = [&](GemmArgs a, int epi) {
-            if (xpk < 0) { const GemmArgs p = skinny_prenorm(c, a, epi); xpk = p.norm_w ? 0 : (p.X == c->dxn ? 1 + p.xpacked : 0); }
-            if (xpk > 0) { a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr; a.xpacked = xpk - 1; }
+            if (xpk < 0) { pn = skinny_prenorm(c, a, epi); xpk = pn.norm_w ? 0 : (pn.X == c->dxn ? 1 + pn.xpacked : 0); }
+            if (xpk > 0) { a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr; a.xpacked = xpk - 1; a.xscale = pn.xscale; a.xgroups = pn.xgroups; }
             return a;
         };
         if (what == 1) { GemmArgs a = gargs(c->dx, H, c->ll[0].wgu, nullptr, c->dgu, f.inter, B); a.norm_w = c->ll[0].mlp_norm; a.eps = f.rms_eps; pre(a, EPI_SILU_MUL); }
@@ -260,6 +261,20 @@ extern "C" int rdx_l2_bench(rdx_ctx* c, int mode, long long bytes_per_wg, int sh
     return 0;
 }
 
+// fp8 weights at batch >= 3 multiply fp8 x fp8 (xstat32_k<W8, A8>): [RMSNorm +] e4m3 quantisation of the rows into the 32-row fragment block,
+// like skinny_prenorm does in the decode step; `tmp` (caller frees) holds the block and its 32 scales
+static int fp8_block_for_test(rdx_ctx* c, GemmArgs& a, int epi, char** tmp) {
+    *tmp = nullptr;
+    if (!(a.W8 && a.wscale) || a.M < xs_min_rows()) return 0;
+    GemmArgs t = a; t.norm_w = nullptr;
+    if (!xstat32_supported(t, epi)) return 0;
+    HIPCHK(c, hipMalloc((void**)tmp, (size_t)32 * a.K + 32 * sizeof(float)));
+    float* xs = (float*)(*tmp + (size_t)32 * a.K);
+    launch_rmsnorm_packed32_fp8(c->cfg.dtype, const_cast<void*>(a.X), a.norm_w, *tmp, xs, a.M, a.K, a.eps, nullptr, 0, c->stream);
+    a.X = *tmp; a.ldx = a.K; a.xpacked = 4; a.xscale = xs; a.xgroups = 1; a.norm_w = nullptr;
+    return 0;
+}
+
 // One bare GEMM through the production kernels (unit tests / kernel benchmarks): out = epilogue(X . W^T).
 // X, resid, norm_w, out are model-dtype device tensors; W [N][K] and bias [N] are fp32 device tensors (W is packed here).
 extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const float* bias, const void* resid, void* out,
@@ -270,8 +285,31 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
     GemmW w;
     w.N = N; w.K = K; w.Npad = N;
     void* wp = nullptr;
-    HIPCHK(c, hipMalloc(&wp, (size_t)N * K * 2 + (force == 4 ? (size_t)N * K + (size_t)N * 4 : 0)));
+    HIPCHK(c, hipMalloc(&wp, (size_t)N * K * 2 + ((force == 4 || (force >= 9 && force <= 11)) ? (size_t)N * K + (size_t)N * 4 : 0)));
     w.w = wp;
+    if (force >= 9 && force <= 11) {
+        // the fp8 path's prefill GEMM (gemm8.hip): e4m3 weights x e4m3 activations with 1 / 2 / 4 K groups; RMSNorm -> fp8 (one group) or quant_rows_k
+        const int G = force == 9 ? 1 : (force == 10 ? 2 : 4);
+        if (K % 64 || (norm_w && G != 1)) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: gemm8 needs K %% 64 == 0 (and one K group behind an RMSNorm)"); }
+        w.w = nullptr; w.w8 = (char*)wp + (size_t)N * K * 2; w.scale = (float*)((char*)wp + (size_t)N * K * 3);
+        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, nullptr, N, K, N, c->stream);
+        char* tmp = nullptr;
+        HIPCHK(c, hipMalloc((void**)&tmp, (size_t)M * K + (size_t)M * 4 * sizeof(float)));
+        float* xs = (float*)(tmp + (size_t)M * K);
+        if (norm_w) launch_rmsnorm_fp8(c->cfg.dtype, X, norm_w, tmp, xs, M, K, eps, c->stream);
+        else launch_quant_rows(c->cfg.dtype, X, K, tmp, xs, M, K, G, c->stream);
+        GemmArgs a = gargs(tmp, K, w, nullptr, out, epi == EPI_SILU_MUL ? N / 2 : N, M);
+        a.resid = resid; a.ldr = N; a.xscale = xs; a.xgroups = G;
+        int rc = 0;
+        if (!gemm8_supported(a, epi)) rc = fail(c, -1, "rdx_gemm_test: shape / epilogue not supported by gemm8");
+        else launch_gemm8(c->cfg.dtype, a, epi, c->stream);
+        hipError_t se = hipStreamSynchronize(c->stream);
+        hipFree(wp); hipFree(tmp);
+        if (rc) return rc;
+        HIPCHK(c, se);
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
     if (force == 4) {                     // fp8 weights: quantise here, stream the e4m3 bytes
         if (K % 64) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: fp8 needs K %% 64 == 0"); }
         w.w8 = (char*)wp + (size_t)N * K * 2;
@@ -289,8 +327,8 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
         if (K % 64) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: fp8 needs K %% 64 == 0"); }
         hipFree(wp);
         HIPCHK(c, hipMalloc(&wp, (size_t)N * K * 3 + (size_t)N * 4));
-        w.w = wp; w.w8 = (char*)wp + (size_t)N * K * 2; w.scale = (float*)((char*)wp + (size_t)N * K * 3);
-        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, wp, N, K, N, c->stream);
+        w.w = nullptr; w.w8 = (char*)wp + (size_t)N * K * 2; w.scale = (float*)((char*)wp + (size_t)N * K * 3);
+        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, nullptr, N, K, N, c->stream);
         a = gargs(X, K, w, bias, out, N, M);
         a.resid = resid; a.ldr = N; a.eps = eps;
         split8 = true; force = 5;
@@ -340,12 +378,19 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
     if (use_skinny) {
         if (M > 32) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: skinny path needs M <= 32"); }
         void* keep = c->dxn;                       // skinny() pre-normalises into c->dxn when the rows do not fit the LDS
+        char* blk = nullptr;
+        int brc = fp8_block_for_test(c, a, epi, &blk);
+        if (brc) { hipFree(wp); return brc; }
         if (a.norm_w && !skinny_fits_lds(M, K)) {
             HIPCHK(c, hipMalloc(&xn, (size_t)32 * K * 2));
             c->dxn = xn;
         }
         skinny(c, a, epi == EPI_RESID_RELU ? EPI_RESID : epi);
         c->dxn = keep;
+        hipError_t se = hipStreamSynchronize(c->stream);
+        if (blk) hipFree(blk);
+        if (int urc = take_unsupported(c)) { hipFree(wp); if (xn) hipFree(xn); return urc; }
+        HIPCHK(c, se);
     } else {
         if (a.norm_w) {
             HIPCHK(c, hipMalloc(&xn, (size_t)M * K * 2));
@@ -383,18 +428,24 @@ extern "C" int rdx_logits_test(rdx_ctx* c, const void* X, const float* W, int M,
     HIPCHK(c, hipMalloc((void**)&wp, wb + qb + 2 * pb + (size_t)M * K * 2));
     w.w = wp;
     if (fp8) {
-        w.w8 = wp + wb; w.scale = (float*)(wp + wb + (size_t)N * K);
-        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, wp, N, K, N, c->stream);
+        w.w = nullptr; w.w8 = wp + wb; w.scale = (float*)(wp + wb + (size_t)N * K);
+        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, nullptr, N, K, N, c->stream);
     } else {
         launch_pack_weight(c->cfg.dtype, W, wp, N, K, N, nullptr, c->stream);
     }
     GemmArgs a = gargs(X, K, w, nullptr, out_logits, N, M);
     a.n_valid = n_valid;
     a.part_val = (float*)(wp + wb + qb); a.part_idx = (int*)(wp + wb + qb + pb);
-    launch_skinny_gemm(c->cfg.dtype, a, EPI_LOGITS, c->stream);
+    char* blk = nullptr;
+    int brc = fp8_block_for_test(c, a, EPI_LOGITS, &blk);
+    if (brc) { hipFree(wp); return brc; }
+    skinny(c, a, EPI_LOGITS);
     std::vector<float> pv((size_t)M * nt);
     std::vector<int> pi((size_t)M * nt);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipError_t se = hipStreamSynchronize(c->stream);
+    if (blk) hipFree(blk);
+    if (int urc = take_unsupported(c)) { hipFree(wp); return urc; }
+    HIPCHK(c, se);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpy(pv.data(), a.part_val, pb, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(pi.data(), a.part_idx, pb, hipMemcpyDeviceToHost));

@@ -29,8 +29,12 @@ GemmArgs skinny_prenorm(rdx_ctx* c, GemmArgs a, int epi) {
         // a K-split projection before this one left its residual epilogue to this RMSNorm (xsplit32_k): x += T(sum of slabs)
         const int pend = (x == c->dx) ? c->pend_groups : 0;
         if (pend) c->pend_groups = 0;
-        if (xstat32_supported(a, epi)) {       // the normalised rows go straight into the consumer's register-fragment order
-            a.xpacked = (a.W8 && a.wscale) ? 2 : 1;
+        if (xstat32_supported(a, epi) && a.W8 && a.wscale) {
+            // fp8 weights: the normalised rows are quantised to e4m3 (one scale per row) in the consumer's 64-deep fragment order: fp8 x fp8 MFMA
+            a.xpacked = 4; a.xscale = c->dxs; a.xgroups = 1;
+            launch_rmsnorm_packed32_fp8(c->cfg.dtype, const_cast<void*>(x), nw, c->dxn, c->dxs, a.M, a.K, a.eps, pend ? c->kslab : nullptr, pend, c->stream);
+        } else if (xstat32_supported(a, epi)) {       // the normalised rows go straight into the consumer's register-fragment order
+            a.xpacked = 1;
             launch_rmsnorm_packed32(c->cfg.dtype, const_cast<void*>(x), nw, c->dxn, a.M, a.K, a.eps, a.xpacked, pend ? c->kslab : nullptr, pend, c->stream);
         } else if (pend) {
             launch_rmsnorm_packed32(c->cfg.dtype, const_cast<void*>(x), nw, c->dxn, a.M, a.K, a.eps, 0, c->kslab, pend, c->stream);
@@ -42,7 +46,27 @@ GemmArgs skinny_prenorm(rdx_ctx* c, GemmArgs a, int epi) {
 }
 
 void skinny(rdx_ctx* c, GemmArgs a, int epi) {
-    launch_skinny_gemm(c->cfg.dtype, skinny_prenorm(c, a, epi), epi, c->stream);
+    a = skinny_prenorm(c, a, epi);
+    if (!a.W && a.W8) {
+        // fp8-only weights: the kernels that read e4m3 are the batch <= 2 GEMV with LDS-staged activations (expanded in registers) and, from
+        // batch 3, the activation-stationary fp8 x fp8 kernel (K = 4096, many tiles). Anything else has no kernel in this mode.
+        const bool gemv8 = skinny_fits_lds(a.M, a.K) && a.K % 64 == 0 && a.M < xs_min_rows();
+        const bool xs8 = a.xpacked == 4 && xstat32_supported(a, epi);
+        if (!gemv8 && !xs8) {
+            char buf[200];
+            snprintf(buf, sizeof(buf), "fp8 weights: no kernel for a %d x %d x %d projection at this batch (batch <= 2: M K <= 16 Ki; batch 3-32: K = 4096)", a.M, a.N, a.K);
+            c->unsupported = buf;
+            return;
+        }
+    }
+    launch_skinny_gemm(c->cfg.dtype, a, epi, c->stream);
+}
+
+int take_unsupported(rdx_ctx* c) {
+    if (c->unsupported.empty()) return 0;
+    const int rc = fail(c, -8, "%s", c->unsupported.c_str());
+    c->unsupported.clear();
+    return rc;
 }
 
 // batch 3-32 decode: gate/up (xstat32_k) can hand its SwiGLU output to down_proj fragment-packed, and down_proj then runs
@@ -58,7 +82,8 @@ bool down_split_ok(rdx_ctx* c, const LlamaLayer& L, int B) {
 
 // A K-split projection (o_proj, down_proj at batch 3-32): its fp32 slabs stay pending for the stand-alone RMSNorm of the
 // projection that follows (skinny_prenorm), which adds them, rounds and applies the residual.
-void launch_ksplit(rdx_ctx* c, const GemmArgs& a) {
+void launch_ksplit(rdx_ctx* c, const GemmArgs& a_in) {
+    const GemmArgs& a = a_in;        // (fp8 weights: every K-group workgroup quantises its range of the activations to e4m3 -- fp8 x fp8)
     launch_xsplit32(c->cfg.dtype, a, c->kslab, c->stream);
     c->pend_groups = xsplit32_groups(a);
 }
@@ -76,6 +101,7 @@ void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split) {
 }
 
 void run_gemm(rdx_ctx* c, GemmArgs a, int epi) {
+    if (!a.W && a.W8 && a.M > 32) { c->unsupported = "fp8 weights: this GEMM has no fp8 kernel (only the Llama projections are quantised)"; return; }
     ConvGeom cg;
     memset(&cg, 0, sizeof(cg));
     if (a.M <= 32) skinny(c, a, epi == EPI_RESID_RELU ? EPI_RESID : epi);

@@ -12,7 +12,11 @@ static int ensure_prefill_ws(rdx_ctx* c, size_t rows) {
     // release the old buffers, then allocate; a failure leaves prefill_rows = 0 so the next call starts over
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->prefill_rows = 0;
-    dfree(c, c->px); dfree(c, c->pxn); dfree(c, c->pqkv); dfree(c, c->pq); dfree(c, c->patt); dfree(c, c->pgu);
+    dfree(c, c->px); dfree(c, c->pxn); dfree(c, c->pqkv); dfree(c, c->pq); dfree(c, c->patt); dfree(c, c->pgu); dfree(c, c->pxq); dfree(c, c->pxs);
+    if (fp8_weights(c->ll[0].wqkv)) {       // e4m3 activations of the fp8 x fp8 prefill GEMMs (gemm8.hip) and their per-(row, K group) scales
+        ALLOC(c, c->pxq, rows * (size_t)std::max(f.hidden, f.inter));
+        ALLOC(c, c->pxs, rows * 4 * sizeof(float));
+    }
     ALLOC(c, c->px, rows * f.hidden * 2); ALLOC(c, c->pxn, rows * f.hidden * 2);
     ALLOC(c, c->pqkv, rows * c->ld.qkv_ld * 2); ALLOC(c, c->pq, rows * f.hidden * 2);
     ALLOC(c, c->patt, rows * f.hidden * 2); ALLOC(c, c->pgu, rows * f.inter * 2);
@@ -79,6 +83,39 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
     }
     launch_embed_splice(dt, ids, c->d_img_pos, c->embed, f.vocab, c->pimg, 32, c->px, B, T, H, qformer_embs ? 1 : 0, s);
 
+    const bool fp8 = fp8_weights(c->ll[0].wqkv);
+    if (fp8) {
+        // fp8 weights (BASELINE configs[4]): every projection of the prompt is an fp8 x fp8 MFMA GEMM (gemm8.hip) over e4m3 activations with one
+        // scale per row and K group -- 1 group behind an RMSNorm (quantised in its epilogue), 2 for o_proj, 4 for down_proj (quant_rows_k on the
+        // attention / SwiGLU output); LoRA-B, RoPE, attention, SwiGLU and the residual adds stay in the model dtype
+        for (int l = 0; l < f.layers; ++l) {
+            const LlamaLayer& L = c->ll[l];
+            void* kc = kv_ptr(c, c->kcache, l);
+            void* vc = kv_ptr(c, c->vcache, l);
+            auto g8 = [&](const GemmW& W, int K, int groups, void* out, int ldo, const void* resid, int epi) {
+                GemmArgs a = gargs(c->pxq, K, W, nullptr, out, ldo, (int)M);
+                a.N = W.Npad; a.xscale = c->pxs; a.xgroups = groups; a.resid = resid; a.ldr = H;
+                if (!gemm8_supported(a, epi)) { c->unsupported = "fp8 weights: prefill projection shape not supported by gemm8 (N % 16, K % 64)"; return; }
+                launch_gemm8(dt, a, epi, s);
+            };
+            launch_rmsnorm_fp8(dt, c->px, L.attn_norm, c->pxq, c->pxs, (int)M, H, f.rms_eps, s);
+            g8(L.wqkv, H, 1, c->pqkv, c->ld.qkv_ld, nullptr, EPI_NONE);
+            launch_rope_kv_prefill(dt, c->ld, c->pqkv, L.lora_bq, L.lora_bv, c->rope_cos, c->rope_sin, c->d_pos_ids, c->pq, kc, vc, B, T, keep, s);
+            AttnArgs at;
+            memset(&at, 0, sizeof(at));
+            at.Q = c->pq; at.q_bs = (long)T * H; at.q_ts = H; at.q_hs = 128;
+            at.K = kc; at.V = vc; at.k_bs = at.v_bs = (long)f.heads * f.max_len * 128; at.k_ts = at.v_ts = 128; at.k_hs = at.v_hs = (long)f.max_len * 128;
+            at.O = c->patt; at.o_bs = (long)T * H; at.o_ts = H; at.o_hs = 128;
+            at.B = B; at.H = f.heads; at.Tq = T; at.Tk = keep + T; at.causal = 1; at.k_perm = c->ld.k_perm; at.key_mask = c->key_mask; at.km_bs = f.max_len;
+            launch_attention(dt, 128, at, s);
+            launch_quant_rows(dt, c->patt, H, c->pxq, c->pxs, (int)M, H, 2, s);
+            g8(L.wo, H, 2, c->px, H, c->px, EPI_RESID);
+            launch_rmsnorm_fp8(dt, c->px, L.mlp_norm, c->pxq, c->pxs, (int)M, H, f.rms_eps, s);
+            g8(L.wgu, H, 1, c->pgu, f.inter, nullptr, EPI_SILU_MUL);
+            launch_quant_rows(dt, c->pgu, f.inter, c->pxq, c->pxs, (int)M, f.inter, 4, s);
+            g8(L.wdown, f.inter, 4, c->px, H, c->px, EPI_RESID);
+        }
+    } else {
     // few rows (one or two prompts): the projections are weight-stream bound -> weight-stationary kernels over fragment-packed
     // activations (wstat.hip); the producers (RMSNorm, attention, the SwiGLU epilogue) write that order directly
     const int mtl = (int)((M + 15) / 16);
@@ -122,10 +159,11 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
         { GemmArgs a = gargs(c->pxn, H, L.wgu, nullptr, c->pgu, f.inter, (int)M); prompt_gemm(a, EPI_SILU_MUL, true); }
         { GemmArgs a = gargs(c->pgu, f.inter, L.wdown, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H; prompt_gemm(a, EPI_RESID, false); }
     }
+    }
     launch_gather_last(dt, c->px, c->datt, B, T, H, s);      // datt doubles as the [B][H] last-position buffer
     lm_head_and_greedy(c, c->datt, B, logits, nullptr, 0, /*advance=*/0);
     HIPCHK(c, hipGetLastError());
-    return 0;
+    return take_unsupported(c);
 }
 
 extern "C" int rdx_prefill(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int T, const float* qformer_embs,
@@ -213,7 +251,7 @@ extern "C" int rdx_decode_step(rdx_ctx* c, void* logits) {
     decode_step_launch(c, logits, nullptr, 0);
     ++c->cur_steps;
     HIPCHK(c, hipGetLastError());
-    return 0;
+    return take_unsupported(c);
 }
 
 // The caller drives the loop and supplies the token itself (what LlamaForCausalLM.forward(input_ids = [B, 1], past_key_values = ...) is
@@ -232,7 +270,7 @@ extern "C" int rdx_decode_step_ids(rdx_ctx* c, const int32_t* ids, void* logits)
     decode_step_launch(c, logits, nullptr, 0);
     ++c->cur_steps;
     HIPCHK(c, hipGetLastError());
-    return 0;
+    return take_unsupported(c);
 }
 
 int build_graph(rdx_ctx* c, void* scores, bool fixed) {
@@ -245,6 +283,7 @@ int build_graph(rdx_ctx* c, void* scores, bool fixed) {
     HIPCHK(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
     decode_step_launch(c, scores, (scores && !fixed) ? c->d_step : nullptr, (long)c->cur_B * f.vocab);
     HIPCHK(c, hipStreamEndCapture(c->stream, &g));
+    if (int urc = take_unsupported(c)) { hipGraphDestroy(g); return urc; }
     HIPCHK(c, hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
     HIPCHK(c, hipGraphDestroy(g));
     c->gkey = k;

@@ -223,6 +223,8 @@ __global__ __launch_bounds__(256) void attention_k(AttnArgs a, int TkP) {
 }
 
 void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s) {
+    // many prompts of head_dim 128 (the batched Llama prefill): 64-query flash-style blocks (flash.hip)
+    if (flash_prefill_supported(head_dim, a)) { launch_flash_prefill(dtype, a, s); return; }
     const int TkP = (a.Tk + 31) & ~31;
     const size_t smem = (size_t)16 * TkP * 2 + std::max((size_t)16 * TkP * 4, (size_t)4 * 2 * 16 * 36 * 2);     // P, then S / the waves' transposed V patches
     dim3 grid((a.Tq + 15) / 16, a.H, a.B), block(256);

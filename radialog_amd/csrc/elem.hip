@@ -5,15 +5,67 @@
 
 namespace rdx {
 
+// ---- e4m3 activation quantisation of the fp8 path (gemm8.hip, xstat32.hip): q = RNE_e4m3(x * (448 / absmax)), scale = absmax / 448 ----------
+// (the arithmetic of pack_weight_fp8_k and of the oracle's fake quantisation: an all-zero range gets scale 1)
+// where the 8 fp8 bytes of elements i .. i + 8 of row `row` go. PACK 5: row-major [rows][H]. PACK 4: the 32-row block in the 64-deep fragment
+// order xstat32_k<W8, A8> reads, [chunk j = i / 64][row tile mt][lane (g = (i % 64) / 16, r = row % 16)][16 bytes], this piece's half i & 8
+template <int PACK> __device__ __forceinline__ unsigned char* dst8(unsigned char* out8, size_t row, int i, int H) {
+    if (PACK == 5) return out8 + row * H + i;
+    return out8 + ((size_t)(((i >> 6) * 2 + (int)(row >> 4)) * 64 + ((i & 63) >> 4) * 16 + (int)(row & 15)) << 4) + (i & 8);
+}
+
+// Row-wise e4m3 quantisation of model-dtype activations [rows][K] (row stride ldx) into row-major bytes [rows][K] + scales [rows][G]:
+// K group q = 64-deep chunks [KC q / G, KC (q + 1) / G) (G <= 4), one absmax / 448 scale per (row, group). One workgroup per row.
+template <typename T>
+__global__ __launch_bounds__(256) void quant_rows_k(const T* __restrict__ x, long ldx, unsigned char* __restrict__ out8, float* __restrict__ xscale,
+                                                    int K, int G) {
+    typedef typename Vec8<T>::type V8;
+    __shared__ float red[32];
+    __shared__ float gmax[4];
+    const size_t row = blockIdx.x;
+    const T* xr = x + row * ldx;
+    const int KC = K >> 6;
+    int end[4];                                                 // first element past group q
+#pragma unroll
+    for (int q = 0; q < 4; ++q) end[q] = q < G ? ((KC * (q + 1)) / G) * 64 : K;
+    auto group_of = [&](int i) { return (i >= end[0]) + (i >= end[1]) + (i >= end[2]); };
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x * 8; i < K; i += blockDim.x * 8) {
+        const float m = amax8<T>(as_vec8<T>(ldg16(xr + i)));
+        const int gq = group_of(i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mx[q] = (q == gq) ? fmaxf(mx[q], m) : mx[q];
+    }
+    for (int q = 0; q < G; ++q) {
+        const float m = block_max(mx[q], red);
+        if (threadIdx.x == 0) gmax[q] = m;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < G) { float sc, inv; fp8_scale(gmax[threadIdx.x], sc, inv); xscale[row * G + threadIdx.x] = sc; }
+    for (int i = threadIdx.x * 8; i < K; i += blockDim.x * 8) {
+        float sc, inv;
+        fp8_scale(gmax[group_of(i)], sc, inv);
+        const u2 q = quant8<T>(as_vec8<T>(ldg16(xr + i)), inv);
+        *reinterpret_cast<u2*>(out8 + row * K + i) = q;
+    }
+}
+
+void launch_quant_rows(int dtype, const void* x, long ldx, void* out8, float* xscale, int rows, int K, int groups, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((quant_rows_k<T>), dim3(rows), dim3(256), 0, s, (const T*)x, ldx, (unsigned char*)out8, xscale, K, groups));
+}
+
 // ---- LlamaRMSNorm (modeling_llama_imgemb.py:85-93): fp32 statistics, (x*rstd).to(T), then weight*h in T ---------------
 // PACK != 0 (batch-32 decode, consumer xstat32_k): the output is written in the MFMA B-operand fragment order of the 32-row
 // block, [fragment f][row tile mt][lane (g, r)][8], so that a wave's activation fragment is one contiguous KiB. A thread's 8
 // elements k = i .. i + 8 of row m are exactly one lane's piece: PACK 1 (32-deep fragments): f = i / 32, g = (i % 32) / 8;
 // PACK 2 (the fp8 weights' 64-deep chunks): f = 2 (i / 64) + (i % 16) / 8, g = (i % 64) / 16. Rows >= n_rows are zero-filled.
 // PACK 3 (one prompt's prefill, consumer wstat_k): the PACK 1 order over `groups` row tiles instead of 2 (no slabs on that path).
+// PACK 4 / 5 (fp8 path): the normalised row is quantised to e4m3 with ONE absmax / 448 scale (xscale[row]); 5 = row-major bytes (prefill,
+// gemm8.hip), 4 = the 32-row block in the 64-deep fragment order (batch 3-32 decode, xstat32_k<W8, A8>); rows >= n_rows are zero bytes, scale 1.
 template <typename T, int PACK>
 __global__ __launch_bounds__(256) void rmsnorm_k(const T* x, const T* __restrict__ w, T* __restrict__ out,
-                                                 int H, float eps, int n_rows, const float* __restrict__ slab, int groups, T* xw) {
+                                                 int H, float eps, int n_rows, const float* __restrict__ slab, int groups, T* xw,
+                                                 float* __restrict__ xscale = nullptr) {
     typedef typename Vec8<T>::type V8;
     __shared__ float red[32];
     const size_t row = blockIdx.x;
@@ -22,7 +74,12 @@ __global__ __launch_bounds__(256) void rmsnorm_k(const T* x, const T* __restrict
         const int f = PACK != 2 ? (i >> 5) : (2 * (i >> 6) + ((i & 15) >> 3)), g = PACK != 2 ? ((i & 31) >> 3) : ((i & 63) >> 4);
         return out + ((size_t)((f * (PACK == 3 ? groups : 2) + (int)(row >> 4)) * 64 + g * 16 + (int)(row & 15)) << 3);
     };
-    if (PACK && (int)row >= n_rows) {
+    if (PACK >= 4 && (int)row >= n_rows) {
+        for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(reinterpret_cast<unsigned char*>(out), row, i, H)) = (u2){0u, 0u};
+        if (threadIdx.x == 0) xscale[row] = 1.0f;
+        return;
+    }
+    if (PACK && PACK < 4 && (int)row >= n_rows) {
         for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) stg16(dst(i), (u4){0u, 0u, 0u, 0u});
         return;
     }
@@ -50,18 +107,27 @@ __global__ __launch_bounds__(256) void rmsnorm_k(const T* x, const T* __restrict
     }
     ss = block_sum(ss, red);
     const float rs = rsqrtf(ss / (float)H + eps);
-    for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) {
+    auto normed = [&](int i) -> V8 {
         V8 v = as_vec8<T>(ldg16(xr + i));
+        if (!w) return v;                           // w == null: re-layout only (test hook)
         V8 o;
-        if (w) {
-            V8 wv = as_vec8<T>(ldg16(w + i));
+        V8 wv = as_vec8<T>(ldg16(w + i));
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof<T>(wv[j]) * rnd<T>(tof<T>(v[j]) * rs));
-        } else {
-            o = v;                                  // w == null: re-layout only (test hook)
-        }
-        stg16(dst(i), as_u4<T>(o));
+        for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof<T>(wv[j]) * rnd<T>(tof<T>(v[j]) * rs));
+        return o;
+    };
+    if (PACK >= 4) {
+        float am = 0.f;
+        for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) am = fmaxf(am, amax8<T>(normed(i)));
+        am = block_max(am, red);
+        float sc, inv;
+        fp8_scale(am, sc, inv);
+        if (threadIdx.x == 0) xscale[row] = sc;
+        for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8)
+            *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(reinterpret_cast<unsigned char*>(out), row, i, H)) = quant8<T>(normed(i), inv);
+        return;
     }
+    for (int i = threadIdx.x * 8; i < H; i += blockDim.x * 8) stg16(dst(i), as_u4<T>(normed(i)));
 }
 
 
@@ -73,7 +139,7 @@ void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, i
 // statistics and the scaling. Same arithmetic and rounding points as rmsnorm_k.
 template <typename T, int PACK>
 __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __restrict__ w, T* __restrict__ out, float eps, int n_rows,
-                                                     const float* __restrict__ slab, int groups, T* xw) {
+                                                     const float* __restrict__ slab, int groups, T* xw, float* __restrict__ xscale = nullptr) {
     typedef typename Vec8<T>::type V8;
     constexpr int H = 4096;
     __shared__ float red[32];
@@ -84,7 +150,14 @@ __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __rest
         return out + ((size_t)((f * (PACK == 3 ? groups : 2) + (int)(row >> 4)) * 64 + g * 16 + (int)(row & 15)) << 3);
     };
     const int i0 = threadIdx.x * 8, i1 = i0 + 2048;
-    if (PACK && (int)row >= n_rows) {
+    if (PACK >= 4 && (int)row >= n_rows) {
+        unsigned char* o8 = reinterpret_cast<unsigned char*>(out);
+        *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row, i0, H)) = (u2){0u, 0u};
+        *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row, i1, H)) = (u2){0u, 0u};
+        if (threadIdx.x == 0) xscale[row] = 1.0f;
+        return;
+    }
+    if (PACK && PACK < 4 && (int)row >= n_rows) {
         stg16(dst(i0), (u4){0u, 0u, 0u, 0u});
         stg16(dst(i1), (u4){0u, 0u, 0u, 0u});
         return;
@@ -123,13 +196,23 @@ __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __rest
         for (int j = 0; j < 8; ++j) { const float f = tof<T>(v[k][j]); ss += f * f; }
     ss = block_sum(ss, red);
     const float rs = rsqrtf(ss / (float)H + eps);
+    V8 o[2];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        V8 o;
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = fromf<T>(tof<T>(wv[k][j]) * rnd<T>(tof<T>(v[k][j]) * rs));
-        stg16(dst(k ? i1 : i0), as_u4<T>(o));
+        for (int j = 0; j < 8; ++j) o[k][j] = fromf<T>(tof<T>(wv[k][j]) * rnd<T>(tof<T>(v[k][j]) * rs));
+    if (PACK >= 4) {
+        const float am = block_max(fmaxf(amax8<T>(o[0]), amax8<T>(o[1])), red);
+        float sc, inv;
+        fp8_scale(am, sc, inv);
+        if (threadIdx.x == 0) xscale[row] = sc;
+        unsigned char* o8 = reinterpret_cast<unsigned char*>(out);
+        *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row, i0, H)) = quant8<T>(o[0], inv);
+        *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row, i1, H)) = quant8<T>(o[1], inv);
+        return;
     }
+    stg16(dst(i0), as_u4<T>(o[0]));
+    stg16(dst(i1), as_u4<T>(o[1]));
 }
 
 void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, int rows, int mtiles, int H, float eps, hipStream_t s) {
@@ -150,6 +233,30 @@ void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows
     }
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T, 0>), dim3(rows), dim3(256), 0, s, (const T*)x, (const T*)w,
                                                 (T*)out, H, eps, rows, (const float*)nullptr, 0, (T*)nullptr));
+}
+
+// RMSNorm -> e4m3 row-major bytes [rows][H] + one scale per row (the fp8 path's prefill: input of the QKV / gate-up gemm8 launches)
+void launch_rmsnorm_fp8(int dtype, const void* x, const void* w, void* out8, float* xscale, int rows, int H, float eps, hipStream_t s) {
+    if (H == 4096 && w) {
+        RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm4096_k<T, 5>), dim3(rows), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out8, eps, rows,
+                                                    (const float*)nullptr, 0, (T*)nullptr, xscale));
+        return;
+    }
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T, 5>), dim3(rows), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out8, H, eps, rows,
+                                                (const float*)nullptr, 0, (T*)nullptr, xscale));
+}
+
+// ... and the batch 3-32 decode form: rows <= 32 into the fragment-packed 32-row fp8 block of xstat32_k<W8, A8> + xscale[32], with the pending
+// K-split slabs folded in first like launch_rmsnorm_packed32
+void launch_rmsnorm_packed32_fp8(int dtype, void* x, const void* w, void* out8, float* xscale, int rows, int H, float eps, const float* slab,
+                                 int groups, hipStream_t s) {
+    if (H == 4096 && w && groups <= 4) {
+        RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm4096_k<T, 4>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out8, eps, rows, slab,
+                                                    groups, (T*)x, xscale));
+        return;
+    }
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T, 4>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out8, H, eps, rows, slab,
+                                                groups, (T*)x, xscale));
 }
 
 void launch_rmsnorm_packed32(int dtype, void* x, const void* w, void* out, int rows, int H, float eps, int pack, const float* slab,

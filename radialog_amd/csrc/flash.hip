@@ -1,0 +1,220 @@
+// Flash-style prefill attention for head_dim 128 (the Llama prompt: causal + key-padding mask), gfx950.
+//
+// attention_k (attn.hip) gives a workgroup 16 queries, splits their key tiles over its four waves and exchanges the scores through
+// LDS ([16][Tk] fp32 + [16][Tk] probabilities): at batch 32 (10 240 workgroups of 10 key tiles) it is bound by VALU issue and by its
+// per-workgroup fixed costs -- 107 us per layer for 0.1 us of MFMA work (profiles/r02_bench_b32_kernel_stats.md). Here a WAVE owns 16
+// queries for their whole key range, so nothing but V crosses waves and the softmax statistics never leave registers:
+//
+//   pass 1  S^T = K Q^T per 16-key tile on the matrix cores (A = K fragment straight from the cache layout, B = the wave's Q
+//           fragments; D[key][query]: a lane holds 4 keys of ONE query), scores rounded like the reference, running row maximum and
+//           sum of exponentials per lane, combined over the four lane groups of a query once at the end;
+//   pass 2  S^T again (the reference rounds the probabilities AFTER normalising by the whole-row sum -- `softmax(..., dtype=float32)
+//           .to(query_states.dtype)`, modeling_llama_imgemb.py:229-233 -- so P needs the row statistics first; recomputing 4 MFMAs
+//           per tile is cheaper than keeping [64][Tk] scores), P = T(exp(s - m) / l), O^T += V^T P^T.
+//           The MFMA k-slot -> key assignment of the P.V product is free (a sum over keys): slot j of lane group g is key
+//           16 (j / 4) + 4 g + (j % 4) of the 32-key chunk, which is exactly what the lane already holds from the two score tiles --
+//           no cross-lane traffic between the two products. V (stored [key][d]) is staged ONCE per workgroup and chunk, transposed
+//           in LDS ([d][key]), so that a lane's A fragment (8 keys of one d) is two 8-byte LDS reads.
+//   Rounding points as in attention_k (modeling_llama_imgemb.py:216-234): T(q.k), T(. / sqrt(d)), fp32 softmax, T(p), T(o). Masked keys
+//   (padding, causal, beyond Tk) score -inf; a query without any visible key gets zeros (nothing reads such rows).
+//
+// 64 queries (4 waves) per workgroup: grid (ceil(Tq / 64), heads, batch). Taken when that grid fills the chip (launch_flash_prefill
+// decides); one or two prompts keep attention_k, whose many small workgroups suit a latency-bound launch.
+#include <stdlib.h>
+#include <algorithm>
+#include "rdx_common.h"
+#include "rdx_kernels.h"
+
+namespace rdx {
+
+constexpr int FL_D = 128, FL_DC = FL_D / 32, FL_WAVES = 4, FL_QB = FL_WAVES * 16;
+constexpr int FL_VTP = 36;                       // keys per transposed V row in LDS (72 B: the two 4-key halves of a lane land 16 banks apart)
+
+template <typename T> __device__ __forceinline__ float scale_score(float s);
+// "/ math.sqrt(head_dim)" on a model-dtype value, rounded to the model dtype. bf16: the product with the fp32 reciprocal rounds to the same bf16
+// for EVERY finite bf16 input (checked exhaustively against torch's division); fp16 has 52 inputs where it does not, so it divides.
+template <> __device__ __forceinline__ float scale_score<bf16>(float s) { return rnd<bf16>(s * 0.08838834764831845f); }
+template <> __device__ __forceinline__ float scale_score<f16>(float s) { return rnd<f16>(s / 11.313708498984761f); }
+
+template <typename T>
+__global__ __launch_bounds__(FL_WAVES * 64, 3) void flash_prefill_k(AttnArgs a) {
+    typedef typename Vec8<T>::type V8;
+    typedef T T4 __attribute__((ext_vector_type(4)));
+    typedef T T2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) T Vt[2][FL_D][FL_VTP];           // two chunks of 32 keys, transposed
+
+    const int q0 = blockIdx.x * FL_QB, h = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const T* Q = reinterpret_cast<const T*>(a.Q) + b * a.q_bs + h * a.q_hs;
+    const T* K = reinterpret_cast<const T*>(a.K) + b * a.k_bs + h * a.k_hs;
+    const T* V = reinterpret_cast<const T*>(a.V) + b * a.v_bs + h * a.v_hs;
+    const uint8_t* km = a.key_mask ? a.key_mask + b * a.km_bs : nullptr;
+    const int Tq = a.Tq, Tk = a.Tk, off = Tk - Tq;
+    const int qw = q0 + w * 16, q = qw + r;               // this wave's first query, this lane's query
+
+    V8 qf[FL_DC];
+#pragma unroll
+    for (int kc = 0; kc < FL_DC; ++kc) {
+        if (q < Tq) qf[kc] = as_vec8<T>(ldg16(Q + (long)q * a.q_ts + kc * 32 + g * 8));
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[kc][j] = fromf<T>(0.f);
+        }
+    }
+    // keys this wave / this workgroup can see (causal: query i attends keys j <= i + off); whole 16-key tiles / 32-key chunks
+    const int kmax_w = qw < Tq ? (a.causal ? min(Tk, qw + 16 + off) : Tk) : 0;
+    const int kmax_g = a.causal ? min(Tk, min(q0 + FL_QB, Tq) + off) : Tk;
+    const int nkt_w = (kmax_w + 15) >> 4;
+    const int nch = (max(kmax_g, 1) + 31) >> 5;
+
+    auto load_kt = [&](int kt, V8 (&kf)[FL_DC], unsigned& mw) {
+        const int key = min(kt * 16 + r, Tk - 1);          // keys >= Tk are clamped here and masked in score()
+#pragma unroll
+        for (int kc = 0; kc < FL_DC; ++kc)
+            kf[kc] = as_vec8<T>(ldg16(a.k_perm ? K + kperm(key, kc * 32 + g * 8) : K + (long)key * a.k_ts + kc * 32 + g * 8));
+        mw = km ? *reinterpret_cast<const unsigned*>(km + min(kt * 16 + g * 4, (int)a.km_bs - 4)) : 0x01010101u;
+    };
+    // the four scores of this lane for key tile kt (keys 16 kt + 4 g + e, query q): rounded like the reference, -inf where masked
+    auto score = [&](int kt, const V8 (&kf)[FL_DC], unsigned mw, float (&sv)[4]) {
+        v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < FL_DC; ++kc) acc = mfma16(kf[kc], qf[kc], acc);      // D[i = key_local = 4 g + e][j = q_local = r]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kj = kt * 16 + g * 4 + e;
+            bool ok = (kj < Tk) && (q < Tq) && ((mw >> (8 * e)) & 0xffu) != 0;
+            if (a.causal) ok = ok && kj <= q + off;
+            sv[e] = ok ? scale_score<T>(rnd<T>(acc[e])) : -INFINITY;
+        }
+    };
+
+    // ---- pass 1: row maximum and sum of exponentials ---------------------------------------------------------------------------------
+    float m = -INFINITY, l = 0.f;
+    {
+        V8 ka[FL_DC], kb[FL_DC];
+        unsigned ma = 0, mb = 0;
+        float sv[4];
+        auto fold = [&]() {
+            const float tm = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+            if (tm > -INFINITY) {
+                const float mn = fmaxf(m, tm);
+                l = l * expf(m - mn) + ((expf(sv[0] - mn) + expf(sv[1] - mn)) + (expf(sv[2] - mn) + expf(sv[3] - mn)));   // exp(-inf) = 0
+                m = mn;
+            }
+        };
+        int kt = 0;
+        if (kt < nkt_w) load_kt(kt, ka, ma);
+        while (kt < nkt_w) {
+            load_kt(min(kt + 1, nkt_w - 1), kb, mb);
+            score(kt, ka, ma, sv); fold();
+            if (++kt >= nkt_w) break;
+            load_kt(min(kt + 1, nkt_w - 1), ka, ma);
+            score(kt, kb, mb, sv); fold();
+            ++kt;
+        }
+    }
+    // the four lane groups of a query hold disjoint keys: combine (m, l) over lanes r, r + 16, r + 32, r + 48
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
+        const float mn = fmaxf(m, mo);
+        l = (mn > -INFINITY) ? l * expf(m - mn) + lo * expf(mo - mn) : 0.f;
+        m = mn;
+    }
+    const bool any_key = (m > -INFINITY) && l > 0.f;
+    const float m_use = any_key ? m : 0.f, l_use = any_key ? l : 1.f;
+
+    // ---- pass 2: P = T(softmax), O^T += V^T P^T over 32-key chunks; V staged transposed through LDS once per workgroup -----------------
+    // staging: thread t takes key pair kp = t / 16 (keys 2 kp, 2 kp + 1 of the chunk) and 8 dims d0 = 8 (t % 16): two 16-byte row pieces,
+    // written as 8 (key, key + 1) pairs -> Vt[d0 + j][2 kp .. + 1]
+    const int kp = threadIdx.x >> 4, d0 = (threadIdx.x & 15) * 8;
+    auto load_v = [&](int c, u4 (&vr)[2]) {
+        const int k0 = min(c * 32 + 2 * kp, Tk - 1), k1 = min(c * 32 + 2 * kp + 1, Tk - 1);   // clamped rows: finite values, probability exactly 0
+        vr[0] = ldg16(V + (long)k0 * a.v_ts + d0);
+        vr[1] = ldg16(V + (long)k1 * a.v_ts + d0);
+    };
+    auto stage_v = [&](int buf, const u4 (&vr)[2]) {
+        const V8 v0 = as_vec8<T>(vr[0]), v1 = as_vec8<T>(vr[1]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            T2 pr; pr[0] = v0[j]; pr[1] = v1[j];
+            *reinterpret_cast<T2*>(&Vt[buf][d0 + j][2 * kp]) = pr;
+        }
+    };
+    v4f acco[FL_D / 16];
+#pragma unroll
+    for (int i = 0; i < FL_D / 16; ++i) acco[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+    {
+        u4 vr[2];
+        V8 ka[FL_DC], kb[FL_DC];                  // even / odd key tile: each set is re-requested for the next chunk right after its MFMAs
+        unsigned ma = 0, mb = 0;
+        const int last_t = 2 * nch - 1;
+        load_v(0, vr);
+        load_kt(0, ka, ma); load_kt(min(1, last_t), kb, mb);
+        stage_v(0, vr);
+        if (nch > 1) load_v(1, vr);
+        __syncthreads();
+        for (int c = 0; c < nch; ++c) {
+            float s0[4], s1[4];
+            score(2 * c, ka, ma, s0);
+            load_kt(min(2 * c + 2, last_t), ka, ma);
+            score(2 * c + 1, kb, mb, s1);
+            load_kt(min(2 * c + 3, last_t), kb, mb);
+            V8 pf;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pf[e] = fromf<T>(s0[e] > -INFINITY ? expf(s0[e] - m_use) / l_use : 0.f);         // exp / sum like torch's softmax (a true division)
+                pf[4 + e] = fromf<T>(s1[e] > -INFINITY ? expf(s1[e] - m_use) / l_use : 0.f);
+            }
+            const int buf = c & 1;
+#pragma unroll
+            for (int dt = 0; dt < FL_D / 16; ++dt) {
+                const T4 lo = *reinterpret_cast<const T4*>(&Vt[buf][dt * 16 + r][4 * g]);
+                const T4 hi = *reinterpret_cast<const T4*>(&Vt[buf][dt * 16 + r][16 + 4 * g]);
+                V8 vf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                acco[dt] = mfma16(vf, pf, acco[dt]);             // D[i = d_local = 4 g + e][j = q_local = r]
+            }
+            // V of chunk c + 1 (already in registers) goes to the other buffer, chunk c + 2 is requested; one barrier per chunk
+            if (c + 1 < nch) stage_v((c + 1) & 1, vr);
+            if (c + 2 < nch) load_v(c + 2, vr);
+            __syncthreads();
+        }
+    }
+
+    if (q < Tq) {
+        T* O = reinterpret_cast<T*>(a.O) + b * a.o_bs + h * a.o_hs;
+#pragma unroll
+        for (int dt = 0; dt < FL_D / 16; ++dt) {
+            T4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fromf<T>(acco[dt][e]);
+            if (a.o_packed_mt) {
+                // fragment-packed for wstat_k (o_proj): row m = b Tq + q, column k = h D + 16 dt + 4 g .. + 4 (see attention_k)
+                const long mrow = (long)b * Tq + q;
+                const int k = h * FL_D + dt * 16 + g * 4;
+                T* Op = reinterpret_cast<T*>(a.O);
+                *reinterpret_cast<T4*>(Op + ((((long)(k >> 5) * a.o_packed_mt + (mrow >> 4)) * 64 + ((k & 31) >> 3) * 16 + (mrow & 15)) << 3) + (k & 7)) = o;
+            } else {
+                *reinterpret_cast<T4*>(O + (long)q * a.o_ts + dt * 16 + g * 4) = o;
+            }
+        }
+    }
+}
+
+bool flash_prefill_supported(int head_dim, const AttnArgs& a) {
+    const char* e = getenv("RDX_FLASH_MIN");                   // read per launch: tests toggle it (0 = never, 1 = always: A / B against attention_k)
+    const int min_wgs = e ? atoi(e) : 512;
+    const long wgs = (long)((a.Tq + FL_QB - 1) / FL_QB) * a.H * a.B;
+    return min_wgs > 0 && head_dim == FL_D && wgs >= min_wgs && (a.v_ts & 7) == 0 && (a.q_ts & 7) == 0 && (a.k_perm || (a.k_ts & 7) == 0) &&
+           (!a.key_mask || (a.km_bs & 3) == 0);
+}
+
+void launch_flash_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
+    dim3 grid((a.Tq + FL_QB - 1) / FL_QB, a.H, a.B), block(FL_WAVES * 64);
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((flash_prefill_k<T>), grid, block, 0, s, a));
+}
+
+}  // namespace rdx

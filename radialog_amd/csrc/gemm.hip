@@ -61,8 +61,8 @@ void launch_pack_weight(int dtype, const float* src, void* dst, int N, int K, in
 // fp8 weights: one workgroup per output row. scale = absmax / 448 (e4m3 max), q = RNE(w * (448 / absmax)); stored in the
 // 64-deep fragment order Wq[n_tile16][k_chunk64][lane][16]: lane (g<<4)|r <-> W[16*nt + r][64*kc + 16*g .. +16], so one
 // wave-wide 16-byte load feeds TWO mfma_16x16x32 (bytes 0..7 and 8..15 of every lane; the activation fragment is read at the
-// matching k offsets). Also writes the dequantised model-dtype copy T(q * scale) in the standard order for the kernels
-// that do not read fp8 (prefill, batch > 4).
+// matching k offsets). With dst != null also writes the dequantised model-dtype copy T(q * scale) in the standard order (kernel test
+// hooks; the engine keeps ONLY the fp8 bytes: prefill and batch >= 3 decode multiply fp8 x fp8, batch <= 2 expands in registers).
 template <typename T>
 __global__ __launch_bounds__(256) void pack_weight_fp8_k(const float* __restrict__ src, unsigned char* __restrict__ dst8,
                                                          float* __restrict__ scale, T* __restrict__ dst, int N, int K, int Npad) {
@@ -89,7 +89,8 @@ __global__ __launch_bounds__(256) void pack_weight_fp8_k(const float* __restrict
         }
         const int kc = q >> 2, g = q & 3;
         reinterpret_cast<u4*>(dst8)[((size_t)nt * KC8 + kc) * 64 + (g * 16 + r)] = (u4){d[0], d[1], d[2], d[3]};
-        // dequantised copy, standard order: chunks of 8 k -> ((nt*KC + k/32)*64 + ((k%32)/8)*16 + r)
+        // dequantised copy (test hooks only; dst == null in the engine), standard order: chunks of 8 k -> ((nt*KC + k/32)*64 + ((k%32)/8)*16 + r)
+        if (dst)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             typename Vec8<T>::type v;
@@ -173,7 +174,8 @@ static void launch_skinny_T(const GemmArgs& a, int epi, hipStream_t s) {
 }
 
 void launch_skinny_gemm(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
-    if (xstat32_supported(a, epi)) { launch_xstat32(dtype, a, epi, s); return; }
+    // (fp8 weights: only with the e4m3 activation block, xpacked 4 -- the batch >= 3 rule of the fp8 scheme; callers go through skinny())
+    if (xstat32_supported(a, epi) && (!(a.W8 && a.wscale) || (a.xpacked == 4 && a.xscale))) { launch_xstat32(dtype, a, epi, s); return; }
     RDX_DISPATCH_T(dtype, T, launch_skinny_T<T>(a, epi, s));
 }
 

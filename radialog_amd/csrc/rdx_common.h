@@ -66,6 +66,26 @@ template <> __device__ __forceinline__ u4 dequant8<f16>(unsigned lo, unsigned hi
                 __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(c[0], c[1])), __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(d[0], d[1]))};
 }
 
+// ---- model dtype -> fp8 (OCP e4m3) activation quantisation of the fp8 path: q = RNE_e4m3(x * (448 / absmax)), scale = absmax / 448 ----------
+// (the arithmetic of pack_weight_fp8_k and of the oracle's fake quantisation; an all-zero range gets scale 1)
+__device__ __forceinline__ void fp8_scale(float amax, float& sc, float& inv) {
+    sc = amax > 0.f ? amax / 448.0f : 1.0f;
+    inv = amax > 0.f ? 448.0f / amax : 1.0f;
+}
+template <typename T> __device__ __forceinline__ u2 quant8(const typename Vec8<T>::type& v, float inv) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(tof<T>(v[0]) * inv, tof<T>(v[1]) * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(tof<T>(v[2]) * inv, tof<T>(v[3]) * inv, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(tof<T>(v[4]) * inv, tof<T>(v[5]) * inv, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(tof<T>(v[6]) * inv, tof<T>(v[7]) * inv, hi, true);
+    return (u2){(unsigned)lo, (unsigned)hi};
+}
+template <typename T> __device__ __forceinline__ float amax8(const typename Vec8<T>::type& v) {
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(tof<T>(v[j])));
+    return m;
+}
 // ---- wave (64 lanes) reductions ----------------------------------------------------------------------------------
 // Cross-lane traffic goes through DPP / v_readlane / v_permlane*_swap (VALU speed, ~8 cycles each) rather than
 // __shfl_xor (ds_bpermute: an LDS-crossbar round trip of ~100 cycles per step) -- these reductions sit on the critical

@@ -76,6 +76,9 @@ struct rdx_ctx {
     float* part_val = nullptr; int* part_idx = nullptr; int n_vtiles = 0;
     // decode-step activations ([max_batch] rows) and prefill activations (grown on demand)
     void *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dgu = nullptr;
+    float* dxs = nullptr;            // fp8 path, batch 3-32 decode: xscale[32] of the e4m3 activation block in dxn (rmsnorm4096_k<T, 4>)
+    void* pxq = nullptr; float* pxs = nullptr;   // fp8 path, prefill: e4m3 activations [rows][max(hidden, inter)] and their scales [rows][4]
+    std::string unsupported;         // set by the dispatch when a shape has no kernel in the current mode (fp8 weights); reported by the entry points
     float* kslab = nullptr;          // batch 3-32 decode: fp32 partial slabs [<= 4 groups][32][hidden] of a K-split projection
     int pend_groups = 0;             // launch-time state: slabs written by the last xsplit32 launch, not yet added into dx
     void *px = nullptr, *pxn = nullptr, *pqkv = nullptr, *pq = nullptr, *patt = nullptr, *pgu = nullptr, *pqe = nullptr, *pimg = nullptr;
@@ -161,6 +164,8 @@ void run_gemm(rdx_ctx* c, GemmArgs a, int epi);
 void conv_gemm(rdx_ctx* c, const void* X, const GemmW& W, const float* bias, const void* resid, void* out, int B,
                int Hin, int Win, int Cin, int KH, int KW, int stride, int pad, int Hout, int Wout, int epi);
 int v_grid(const rdx_config& f);      // side of the trunk's output grid
+inline bool fp8_weights(const GemmW& W) { return W.w8 && W.scale && !W.w; }       // the engine's fp8 mode keeps no model-dtype copy
+int take_unsupported(rdx_ctx* c);     // nonzero (and rdx_last_error set) when a launch since the last call had no kernel for its shape
 
 // ---- decoder (api_llama.hip) ----
 inline void* kv_ptr(rdx_ctx* c, void* base, int layer) { return (char*)base + (size_t)layer * c->kv_layer_elems * 2; }

@@ -33,6 +33,9 @@ struct GemmArgs {
     int xpacked;                     // xstat32_k: X is the fragment-packed 32-row block written by launch_rmsnorm_packed32 (1 / 2);
                                      // 3 (wstat_k): fragment-packed [k / 32][mtiles][lane][8] over `mtiles` row tiles of 16 (out_packed 3 alike)
     int mtiles;
+    // fp8 activations (W8A8: gemm8.hip, xstat32_k<.., A8>): X holds e4m3 bytes, xscale[row][xgroups] their absmax / 448 scales over `xgroups`
+    // equal K ranges (1 behind an RMSNorm, 2 o_proj, 4 down_proj); xpacked 4 = the 32-row block in the 64-deep fragment order
+    const float* xscale; int xgroups;
     long long* trace;                // debug: [tile][8] timestamps (100 MHz ticks) written by thread 0 of every workgroup (skinny_tile)
 };
 
@@ -113,6 +116,9 @@ void launch_stem_pool(int dtype, const void* in, const void* Wp, const float* bi
 void launch_l2_bench(int mode, const void* buf, size_t bytes_per_wg, int shared, int reps, int wgs, unsigned* sink, hipStream_t s);
 
 void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s);
+// 64-query flash-style blocks for head_dim 128 (flash.hip); launch_attention takes it when the grid fills the chip (RDX_FLASH_MIN workgroups)
+bool flash_prefill_supported(int head_dim, const AttnArgs& a);
+void launch_flash_prefill(int dtype, const AttnArgs& a, hipStream_t s);
 // prefill: LoRA add + RoPE + KV-cache write for T tokens of B rows; q -> qout [B*T][hidden]
 void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,
                             const void* cos_t, const void* sin_t, const int* pos_ids, void* qout, void* kcache,
@@ -158,6 +164,14 @@ bool attn_oproj16_supported(const LlamaDims& d, int N, int K, int B);
 void launch_attn_oproj16(int dtype, const DecAttnArgs& a, const GemmArgs& g, int B, int* counter, int* err, hipStream_t s);
 
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s);
+// fp8 path (BASELINE configs[4]): e4m3 activations with absmax / 448 scales -- see gemm8.hip for the scheme
+void launch_quant_rows(int dtype, const void* x, long ldx, void* out8, float* xscale, int rows, int K, int groups, hipStream_t s);
+void launch_rmsnorm_fp8(int dtype, const void* x, const void* w, void* out8, float* xscale, int rows, int H, float eps, hipStream_t s);
+void launch_rmsnorm_packed32_fp8(int dtype, void* x, const void* w, void* out8, float* xscale, int rows, int H, float eps, const float* slab,
+                                 int groups, hipStream_t s);
+// fp8 x fp8 MFMA GEMM over row-major e4m3 activations (any M; N % 16 == 0, K % 64 == 0): epilogues NONE / RESID / SILU_MUL
+bool gemm8_supported(const GemmArgs& a, int epi);
+void launch_gemm8(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 // rows <= 32 normalised into the 32-row fragment-packed block xstat32_k reads (pack 1: 32-deep fragments, 2: fp8 64-deep order)
 // slab != null: the rows are first completed as x[row] = x[row] + T(sum over g < groups of slab[g][row][:]) (written back to x)
 void launch_rmsnorm_packed32(int dtype, void* x, const void* w, void* out, int rows, int H, float eps, int pack, const float* slab,

@@ -22,8 +22,20 @@ namespace rdx {
 
 constexpr int XS_WAVES = 8, XS_THREADS = 512, XS_K = 4096, XS_CPW = XS_K / 32 / XS_WAVES;   // 16 chunks of 32 per wave
 
-template <typename T, int EPI, bool W8>
+// fp8 x fp8: one 16-byte piece of each operand = two v_mfma_f32_16x16x32_fp8_fp8 (bytes 0..7 and 8..15 of every lane, k = 64 c + 16 g + 8 h ..)
+__device__ __forceinline__ v4f xs_mfma8(const u4& a, const u4& b, v4f c) {
+    const long a0 = (long)(((unsigned long long)a.y << 32) | a.x), a1 = (long)(((unsigned long long)a.w << 32) | a.z);
+    const long b0 = (long)(((unsigned long long)b.y << 32) | b.x), b1 = (long)(((unsigned long long)b.w << 32) | b.z);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, c, 0, 0, 0);
+}
+
+// A8 (with W8): the activations arrive as e4m3 bytes in the 64-deep fragment order (xpacked 4, written by rmsnorm4096_k<T, 4> with one scale per
+// row): a piece is 16 bytes per lane like a weight piece, two fp8 MFMAs per pair, half the activation registers and half the start-up fetch;
+// the fp32 sum is scaled by wscale[n] * xscale[m] in the epilogue.
+template <typename T, int EPI, bool W8, bool A8 = false>
 __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
+    static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
     constexpr int TPI = W8 ? 2 : 1;                   // tiles per trip
     constexpr int LPT = W8 ? XS_CPW / 2 : XS_CPW;     // 16-byte weight loads per wave per tile
     constexpr int RING = TPI * LPT;                   // 16
@@ -63,18 +75,26 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
     // ---- activations -> registers, requested AFTER the first ring of weights: the 256 workgroups read the same 256 KiB from L2
     // at once (~6 us of L2 hot-spotting), and weight requests queued behind them would leave HBM idle meanwhile. xf[mt][c] is the B fragment (column = row 16 mt + r of X, k = 8 g .. + 8 within the chunk)
     const T* X = reinterpret_cast<const T*>(a.X);
-    u4 xf[2][XS_CPW];
+    constexpr int NXF = A8 ? XS_CPW / 2 : XS_CPW;
+    u4 xf[2][NXF];
     const bool xp = a.xpacked != 0;          // fragment-packed by rmsnorm_k<T, PACK>: fragment (f, mt) is one contiguous KiB
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const T* xr = xp ? X + (size_t)(((wa * XS_CPW) * 2 + mt) * 64 + lane) * 8
-                         : X + (size_t)min(mt * 16 + r, a.M - 1) * a.ldx + wa * (XS_CPW * 32);
+        if (A8) {
+            // e4m3 block [chunk j][mt][lane][16]: this wave's chunks j = (XS_CPW / 2) wa .. + XS_CPW / 2
+            const u4* x8 = reinterpret_cast<const u4*>(a.X) + (size_t)((wa * (XS_CPW / 2)) * 2 + mt) * 64 + lane;
 #pragma unroll
-        for (int c = 0; c < XS_CPW; ++c) {
-            // row-major X, bf16/f16 weights: chunk c covers k = 32 c + 8 g .. + 8. fp8: load j = c / 2 covers k = 64 j + 16 g .. + 16
-            // and MFMA h = c & 1 takes k = 64 j + 16 g + 8 h .. + 8  (16 rows x 16 B per quarter wave: slow, tests only)
-            const int koff = W8 ? ((c >> 1) * 64 + g * 16 + (c & 1) * 8) : (c * 32 + g * 8);
-            xf[mt][c] = ldg16(xr + (xp ? c * 1024 : koff));
+            for (int c = 0; c < NXF; ++c) xf[mt][c] = ldg16(x8 + (size_t)c * 128);
+        } else {
+            const T* xr = xp ? X + (size_t)(((wa * XS_CPW) * 2 + mt) * 64 + lane) * 8
+                             : X + (size_t)min(mt * 16 + r, a.M - 1) * a.ldx + wa * (XS_CPW * 32);
+#pragma unroll
+            for (int c = 0; c < NXF; ++c) {
+                // row-major X, bf16/f16 weights: chunk c covers k = 32 c + 8 g .. + 8. fp8: load j = c / 2 covers k = 64 j + 16 g .. + 16
+                // and MFMA h = c & 1 takes k = 64 j + 16 g + 8 h .. + 8  (16 rows x 16 B per quarter wave: slow, tests only)
+                const int koff = W8 ? ((c >> 1) * 64 + g * 16 + (c & 1) * 8) : (c * 32 + g * 8);
+                xf[mt][c] = ldg16(xr + (xp ? c * 1024 : koff));
+            }
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -90,12 +110,13 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
         const int grp = (int)blockIdx.x + it * G, t0 = grp * TPI;
         // operands the epilogue needs come first in the (in-order) load queue, ahead of the ring refills
         float e_res[TPI], e_sc[TPI], e_bias[TPI];
+        const float e_xs = A8 ? a.xscale[e_m] : 1.f;                   // xscale[32]: one per row of the block (rows >= M: 1)
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
             const int n = min((t0 + q) * 16 + e_nl, ntiles * 16 - 1);
             e_res[q] = 0.f; e_sc[q] = 1.f; e_bias[q] = 0.f;
             if (EPI == EPI_RESID) e_res[q] = tof<T>(reinterpret_cast<const T*>(a.resid)[(size_t)min(e_m, a.M - 1) * a.ldr + min(n, a.N - 1)]);
-            if (W8) e_sc[q] = a.wscale[n];
+            if (W8) e_sc[q] = a.wscale[n] * e_xs;
             if (a.bias) e_bias[q] = a.bias[min(n, a.N - 1)];
         }
         v4f acc[TPI][2];
@@ -107,16 +128,19 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < LPT; ++j) {
                 const u4 wv = ring[q * LPT + j];
-                if (W8) {
+                if (A8) {
+                    acc[q][0] = xs_mfma8(wv, xf[0][A8 ? j : 0], acc[q][0]);
+                    acc[q][1] = xs_mfma8(wv, xf[1][A8 ? j : 0], acc[q][1]);
+                } else if (W8) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const u4 wd = dequant8<T>(h ? wv.z : wv.x, h ? wv.w : wv.y);
-                        acc[q][0] = mfma16(as_vec8<T>(wd), as_vec8<T>(xf[0][2 * j + h]), acc[q][0]);
-                        acc[q][1] = mfma16(as_vec8<T>(wd), as_vec8<T>(xf[1][2 * j + h]), acc[q][1]);
+                        acc[q][0] = mfma16(as_vec8<T>(wd), as_vec8<T>(xf[0][A8 ? 0 : 2 * j + h]), acc[q][0]);
+                        acc[q][1] = mfma16(as_vec8<T>(wd), as_vec8<T>(xf[1][A8 ? 0 : 2 * j + h]), acc[q][1]);
                     }
                 } else {
-                    acc[q][0] = mfma16(as_vec8<T>(wv), as_vec8<T>(xf[0][j]), acc[q][0]);
-                    acc[q][1] = mfma16(as_vec8<T>(wv), as_vec8<T>(xf[1][j]), acc[q][1]);
+                    acc[q][0] = mfma16(as_vec8<T>(wv), as_vec8<T>(xf[0][A8 ? 0 : j]), acc[q][0]);
+                    acc[q][1] = mfma16(as_vec8<T>(wv), as_vec8<T>(xf[1][A8 ? 0 : j]), acc[q][1]);
                 }
                 if (PF) ring[q * LPT + j] = ldg16_nt(wn + (unsigned)(j * 64 + lane));
                 __builtin_amdgcn_sched_barrier(0);           // keep consume-j / refill-j order: the waits stay vmcnt(RING - 1)
@@ -205,8 +229,12 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
 // (A variant that ran that RMSNorm as a tail of this launch -- write-through slabs, arrival counter, workgroups 0..31 finishing one
 // row each -- was measured 1.2 us slower per norm than the 5-us launch it replaced and made low-index workgroups wait on all others,
 // against the liveness rule of handoff.h; removed in round 2.)
-template <typename T, int KC, int KGN, bool W8, int TPI>
+// A8 (with W8): the workgroup quantises ITS K range of the (model-dtype, fragment-packed) activations to e4m3 at start-up -- one absmax / 448
+// scale per row over the range (cross-wave maximum through LDS) -- and multiplies fp8 x fp8; the partial carries wscale[n] * that scale. The
+// ranges of the KGN groups are the `xgroups` K groups of the fp8 scheme (gemm8.hip): o_proj 2, down_proj 4.
+template <typename T, int KC, int KGN, bool W8, int TPI, bool A8 = false>
 __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __restrict__ slab) {
+    static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
     constexpr int SLOTS = XS_WAVES * KGN, CPW = (KC + SLOTS - 1) / SLOTS, FPL = W8 ? 2 : 1;   // fragments (MFMAs per row tile) per load
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
     float* red = reinterpret_cast<float*>(smx);       // [2 bufs][TPI][8 waves][2 mt][256]
@@ -251,6 +279,43 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 
     const int e_mt = threadIdx.x >> 8, e_idx = threadIdx.x & 255, e_m = e_mt * 16 + (e_idx >> 4), e_nl = e_idx & 15;
     float* sl = slab + ((size_t)kg * 32 + e_m) * a.N;
+    u4 xq[2][A8 ? CPW : 1];
+    float e_xs = 1.f;
+    if (A8) {
+        // row maxima over this workgroup's K range: lane -> its 4 lane groups (same row, other k) -> the 8 waves through LDS (`red` is free here)
+        float* rowmax = red;                       // [8 waves][32 rows]
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float am = 0.f;
+#pragma unroll
+            for (int j = 0; j < CPW * FPL; ++j) am = fmaxf(am, amax8<T>(as_vec8<T>(xf[mt][j])));
+            am = fmaxf(am, __shfl_xor(am, 16, 64));
+            am = fmaxf(am, __shfl_xor(am, 32, 64));
+            if (g == 0) rowmax[wa * 32 + mt * 16 + r] = am;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float am = 0.f;
+#pragma unroll
+            for (int i = 0; i < XS_WAVES; ++i) am = fmaxf(am, rowmax[i * 32 + mt * 16 + r]);
+            float sc, inv;
+            fp8_scale(am, sc, inv);
+#pragma unroll
+            for (int j = 0; j < CPW; ++j) {
+                const u2 lo = quant8<T>(as_vec8<T>(xf[mt][2 * j]), inv), hi = quant8<T>(as_vec8<T>(xf[mt][2 * j + 1]), inv);
+                xq[mt][j] = (u4){lo.x, lo.y, hi.x, hi.y};
+            }
+        }
+        {
+            float am = 0.f;
+#pragma unroll
+            for (int i = 0; i < XS_WAVES; ++i) am = fmaxf(am, rowmax[i * 32 + e_m]);
+            float inv;
+            fp8_scale(am, e_xs, inv);
+        }
+        __syncthreads();                           // rowmax is read before the first trip's partials overwrite `red`
+    }
 
     auto trip = [&](int it, auto pf_tag) {
         constexpr bool PF = decltype(pf_tag)::value;
@@ -266,7 +331,10 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 #pragma unroll
             for (int j = 0; j < CPW; ++j) {
                 const u4 wv = ring[q][j];
-                if (W8) {
+                if (A8) {
+                    acc[q][0] = xs_mfma8(wv, xq[0][A8 ? j : 0], acc[q][0]);
+                    acc[q][1] = xs_mfma8(wv, xq[1][A8 ? j : 0], acc[q][1]);
+                } else if (W8) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const u4 wd = dequant8<T>(h ? wv.z : wv.x, h ? wv.w : wv.y);
@@ -297,7 +365,7 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 #pragma unroll
             for (int i = 0; i < XS_WAVES; ++i) v += rb[((q * XS_WAVES + i) * 2 + e_mt) * 256 + e_idx];
             const int tl = it * TPI + q, n = (ts + tl * nts) * 16 + e_nl;
-            if (tl < ntl && e_m < a.M && n < a.N) sl[n] = v * e_sc[q];
+            if (tl < ntl && e_m < a.M && n < a.N) sl[n] = v * e_sc[q] * e_xs;
         }
     };
     if (nit > 1) {
@@ -335,16 +403,16 @@ int xsplit32_groups(const GemmArgs& a) {
 void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
     const int kgn = xsplit32_groups(a);
     const int nt = (a.N + 15) / 16;
-    const bool w8 = a.W8 && a.wscale;
+    const bool w8 = a.W8 && a.wscale;                        // fp8 weights: fp8 x fp8, every K-group workgroup quantises its range of the activations
     const size_t smem = (size_t)2 * (w8 ? 2 : 1) * XS_WAVES * 2 * 256 * 4;
     RDX_DISPATCH_T(dtype, T, {
         if (kgn == 4) {
             const int nts = std::min(nt, 256 / 4);
-            if (w8) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
+            if (w8) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2, true>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
             else hipLaunchKernelGGL((xsplit32_k<T, 344, 4, false, 1>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
         } else if (kgn == 2) {
             const int nts = std::min(nt, 256 / 2);
-            if (w8) hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
+            if (w8) hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2, true>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
             else hipLaunchKernelGGL((xsplit32_k<T, 128, 2, false, 1>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
         }
     });
@@ -357,7 +425,7 @@ bool xstat32_supported(const GemmArgs& a, int epi) {
            (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL || epi == EPI_LOGITS);
 }
 
-template <typename T, bool W8>
+template <typename T, bool W8, bool A8 = false>
 static void launch_xstat32_t(const GemmArgs& a, int epi, hipStream_t s) {
     constexpr int TPI = W8 ? 2 : 1;
     const int nt = (a.N + 15) / 16, groups = (nt + TPI - 1) / TPI;
@@ -370,17 +438,20 @@ static void launch_xstat32_t(const GemmArgs& a, int epi, hipStream_t s) {
     dim3 grid(g), block(XS_THREADS);
     const size_t smem = (size_t)2 * TPI * XS_WAVES * 2 * 256 * 4;
     switch (epi) {
-        case EPI_NONE: hipLaunchKernelGGL((xstat32_k<T, EPI_NONE, W8>), grid, block, smem, s, a); break;
-        case EPI_RESID: hipLaunchKernelGGL((xstat32_k<T, EPI_RESID, W8>), grid, block, smem, s, a); break;
-        case EPI_SILU_MUL: hipLaunchKernelGGL((xstat32_k<T, EPI_SILU_MUL, W8>), grid, block, smem, s, a); break;
-        case EPI_LOGITS: hipLaunchKernelGGL((xstat32_k<T, EPI_LOGITS, W8>), grid, block, smem, s, a); break;
+        case EPI_NONE: hipLaunchKernelGGL((xstat32_k<T, EPI_NONE, W8, A8>), grid, block, smem, s, a); break;
+        case EPI_RESID: hipLaunchKernelGGL((xstat32_k<T, EPI_RESID, W8, A8>), grid, block, smem, s, a); break;
+        case EPI_SILU_MUL: hipLaunchKernelGGL((xstat32_k<T, EPI_SILU_MUL, W8, A8>), grid, block, smem, s, a); break;
+        case EPI_LOGITS: hipLaunchKernelGGL((xstat32_k<T, EPI_LOGITS, W8, A8>), grid, block, smem, s, a); break;
         default: break;
     }
 }
 
 void launch_xstat32(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
-    const bool w8 = a.W8 && a.wscale;
-    RDX_DISPATCH_T(dtype, T, { if (w8) launch_xstat32_t<T, true>(a, epi, s); else launch_xstat32_t<T, false>(a, epi, s); });
+    const bool w8 = a.W8 && a.wscale;        // fp8 weights: the activations are the e4m3 block of rmsnorm4096_k<T, 4> (xpacked 4; launch_skinny_gemm checks)
+    RDX_DISPATCH_T(dtype, T, {
+        if (w8) launch_xstat32_t<T, true, true>(a, epi, s);
+        else launch_xstat32_t<T, false>(a, epi, s);
+    });
 }
 
 }  // namespace rdx

@@ -17,11 +17,14 @@ def eng(request):
     e.close()
 
 
-def _ref(x, w, bias, resid, epi, norm_w, eps, dt, wdt=None):
+def _ref(x, w, bias, resid, epi, norm_w, eps, dt, wdt=None, act_groups=0):
     xf = x.float()
     if norm_w is not None:
         var = xf.pow(2).mean(-1, keepdim=True)
         xf = (norm_w.to(dt) * (xf * torch.rsqrt(var + eps)).to(dt)).float()
+    if act_groups:                      # fp8 x fp8: e4m3 activations, one scale per row and K group (oracle.ref_cpu.fake_quant_e4m3)
+        from oracle.ref_cpu import fake_quant_e4m3
+        xf = fake_quant_e4m3(xf, act_groups)
     y = xf.double() @ w.to(wdt or dt).double().t()
     if bias is not None:
         y = y + bias.double()
@@ -129,16 +132,16 @@ def _fake_quant_e4m3(w):
 
 
 FP8_CASES = [
-    # M, N, K, epi, norm     (K % 64 == 0; M*K*2 <= 32 KiB streams the fp8 bytes, larger M falls back to the dequantised copy)
-    (1, 256, 4096, 0, True), (1, 64, 11008, 3, False), (3, 128, 512, 4, True), (1, 2064, 4096, 0, True),
-    (2, 4096, 4096, 3, False), (4, 16400, 4096, 4, True), (8, 64, 4096, 0, False), (1, 48, 704, 0, False),
+    # M, N, K, epi, norm     batch <= 2: the GEMV streams the e4m3 bytes and expands them in registers, activations stay in the model dtype
+    (1, 256, 4096, 0, True), (1, 64, 11008, 3, False), (2, 128, 512, 4, True), (1, 2064, 4096, 0, True),
+    (2, 4096, 4096, 3, False), (1, 48, 704, 0, False), (2, 8208, 4096, 4, True),
 ]
 
 
 @pytest.mark.parametrize("M,N,K,epi,norm", FP8_CASES)
 def test_fp8_weight_gemv_matches_fake_quantised_fp32(eng, M, N, K, epi, norm):
-    """BASELINE configs[4]: e4m3 weights + per-row scale through the weight-streaming kernels. Reference = the same
-    math with the fake-quantised weights q * scale in fp32."""
+    """BASELINE configs[4], batch <= 2: e4m3 weights + per-row scale through the weight-streaming GEMV (model-dtype activations).
+    Reference = the same math with the fake-quantised weights q * scale in fp32."""
     dt = DT[eng.dtype]
     x = synth.synth(f"g8.x{M}.{K}", (M, K), -1.0, 1.0).to(dt)
     w = synth.synth(f"g8.w{N}.{K}", (N, K), -0.05, 0.05)
@@ -152,28 +155,48 @@ def test_fp8_weight_gemv_matches_fake_quantised_fp32(eng, M, N, K, epi, norm):
     assert err < tol, f"max abs err {err} (tol {tol})"
 
 
-@pytest.mark.parametrize("M,N,K,epi,norm,force", [(32, 8208, 512, 3, False, 4), (20, 16400, 1024, 4, True, 4), (32, 8224, 4096, 0, False, 4),
-                                                  (25, 8208, 4096, 4, False, 4), (32, 12304, 4096, 3, True, 4),
-                                                  # K-split slab path with fp8 weights (force 6): down_proj and o_proj shapes
-                                                  (32, 4096, 11008, 3, False, 6), (19, 4096, 4096, 3, False, 6), (32, 2048, 11008, 3, False, 6)])
-def test_fp8_weight_batch32_gemm_matches_fake_quantised_fp32(eng, M, N, K, epi, norm, force):
-    """fp8 weights through the 16 < M <= 32 kernels (skinny32.hip LDS-staged, xstat32.hip activation-stationary at K = 4096,
-    xsplit32_k K-split with the slab combine)."""
+def test_fp8_weights_have_no_kernel_for_odd_batch3_shapes(eng):
+    """The fp8 engine keeps ONLY the e4m3 bytes (no model-dtype copy): a shape outside the fp8 kernels' families must fail loudly
+    (rdx error), not run on a silent fallback. Batch >= 3 needs K = 4096 and >= 512 tiles (the decoder's QKV / gate-up / lm_head)."""
+    from radialog_amd._lib import RdxError
+    dt = DT[eng.dtype]
+    x = synth.synth("g8.xodd", (8, 512), -1.0, 1.0).to(dt)
+    w = synth.synth("g8.wodd", (64, 512), -0.05, 0.05)
+    with pytest.raises(RdxError, match="fp8 weights"):
+        eng.gemm_test(x, w, None, None, 0, None, 1e-6, 4)
+
+
+@pytest.mark.parametrize("M,N,K,epi,norm,force,groups", [
+    # batch 3-32 decode, fp8 x fp8 (xstat32_k<W8, A8>): the rows are RMS-normalised (or just re-laid) and quantised to e4m3 by rmsnorm -> fp8
+    (32, 8224, 4096, 0, False, 4, 1), (25, 8208, 4096, 4, False, 4, 1), (32, 12304, 4096, 3, True, 4, 1), (4, 16400, 4096, 4, True, 4, 1),
+    (3, 8208, 4096, 0, True, 4, 1),
+    # K-split slab path (force 6): every K-group workgroup quantises its range -- down_proj (4 groups) and o_proj (2 groups) shapes
+    (32, 4096, 11008, 3, False, 6, 4), (19, 4096, 4096, 3, False, 6, 2), (32, 2048, 11008, 3, False, 6, 4),
+    # prefill, fp8 x fp8 (gemm8.hip; force 9 / 10 / 11 = 1 / 2 / 4 K groups): single prompt (128 x 128 blocks), batched (256 x 256 blocks), ragged
+    # M and N, an odd number of 64-deep chunks with uneven groups (the small config's inter = 1408), every epilogue
+    (160, 12304, 4096, 0, True, 9, 1), (160, 4096, 4096, 3, False, 10, 2), (160, 22016, 4096, 4, True, 9, 1), (160, 4096, 11008, 3, False, 11, 4),
+    (5120, 4096, 4096, 3, False, 10, 2), (1300, 16400, 4096, 4, True, 9, 1), (1024, 4096, 11008, 3, False, 11, 4), (5000, 12304, 4096, 0, True, 9, 1),
+    (216, 512, 1408, 3, False, 11, 4), (50, 2832, 512, 4, True, 9, 1), (3, 528, 512, 0, True, 9, 1), (257, 144, 704, 0, False, 10, 2)])
+def test_fp8_x_fp8_gemm_matches_fake_quantised_fp32(eng, M, N, K, epi, norm, force, groups):
+    """BASELINE configs[4]: e4m3 weights (one scale per output row) x e4m3 activations (one scale per row and K group) on
+    v_mfma_f32_16x16x32_fp8_fp8 -- prefill (gemm8.hip) and batch 3-32 decode (xstat32.hip). Reference = fp32 math on the fake-quantised
+    operands. The quantisation grid makes the comparison discontinuous (an activation one model-dtype ulp away can land on the next
+    e4m3 code, 6 % apart), so the bar is 2 x the model-dtype tolerance on the largest output."""
     dt = DT[eng.dtype]
     x = synth.synth(f"g8.x{M}.{K}", (M, K), -1.0, 1.0).to(dt)
     w = synth.synth(f"g8.w{N}.{K}", (N, K), -0.05, 0.05)
     resid = synth.synth(f"g8.r{M}.{N}", (M, N), -1.0, 1.0).to(dt) if epi == 3 else None
     nw = synth.synth(f"g8.n{K}", (K,), 0.8, 1.2).to(dt) if norm else None
     out = eng.gemm_test(x, w, None, resid, epi, nw, 1e-6, force).float().cpu()
-    ref = _ref(x, _fake_quant_e4m3(w), None, resid, epi, nw, 1e-6, dt, wdt=torch.float32).float()
-    tol = {"f16": 2e-3, "bf16": 1.6e-2}[eng.dtype] * max(1.0, float(ref.abs().max()))
+    ref = _ref(x, _fake_quant_e4m3(w), None, resid, epi, nw, 1e-6, dt, wdt=torch.float32, act_groups=groups).float()
+    tol = 2 * {"f16": 2e-3, "bf16": 1.6e-2}[eng.dtype] * max(1.0, float(ref.abs().max()))
     err = float((out - ref).abs().max())
-    assert err < tol, f"max abs err {err} (tol {tol})"
+    assert torch.isfinite(out).all() and err < tol, f"max abs err {err} (tol {tol})"
 
 
 @pytest.mark.parametrize("M,N,K,n_valid,fp8", [(1, 2064, 4096, 2049, False), (12, 1040, 512, 1033, False), (32, 8208, 512, 8201, False),
                                                (32, 8208, 4096, 8201, False), (21, 32016, 4096, 32001, False), (32, 8208, 4096, 8195, True),
-                                               (3, 4112, 4096, 4100, True)])
+                                               (3, 8208, 4096, 8200, True), (2, 4112, 4096, 4100, True)])
 def test_lm_head_epilogue_logits_and_greedy_choice(eng, M, N, K, n_valid, fp8):
     """EPI_LOGITS of every weight-streaming kernel (skinny M <= 16, skinny32, xstat32; bf16/f16 and fp8 weights): logits rounded
     to the model dtype and argmax over n < n_valid taken ON the rounded values with ties to the lowest index (torch.argmax of
@@ -184,8 +207,12 @@ def test_lm_head_epilogue_logits_and_greedy_choice(eng, M, N, K, n_valid, fp8):
     out, am = eng.logits_test(x, w, n_valid, fp8)
     out = out.float().cpu()
     wr = _fake_quant_e4m3(w) if fp8 else w.to(dt).float()
-    ref = (x.double() @ wr.double().T).float()
-    tol = {"f16": 2e-3, "bf16": 1.6e-2}[eng.dtype] * max(1.0, float(ref.abs().max()))
+    xr = x.float()
+    if fp8 and M >= 3:                       # batch >= 3 multiplies fp8 x fp8: e4m3 activations, one scale per row
+        from oracle.ref_cpu import fake_quant_e4m3
+        xr = fake_quant_e4m3(xr, 1)
+    ref = (xr.double() @ wr.double().T).float()
+    tol = (2 if fp8 and M >= 3 else 1) * {"f16": 2e-3, "bf16": 1.6e-2}[eng.dtype] * max(1.0, float(ref.abs().max()))
     assert float((out[:, :n_valid] - ref[:, :n_valid]).abs().max()) < tol
     assert float(out[:, n_valid:].abs().max()) == 0.0                      # padded vocab columns are never written
     # the greedy choice is exactly the argmax of the kernel's own rounded logits (first index on ties) ...
