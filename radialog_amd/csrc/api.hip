@@ -62,8 +62,6 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
     c->device = device_id;
     if (const char* e = getenv("RDX_FUSE_AO")) c->fuse_attn_oproj = atoi(e) != 0;
     if (const char* e = getenv("RDX_CHAIN")) c->chain_mlp = atoi(e) != 0;
-    if (const char* e = getenv("RDX_CHAIN_NAPS")) c->chain_naps = atoi(e);
-    if (const char* e = getenv("RDX_DMA")) c->use_dma_gemm = atoi(e) != 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return fail(nullptr, -2, "rdx_create: cannot create stream on device %d", device_id);

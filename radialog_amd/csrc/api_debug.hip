@@ -399,7 +399,7 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
         }
         ConvGeom cg;
         memset(&cg, 0, sizeof(cg));
-        if (force == 3 || (force == 0 && c->use_dma_gemm && gemm_dma_supported(a))) {
+        if (force == 3 || (force == 0 && gemm_dma_supported(a))) {
             if (!gemm_dma_supported(a)) { hipFree(wp); if (xn) hipFree(xn); return fail(c, -1, "rdx_gemm_test: shape not supported by gemm_dma_k"); }
             launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
         } else {

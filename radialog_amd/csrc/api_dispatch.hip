@@ -105,9 +105,9 @@ void run_gemm(rdx_ctx* c, GemmArgs a, int epi) {
     ConvGeom cg;
     memset(&cg, 0, sizeof(cg));
     if (a.M <= 32) skinny(c, a, epi == EPI_RESID_RELU ? EPI_RESID : epi);
-    else if ((c->ws_ok || (a.M > 128 && a.M <= 256 && a.N >= 2048)) && c->zero16 && wsgemm_supported(a, cg, epi))
-        launch_wsgemm(c->cfg.dtype, a, cg, epi, c->zero16, c->stream);       // the encoder's GEMMs; a single prompt's prefill GEMMs
-    else if (c->use_dma_gemm && gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
+    else if (c->ws_ok && c->zero16 && wsgemm_supported(a, cg, epi))
+        launch_wsgemm(c->cfg.dtype, a, cg, epi, c->zero16, c->stream);       // the encoder's short-K residual GEMMs
+    else if (gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
     else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
 }
 
@@ -131,8 +131,8 @@ void conv_gemm(rdx_ctx* c, const void* X, const GemmW& W, const float* bias, con
     if (conv1x1_stream_supported(a, cg, epi)) { launch_conv1x1_stream(c->cfg.dtype, a, cg, epi, c->stream); return; }
     if (c->ws_ok && c->zero16 && wsgemm_supported(a, cg, epi)) { launch_wsgemm(c->cfg.dtype, a, cg, epi, c->zero16, c->stream); return; }
     // 1x1 stride-1 convolutions are plain GEMMs; everything else needs the gather path of the tiled kernel
-    if (cg.mode == 0 && c->use_dma_gemm && gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
-    else if (c->use_dma_gemm && c->zero16 && !resid && gemm_dma_conv_supported(a, cg, epi)) launch_gemm_dma_conv(c->cfg.dtype, a, cg, epi, c->zero16, c->gemm_ws, c->gemm_ws_floats, c->stream);
+    if (cg.mode == 0 && gemm_dma_supported(a)) launch_gemm_dma(c->cfg.dtype, a, epi, c->gemm_ws, c->gemm_ws_floats, c->stream);
+    else if (c->zero16 && !resid && gemm_dma_conv_supported(a, cg, epi)) launch_gemm_dma_conv(c->cfg.dtype, a, cg, epi, c->zero16, c->gemm_ws, c->gemm_ws_floats, c->stream);
     else launch_tiled_gemm(c->cfg.dtype, a, cg, epi, c->stream);
 }
 

@@ -119,11 +119,11 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
     // few rows (one or two prompts): the projections are weight-stream bound -> weight-stationary kernels over fragment-packed
     // activations (wstat.hip); the producers (RMSNorm, attention, the SwiGLU epilogue) write that order directly
     const int mtl = (int)((M + 15) / 16);
-    static const int ws_maxm = getenv("RDX_WSTAT_MAXM") ? atoi(getenv("RDX_WSTAT_MAXM")) : 384;
+    constexpr int ws_maxm = 384;
     // measured (tools/prefill_only.py, 32 layers): wstat's time grows with the row tiles of 16, the 128-row tile GEMMs' with the row tiles of 128 --
     // M = 64: 4.84 vs 5.34 ms, 100: 6.06 / 6.26, 160: 7.30 / 7.64, 320: 11.43 / 11.92, but 250: 9.56 / 8.86. Take wstat when the 128-row
     // tiling would pad by 24 rows or more.
-    static const int ws_minpad = getenv("RDX_WSTAT_MINPAD") ? atoi(getenv("RDX_WSTAT_MINPAD")) : 24;
+    constexpr int ws_minpad = 24;
     bool ws = (int)M > 32 && (int)M <= ws_maxm && (int)((M + 127) / 128 * 128 - M) >= ws_minpad;
     if (ws) {
         GemmArgs p = gargs(c->pxn, H, c->ll[0].wqkv, nullptr, c->pqkv, c->ld.qkv_ld, (int)M); p.xpacked = 3; p.mtiles = mtl;

@@ -338,10 +338,8 @@ void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, cons
     const int threads = ((d.hidden / 8 + 63) / 64) * 64;          // hidden <= 8192
     // tokens per workgroup: 1 while that still leaves the chip short of workgroups (a single prompt: 160); for batched prompts as many as make the
     // grid one round of the 512 workgroups the chip holds (two per CU): 32 x 160 tokens -> 10 (8 gave 640 workgroups: a second round a quarter full)
-    static const int tpb_env = getenv("RDX_ROPE_TPB") ? atoi(getenv("RDX_ROPE_TPB")) : 0;
     int tpb = 1;
     if ((long)T_ * B >= 2048) { tpb = (int)(((long)T_ * B + 511) / 512); tpb = tpb < 4 ? 4 : (tpb > 16 ? 16 : tpb); }
-    if (tpb_env > 0) tpb = tpb_env;
     dim3 grid((T_ + tpb - 1) / tpb, B), block(threads);
     const size_t smem = (size_t)d.hidden * sizeof(float);
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rope_kv_prefill_k<T>), grid, block, smem, s, d, (const T*)qkv, (const T*)lora_bq, (const T*)lora_bv,

@@ -158,8 +158,7 @@ static bool cs_shape(int K, int N, int* kc, int* nt) {
 }
 
 bool conv1x1_stream_supported(const GemmArgs& a, const ConvGeom& cg, int epi) {
-    const char* e = getenv("RDX_CONV1X1");                       // 0 = off; else the minimum row count
-    const int min_rows = e ? atoi(e) : 8192;
+    constexpr int min_rows = 8192;                               // below that the grid does not cover the chip: the tile GEMMs take it
     int kc, nt;
     if (min_rows <= 0 || a.M < min_rows || a.ldx % 8 || a.ldo % 8 || a.N % 16) return false;
     if (!(epi == EPI_NONE || epi == EPI_RELU || epi == EPI_RESID_RELU)) return false;

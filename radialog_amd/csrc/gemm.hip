@@ -148,7 +148,7 @@ static void launch_skinny_T(const GemmArgs& a, int epi, hipStream_t s) {
     constexpr int WV = 8;
     // few output tiles (N <= 4096 -> at most one workgroup per CU): 16 waves per workgroup put twice as many
     // weight loads in flight per CU
-    static const int wide = getenv("RDX_SK_WIDE") ? atoi(getenv("RDX_SK_WIDE")) : 1;
+    constexpr bool wide = true;
     const bool w8 = a.W8 && a.wscale && skinny_fits_lds(a.M, a.K) && a.K % 64 == 0;   // fp8 weight stream (else: the dequantised copy)
     if (wide && skinny_fits_lds(a.M, a.K) && (a.N + 15) / 16 <= 256 && a.K >= 4096) {
         if (w8) { if (norm) launch_skinny_epi<T, 1, true, 16, true, true>(a, epi, s); else launch_skinny_epi<T, 1, false, 16, true, true>(a, epi, s); return; }
@@ -157,7 +157,7 @@ static void launch_skinny_T(const GemmArgs& a, int epi, hipStream_t s) {
     }
     // many output tiles: 4-wave workgroups at <= 64 VGPRs keep up to 2048 tiles resident at once (8 per CU), so the
     // whole GEMV runs as ONE round of workgroups sharing HBM evenly instead of 2-4 quantised rounds
-    static const int smallwg = getenv("RDX_SK_SMALLWG") ? atoi(getenv("RDX_SK_SMALLWG")) : 1;
+    constexpr bool smallwg = true;
     if (smallwg && skinny_fits_lds(a.M, a.K) && (a.N + 15) / 16 > 512 && (size_t)a.M * a.K * 2 <= 16 * 1024) {
         if (w8) { if (norm) launch_skinny_epi<T, 1, true, 4, true, true>(a, epi, s); else launch_skinny_epi<T, 1, false, 4, true, true>(a, epi, s); return; }
         if (norm) launch_skinny_epi<T, 1, true, 4, true>(a, epi, s); else launch_skinny_epi<T, 1, false, 4, true>(a, epi, s);

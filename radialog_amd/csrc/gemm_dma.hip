@@ -362,39 +362,33 @@ template <typename T, int EPI>
 static void launch_dma_epi(const GemmArgs& a_in, float* ws, size_t ws_floats, hipStream_t s) {
     const GemmArgs& a = a_in;
     {   // large M: the 256 x 256 tile kernel with the 4-stage ring, as long as its grid still covers the chip
-        const char* e256 = getenv("RDX_DMA256");
-        const int big = e256 ? atoi(e256) : 256;                  // minimum number of 256 x 256 tiles (0 = never)
+        constexpr int big = 256;                                  // minimum number of 256 x 256 tiles
         const int MB2 = (a.M + 255) / 256, NB2 = (a.N + G2_BN - 1) / G2_BN;
         // (the short-K / narrow-N 1x1 convolutions of the encoder are memory-bound and do better with the small tile)
         if (big && a.M >= 1024 && a.K >= 512 && a.N >= 1024 && MB2 * NB2 >= big) {
-            static const int spread = getenv("RDX_DMA256_SPREAD") ? atoi(getenv("RDX_DMA256_SPREAD")) : 1;
             // 320-row blocks when they save rounds on the 256 CUs: cost = rounds x rows per block, with a 15 % handicap -- a 320-row tile is less
             // efficient than its size says (24 activation sub-tiles staged for 20, 200 VGPRs): the Q-Former cross-K/V GEMM (6272 x 9216: 3 rounds of
             // 320 rows against 4 of 256) measured 219 us against 188 us
-            static const int allow320 = getenv("RDX_DMA320") ? atoi(getenv("RDX_DMA320")) : 1;
+            constexpr bool allow320 = true;
             const int MB3 = (a.M + 319) / 320;
             const long c256 = (long)((MB2 * NB2 + 255) / 256) * 256, c320 = (long)((MB3 * NB2 + 255) / 256) * 320;
             if (allow320 && c320 * 115 < c256 * 100) {
                 const size_t smem3 = (size_t)G2_NS * (16 + 20) * 64 * sizeof(u4);   // 144 KiB
                 static bool attr3 = false;
                 if (!attr3) {
-                    hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 10, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
                     hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 10, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
                     attr3 = true;
                 }
-                if (spread) hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 10, 1>), dim3(MB3 * NB2), dim3(512), smem3, s, a);
-                else hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 10, 0>), dim3(MB3 * NB2), dim3(512), smem3, s, a);
+                hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 10, 1>), dim3(MB3 * NB2), dim3(512), smem3, s, a);
                 return;
             }
             const size_t smem2 = (size_t)G2_NS * 2 * 16 * 64 * sizeof(u4);   // 128 KiB
             static bool attr2 = false;
             if (!attr2) {
-                hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 8, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
                 hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
                 attr2 = true;
             }
-            if (spread) hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 8, 1>), dim3(MB2 * NB2), dim3(512), smem2, s, a);
-            else hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 8, 0>), dim3(MB2 * NB2), dim3(512), smem2, s, a);
+            hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 8, 1>), dim3(MB2 * NB2), dim3(512), smem2, s, a);
             return;
         }
     }

@@ -91,14 +91,13 @@ struct rdx_ctx {
                                      // ONE 16-wave launch with a fence-free hand-off (chain.hip: attn_oproj16_k)
     bool chain_mlp = true;           // RDX_CHAIN=0 (tests): one kernel per unit. Default at batch <= 2: down(l) -> QKV(l+1) as one chained
                                      // launch, one workgroup per CU (chain.hip: decode_chain_k)
-    int chain_naps = 1;              // RDX_CHAIN_NAPS: poll back-off of the chained launch
+    int chain_naps = 1;              // poll back-off of the chained launch (x s_sleep(8) between polls)
     GemmW cls_fc1, cls_fc2; const float *cls_fc1_b = nullptr, *cls_fc2_b = nullptr;   // findings classifier head
     void *cls_pooled = nullptr, *cls_h = nullptr, *cls_out = nullptr;
     void* zero16 = nullptr;          // 16 zero bytes: source of padding taps in the DMA conv gather
     void* d_cur_rope = nullptr;      // [B][2][128] cos | sin row of each row's current position (written by greedy_step_k)
     ChainLayer* d_clayers = nullptr; int* d_cctr = nullptr;
     int *d_ctr = nullptr, *d_err = nullptr;   // per-layer hand-off counters of the fused launch, sticky error flag
-    bool use_dma_gemm = true;        // RDX_DMA=0: route every large-M GEMM through tiled_gemm_k
     bool ws_ok = false;              // set while the image encoder runs: its many-row GEMMs / convolutions may take wsgemm_k
     float* gemm_ws = nullptr; size_t gemm_ws_floats = 0;      // split-K slabs of gemm_dma_k
     GraphKey gkey;

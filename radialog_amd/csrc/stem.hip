@@ -105,8 +105,6 @@ __global__ __launch_bounds__(256) void stem_pool_k(const T* __restrict__ in, con
 }
 
 bool stem_pool_supported(int stem_channels) {
-    const char* e = getenv("RDX_STEM_FUSED");
-    if (e && atoi(e) == 0) return false;
     return stem_channels == 64 || stem_channels == 32;
 }
 

@@ -223,28 +223,19 @@ __global__ __launch_bounds__(WAVES * 64) void wsgemm_k(GemmArgs a, ConvGeom cg, 
 // (128-row tiles: 14^2 stage, projector), C = 4 waves x 32 rows x 64 columns (Q-Former at batch: M = 32 x batch rows,
 // N = 768 .. 3072). Chosen so that the grid covers the chip.
 bool wsgemm_supported(const GemmArgs& a, const ConvGeom& cg, int epi) {
-    const char* e = getenv("RDX_WSGEMM");                        // 0 = off; else minimum row count
-    const int min_rows = e ? atoi(e) : 512;
-    // RDX_WSGEMM_PROMPT=1: one prompt's prefill GEMMs on the single-row-block shapes F / G / H. Measured and rejected: prefill of a
-    // 160-token prompt 7.5 -> 10.7 ms (T = 250: 8.8 -> 12.5 ms) -- off by default, the shapes stay covered by tests/test_gpu_gemm.py.
-    static const bool prompt_on = getenv("RDX_WSGEMM_PROMPT") && atoi(getenv("RDX_WSGEMM_PROMPT"));
-    const bool prompt_shape = prompt_on && a.M > 128 && a.M <= 256 && a.N >= 2048 && a.K <= 4096;
-    if (min_rows <= 0 || (a.M < min_rows && !prompt_shape) || a.K % 64 || a.N % 16 || a.ldo % 8) return false;
-    if (!(epi == EPI_NONE || epi == EPI_RELU || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_RESID_RELU || epi == EPI_SILU_MUL)) return false;
-    if (epi == EPI_SILU_MUL && (a.bias || cg.mode == 1)) return false;
+    constexpr int min_rows = 512;
+    // (Round 2 also tried it on one prompt's prefill GEMMs -- single 256-row block shapes F / G / H -- and on every encoder shape: prefill of a
+    // 160-token prompt 7.5 -> 10.7 ms, long-K / wide-N encoder shapes 10-60 % slower than the 128 x 128 LDS-DMA tiles; both removed in round 3.)
+    if (a.M < min_rows || a.K % 64 || a.N % 16 || a.ldo % 8) return false;
+    if (!(epi == EPI_NONE || epi == EPI_RELU || epi == EPI_GELU || epi == EPI_RESID || epi == EPI_RESID_RELU)) return false;
     if ((epi == EPI_RESID || epi == EPI_RESID_RELU) && (!a.resid || a.ldr % 8)) return false;
     if (a.N % 8) return false;
-    // where it measured faster than gemm_dma_k at batch 32 (tools/enc_kernels.py; RDX_WSGEMM_ALL=1 lifts the restriction): the
-    // 3x3 convolutions of layer1 / layer2 (Cin <= 128: 112 -> 90, 57 -> 51 us) and the residual epilogues with short K (c3 of layer4
-    // 43 -> 33 us, Q-Former output projection 17 -> 12 us: the coalesced epilogue). Long-K, wide-N shapes are bound by the operand
-    // bandwidth of a CU either way and the 128 x 128 LDS-DMA tiles do as well or better there.
-    static const bool all = getenv("RDX_WSGEMM_ALL") && atoi(getenv("RDX_WSGEMM_ALL"));
-    if (cg.mode == 1) return cg.Cin % 64 == 0 && (all || cg.Cin <= 128);
-    // one prompt's prefill GEMMs (128 < M <= 256 rows, wide N, K <= 4096: QKV, o_proj, gate/up; down_proj keeps the split-K LDS-DMA
-    // kernel): the single-row-block shapes F / G / H
-    const bool one_prompt = prompt_shape && (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL);
-    if (epi == EPI_SILU_MUL) return a.ldx % 8 == 0 && (one_prompt || all) && a.M <= 256;
-    return a.ldx % 8 == 0 && (all || one_prompt || ((epi == EPI_RESID || epi == EPI_RESID_RELU) && a.K <= 768));
+    // where it measured faster than gemm_dma_k at batch 32 (tools/enc_kernels.py): the 3x3 convolutions of layer1 / layer2 (Cin <= 128:
+    // 112 -> 90, 57 -> 51 us) and the residual epilogues with short K (c3 of layer4 43 -> 33 us, Q-Former output projection 17 -> 12 us: the
+    // coalesced epilogue). Long-K, wide-N shapes are bound by the operand bandwidth of a CU either way and the 128 x 128 LDS-DMA tiles do as
+    // well or better there.
+    if (cg.mode == 1) return cg.Cin % 64 == 0 && cg.Cin <= 128;
+    return a.ldx % 8 == 0 && (epi == EPI_RESID || epi == EPI_RESID_RELU) && a.K <= 768;
 }
 
 template <typename T, int EPI, int NT, int MT, int WAVES, bool CONV>
@@ -258,29 +249,12 @@ static void launch_ws_cfg(const GemmArgs& a, const ConvGeom& cg, const void* zer
 
 template <typename T, int EPI, bool CONV>
 static void launch_ws_epi(const GemmArgs& a, const ConvGeom& cg, const void* zero16, hipStream_t s) {
-    const char* e = getenv("RDX_WS_CFG");                        // force a tile shape: A .. H
-    // one prompt (or a few): 128 < M <= 256 rows. ONE row block of 4 waves x 64 rows holds every row (the weight slice is staged once,
-    // not once per 128-row tile, and each 1-KiB weight fragment read from LDS feeds 4 MFMAs); the column tile is as wide as still
-    // fills the chip: 128 (F), 64 (G) or 32 (H) columns
-    if (!CONV && a.M > 128 && a.M <= 256 && !(e && *e)) {
-        const int t128 = (a.N + 127) / 128;
-        if (t128 >= 160) launch_ws_cfg<T, EPI, 8, 4, 4, false>(a, cg, zero16, s);
-        else if (t128 >= 80) launch_ws_cfg<T, EPI, 4, 4, 4, false>(a, cg, zero16, s);
-        else launch_ws_cfg<T, EPI, 2, 4, 4, false>(a, cg, zero16, s);
-        return;
-    }
+    const char* e = getenv("RDX_WS_CFG");                        // tests: force a tile shape A .. E
     const int wgA = ((a.M + 511) / 512) * ((a.N + 127) / 128), wgB = ((a.M + 127) / 128) * ((a.N + 127) / 128);
     char cfg = a.N <= 64 ? 'D' : (wgA >= 200 ? 'A' : (wgB >= 160 ? 'B' : 'C'));
-    if (e && *e) cfg = *e;
+    if (e && *e >= 'A' && *e <= 'E') cfg = *e;
     // (the implicit-GEMM address state of a convolution does not fit next to 128 accumulators: its large tile is 256 rows, E)
-    if (cfg == 'A' && (CONV || (e && *e == 'E'))) cfg = 'E';
     if (CONV && cfg == 'A') cfg = 'E';
-    if (cfg == 'F' || cfg == 'G' || cfg == 'H') {
-        if (cfg == 'F') launch_ws_cfg<T, EPI, 8, 4, 4, false>(a, cg, zero16, s);
-        else if (cfg == 'G') launch_ws_cfg<T, EPI, 4, 4, 4, false>(a, cg, zero16, s);
-        else launch_ws_cfg<T, EPI, 2, 4, 4, false>(a, cg, zero16, s);
-        return;
-    }
     if (cfg == 'D') launch_ws_cfg<T, EPI, 4, 4, 8, CONV>(a, cg, zero16, s);          // N <= 64: 512 rows x 64 columns
     else if (cfg == 'E') launch_ws_cfg<T, EPI, 8, 2, 8, CONV>(a, cg, zero16, s);
     else if (cfg == 'A') launch_ws_cfg<T, EPI, 8, 4, 8, false>(a, cg, zero16, s);
@@ -296,7 +270,6 @@ static void launch_ws_T(const GemmArgs& a, const ConvGeom& cg, int epi, const vo
         case EPI_GELU: launch_ws_epi<T, EPI_GELU, CONV>(a, cg, zero16, s); break;
         case EPI_RESID: launch_ws_epi<T, EPI_RESID, CONV>(a, cg, zero16, s); break;
         case EPI_RESID_RELU: launch_ws_epi<T, EPI_RESID_RELU, CONV>(a, cg, zero16, s); break;
-        case EPI_SILU_MUL: if (!CONV) launch_ws_epi<T, EPI_SILU_MUL, false>(a, cg, zero16, s); break;
         default: break;
     }
 }

@@ -193,8 +193,7 @@ static int wstat_cfg(const GemmArgs& a, int epi) {
 }
 
 bool wstat_supported(const GemmArgs& a, int epi) {
-    static const int on = getenv("RDX_WSTAT") ? atoi(getenv("RDX_WSTAT")) : 1;
-    return on && wstat_cfg(a, epi) != 0;
+    return wstat_cfg(a, epi) != 0;
 }
 
 template <typename T, int EPI, int NT, int WAVES, int CPW, int RING>
@@ -209,10 +208,9 @@ static void launch_ws1(const GemmArgs& a, hipStream_t s) {
 template <typename T, int EPI>
 static void launch_ws_T(const GemmArgs& a, int cfg, hipStream_t s) {
     const int ntiles = (a.N + 15) >> 4;
-    static const int nt_env = getenv("RDX_WSTAT_NT") ? atoi(getenv("RDX_WSTAT_NT")) : 0;
     if (cfg == 2) { launch_ws1<T, EPI, 1, 8, 43, 8>(a, s); return; }
     // one tile per workgroup while that still gives every CU one (o_proj: 256 tiles); two otherwise
-    const int nt = nt_env ? nt_env : (ntiles <= 256 ? 1 : 2);
+    const int nt = ntiles <= 256 ? 1 : 2;
     if (nt == 1) launch_ws1<T, EPI, 1, 8, 16, 16>(a, s);
     else launch_ws1<T, EPI, 2, 8, 16, 16>(a, s);
 }

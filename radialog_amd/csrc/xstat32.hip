@@ -385,14 +385,11 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 // batch 8 3.53 -> 3.29, batch 16 4.23 -> 3.53 (rows beyond the batch ride along as zero columns of the 32-row block); batch 3 and
 // 4, whose rows would still fit the GEMV's LDS stage: 3.39 / 3.56 ms there. Batch 1-2 keep the fused / chained GEMV launches.
 int xs_min_rows() {
-    const char* e = getenv("RDX_XS_MINM");
-    return e ? atoi(e) : 3;
+    return 3;
 }
 
 // K groups for this shape (0 = not supported): needs fragment-packed activations (xpacked 1; 2 = the fp8 64-deep order)
 int xsplit32_groups(const GemmArgs& a) {
-    const char* e = getenv("RDX_XSPLIT");                     // 0 = off
-    if (e && atoi(e) == 0) return 0;
     const bool w8 = a.W8 && a.wscale;
     if (!(a.M >= xs_min_rows() && a.M <= 32) || a.xpacked != (w8 ? 2 : 1) || a.norm_w || a.bias || (a.N + 15) / 16 < 128 || (a.N + 15) / 16 > 512) return 0;
     if (a.K == 11008) return 4;
@@ -419,9 +416,8 @@ void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
 }
 
 bool xstat32_supported(const GemmArgs& a, int epi) {
-    const char* e = getenv("RDX_XS32");                       // minimum tile count (0 = off); read per launch (tests toggle it)
-    const int min_tiles = e ? atoi(e) : 512;
-    return min_tiles > 0 && a.M >= xs_min_rows() && a.M <= 32 && a.K == XS_K && !a.norm_w && (a.N + 15) / 16 >= min_tiles &&
+    constexpr int min_tiles = 512;                            // fewer tiles: the K-split variant (256-tile projections) or the GEMV family
+    return a.M >= xs_min_rows() && a.M <= 32 && a.K == XS_K && !a.norm_w && (a.N + 15) / 16 >= min_tiles &&
            (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL || epi == EPI_LOGITS);
 }
 

@@ -78,10 +78,7 @@ CASES = [
 # (RDX_WS_CFG), every epilogue, ragged M / N, one k-stage and many
 WS_CASES = [(cfg_, M, N, K, epi) for cfg_ in "ABCDE" for (M, N, K, epi) in
             [(700, 272, 64, 0), (1025, 128, 576, 1), (513, 768, 768, 3), (2048, 96, 1408, 2), (1300, 2064, 256, 6)]]
-# the single-prompt prefill shapes F / G / H (one 256-row block, 128 / 64 / 32 columns) incl. the SwiGLU epilogue on interleaved gate/up tiles
-WS_CASES += [(cfg_, M, N, K, epi) for cfg_ in "FGH" for (M, N, K, epi) in
-             [(160, 2064, 512, 0), (160, 4096, 1024, 3), (200, 2048, 512, 4), (129, 4128, 256, 4), (256, 2048, 4096, 0)]]
-WS_CASES += [("", 160, 22016, 4096, 4), ("", 160, 12304, 4096, 0), ("", 160, 4096, 4096, 3)]        # the production prefill shapes, default dispatch
+WS_CASES += [("", 1024, 768, 768, 3), ("", 6272, 2048, 512, 6)]        # production shapes it is dispatched for (Q-Former o_proj at batch 32, layer4 c3), default tile choice
 
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 profiling pass (run on the GPU box from the repo root): rocprofv3 kernel-trace summaries of the three phases and of the
+# Round-3 profiling pass (run on the GPU box from the repo root): rocprofv3 kernel-trace summaries of the three phases and of the
 # bench, PMC HBM-traffic passes of the decode kernels, and the per-shape encoder table. Text summaries only -> gpurun_out/prof/.
 set -u
 ROOT=$PWD
@@ -26,13 +26,16 @@ if [ $what = all ] || [ $what = trace ]; then
   trace enc_b32 6 python $ROOT/tools/enc_only.py 32 5
   trace prefill_b1 11 python $ROOT/tools/prefill_only.py 1 160 10
   trace prefill_b32 4 python $ROOT/tools/prefill_only.py 32 160 3
-  trace bench_b1 0 python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-b32
+  trace prefill_b32_fp8 4 python $ROOT/tools/prefill_only.py 32 160 3 fp8
+  trace bench_b1 0 python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-b32 --no-fp8
   trace bench_b32 0 python $ROOT/bench.py --batch 32 --steps 2 --warmup 1 --no-cpu-baseline
+  trace bench_b32_fp8 0 python $ROOT/bench.py --batch 32 --fp8 --steps 2 --warmup 1 --no-cpu-baseline
 fi
 if [ $what = all ] || [ $what = pmc ]; then
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    pmc b1 $ctr python $ROOT/bench.py --steps 1 --warmup 0 --new-tokens 8 --no-cpu-baseline --no-b32 --no-graph
+    pmc b1 $ctr python $ROOT/bench.py --steps 1 --warmup 0 --new-tokens 8 --no-cpu-baseline --no-b32 --no-fp8 --no-graph
     pmc b32 $ctr python $ROOT/bench.py --batch 32 --steps 1 --warmup 0 --new-tokens 8 --no-cpu-baseline --no-graph
+    pmc b32fp8 $ctr python $ROOT/bench.py --batch 32 --fp8 --steps 1 --warmup 0 --new-tokens 8 --no-cpu-baseline --no-graph
   done
 fi
 if [ $what = all ] || [ $what = shapes ]; then
@@ -42,6 +45,7 @@ fi
 du -sh $OUT
 if [ $what = prefill ]; then
   trace prefill_b32 4 python $ROOT/tools/prefill_only.py 32 160 3
+  trace prefill_b32_fp8 4 python $ROOT/tools/prefill_only.py 32 160 3 fp8
   trace prefill_b1 11 python $ROOT/tools/prefill_only.py 1 160 10
 fi
 if [ $what = prefill_pmc ]; then
