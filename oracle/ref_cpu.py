@@ -239,16 +239,17 @@ def positions_from_mask(mask: torch.Tensor) -> torch.Tensor:
 
 
 def fake_quant_e4m3(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
-    """fp32 values of x after OCP e4m3 quantisation along the last dim: one absmax / 448 scale per row and K group, group q = 64-deep
-    chunks [KC q / G, KC (q + 1) / G) -- q = RNE((x * (448 / absmax))), value = q * (absmax / 448); an all-zero range keeps scale 1.
-    The arithmetic of librdx's pack_weight_fp8_k / quant_rows_k / rmsnorm -> fp8 (the fp8 weight path of BASELINE configs[4])."""
+    """fp32 values of x after OCP e4m3 quantisation along the last dim: one absmax / 448 scale per row and K group, group q = 128-deep
+    blocks [NB q / G, NB (q + 1) / G), NB = K / 128 (the last group takes a K % 128 tail; per-row weight scales: groups = 1) --
+    q = RNE((x * (448 / absmax))), value = q * (absmax / 448); an all-zero range keeps scale 1. The arithmetic of librdx's
+    pack_weight_fp8_k / quant_rows_k / rmsnorm -> fp8 (the fp8 weight path of BASELINE configs[4])."""
     xf = x.float()
     K = xf.shape[-1]
-    KC = K // 64
+    NB = K // 128
     out = torch.empty_like(xf)
     for q in range(groups):
-        a = (KC * q // groups) * 64
-        b = K if q == groups - 1 else (KC * (q + 1) // groups) * 64
+        a = (NB * q // groups) * 128
+        b = K if q == groups - 1 else (NB * (q + 1) // groups) * 128
         seg = xf[..., a:b]
         am = seg.abs().amax(dim=-1, keepdim=True)
         inv = torch.where(am > 0, 448.0 / am, torch.ones_like(am))

@@ -310,11 +310,12 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
         HIPCHK(c, hipGetLastError());
         return 0;
     }
-    if (force == 4) {                     // fp8 weights: quantise here, stream the e4m3 bytes
+    if (force == 4) {                     // fp8 weights as the engine holds them: e4m3 bytes + scales only (no model-dtype copy)
         if (K % 64) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: fp8 needs K %% 64 == 0"); }
+        w.w = nullptr;
         w.w8 = (char*)wp + (size_t)N * K * 2;
         w.scale = (float*)((char*)wp + (size_t)N * K * 3);
-        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, wp, N, K, N, c->stream);
+        launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, nullptr, N, K, N, c->stream);
         force = 1;
     } else
     launch_pack_weight(c->cfg.dtype, W, wp, N, K, N, nullptr, c->stream);

@@ -15,7 +15,8 @@ template <int PACK> __device__ __forceinline__ unsigned char* dst8(unsigned char
 }
 
 // Row-wise e4m3 quantisation of model-dtype activations [rows][K] (row stride ldx) into row-major bytes [rows][K] + scales [rows][G]:
-// K group q = 64-deep chunks [KC q / G, KC (q + 1) / G) (G <= 4), one absmax / 448 scale per (row, group). One workgroup per row.
+// K group q = 128-deep blocks [NB q / G, NB (q + 1) / G), NB = K / 128 (G <= 4; K % 128 == 0), one absmax / 448 scale per (row, group). One
+// workgroup per row.
 template <typename T>
 __global__ __launch_bounds__(256) void quant_rows_k(const T* __restrict__ x, long ldx, unsigned char* __restrict__ out8, float* __restrict__ xscale,
                                                     int K, int G) {
@@ -24,10 +25,10 @@ __global__ __launch_bounds__(256) void quant_rows_k(const T* __restrict__ x, lon
     __shared__ float gmax[4];
     const size_t row = blockIdx.x;
     const T* xr = x + row * ldx;
-    const int KC = K >> 6;
+    const int NB = K >> 7;
     int end[4];                                                 // first element past group q
 #pragma unroll
-    for (int q = 0; q < 4; ++q) end[q] = q < G ? ((KC * (q + 1)) / G) * 64 : K;
+    for (int q = 0; q < 4; ++q) end[q] = q < G ? ((NB * (q + 1)) / G) * 128 : K;
     auto group_of = [&](int i) { return (i >= end[0]) + (i >= end[1]) + (i >= end[2]); };
     float mx[4] = {0.f, 0.f, 0.f, 0.f};
     for (int i = threadIdx.x * 8; i < K; i += blockDim.x * 8) {

@@ -3,7 +3,7 @@
 // Weights: OCP e4m3, one absmax / 448 scale per output row, stored in the 64-deep fragment order [n_tile16][k_chunk64][lane (g, r)][16]
 // (gemm.hip: pack_weight_fp8_k) -- lane (g, r) holds W[16 nt + r][64 kc + 16 g .. + 16]: one 16-byte piece feeds TWO
 // v_mfma_f32_16x16x32_fp8_fp8 (bytes 0..7 and 8..15). Activations: e4m3 row-major [M][K], quantised per row and per K GROUP
-// (`xgroups` ranges of K: group q = 64-deep chunks [KC q / G, KC (q + 1) / G); 1 for the projections behind an RMSNorm, 2 for o_proj, 4 for down_proj -- the
+// (`xgroups` ranges of K: group q = 128-deep blocks [NB q / G, NB (q + 1) / G), NB = K / 128; 1 for the projections behind an RMSNorm, 2 for o_proj, 4 for down_proj -- the
 // ranges one workgroup of the batch 3-32 K-split decode kernels holds, xstat32.hip, so that one rule describes prefill and decode),
 // scale = absmax / 448 in fp32 [M][xgroups] (elem.hip: quant_rows_k, rmsnorm -> fp8). The LoRA-B product and every other epilogue
 // stay in the model dtype (finetune.py:167-173 keeps the adapter un-merged, demo.py:232-234).
@@ -12,8 +12,10 @@
 //   operands, fp32): same value up to fp32 rounding order.
 // Two kernels, the LDS-DMA pipelines of gemm_dma.hip with twice the MFMAs per staged byte:
 //   gemm8_k      128 x 128 block, 4 waves (2 x 2), BK = 128 per step (32 KiB staged: 16 + 16 pieces of 1 KiB), two LDS buffers, counted
-//                vmcnt + raw s_barrier; any M, N % 16 == 0, K % 128 == 0 (or K % 64 == 0 with an odd last step handled by clamping);
-//   gemm8_256_k  256 x 256 block, 8 waves (2 x 4), one 64-deep chunk per stage, four-stage ring (M >= 1024 and >= 256 blocks).
+//                vmcnt + raw s_barrier; any M, N % 16 == 0, K % 128 == 0;
+//   gemm8_256_k  256 x 256 block, 8 waves (2 x 4), a pair of chunks (K = 128) per step, two LDS buffers (M >= 1024 and >= 256 blocks).
+// Both issue v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: K = 128 per instruction, twice the bf16 MFMA rate (the K groups are
+// whole 128-deep blocks, so a step never straddles a boundary).
 // Epilogues: NONE, RESID (out = resid + T(v)), SILU_MUL (gate / up rows interleaved 8 + 8 per tile).
 #include <algorithm>
 #include <stdlib.h>
@@ -27,11 +29,16 @@ namespace rdx {
 typedef __attribute__((address_space(1))) const void* gptr8_t;
 typedef __attribute__((address_space(3))) void* lptr8_t;
 
-__device__ __forceinline__ v4f mfma8(const u4& a, const u4& b, v4f c) {
-    const long a0 = (long)(((unsigned long long)a.y << 32) | a.x), a1 = (long)(((unsigned long long)a.w << 32) | a.z);
-    const long b0 = (long)(((unsigned long long)b.y << 32) | b.x), b1 = (long)(((unsigned long long)b.w << 32) | b.z);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, c, 0, 0, 0);
+// Two consecutive 64-deep pieces of each operand at once on the block-scaled instruction v_mfma_scale_f32_16x16x128_f8f6f4 (formats e4m3 x e4m3,
+// every E8M0 block scale = 2^0): one MFMA of K = 128 at TWICE the bf16 rate (MI355X_MICROARCH.md: the non-scaled fp8 16x16x32 runs at the
+// bf16 rate). It is a dot product over its 128 k slots, so ANY slot <-> k assignment is valid as long as both operands use the same one:
+// a lane's 32 bytes are simply its 16-byte pieces of chunk c and chunk c + 1 (k = 64 c + 16 g .. + 16 and 64 (c + 1) + 16 g .. + 16).
+typedef int v8i __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ v8i pair8(const u4& p0, const u4& p1) {
+    return (v8i){(int)p0.x, (int)p0.y, (int)p0.z, (int)p0.w, (int)p1.x, (int)p1.y, (int)p1.z, (int)p1.w};
+}
+__device__ __forceinline__ v4f mfma8x2(const v8i& a, const v8i& b, v4f c) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
 
 // 4 consecutive columns n .. n + 3 of row m: v already carries both scales
@@ -116,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm8_k(GemmArgs a) {
     const int r = lane & 15, g = lane >> 4;
     const int wm = w >> 1, wn = w & 1;
     const int KC = a.K >> 6, NT16 = (a.N + 15) >> 4;                  // 64-deep chunks
-    const int nsteps = (KC + 1) >> 1;                                  // two chunks per step (an odd last chunk is clamped and skipped)
+    const int nsteps = KC >> 1;                                        // two chunks per step (K % 128 == 0)
     const unsigned char* X8 = reinterpret_cast<const unsigned char*>(a.X);
     const u4* Wp = reinterpret_cast<const u4*>(a.W8);
 
@@ -148,8 +155,8 @@ __global__ __launch_bounds__(256) void gemm8_k(GemmArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
-    const int G = a.xgroups > 0 ? a.xgroups : 1;                      // K group q = 64-deep chunks [KC q / G, KC (q + 1) / G)
-    int grp = 0, next_b = KC / G;
+    const int G = a.xgroups > 0 ? a.xgroups : 1;                      // K group q = steps (128-deep blocks) [nsteps q / G, nsteps (q + 1) / G)
+    int grp = 0, next_b = nsteps / G;
 
     if (nsteps > 0) stage(0, 0);
     for (int s = 0; s < nsteps; ++s) {
@@ -162,34 +169,32 @@ __global__ __launch_bounds__(256) void gemm8_k(GemmArgs a) {
         }
         __builtin_amdgcn_s_barrier();
         const u4* base = lds + (size_t)buf * 2 * 16 * 64;
+        if (s == next_b && grp + 1 < G) { regroup8<4, 4>(a, acc, M0, wm, r, grp); ++grp; next_b = (nsteps * (grp + 1)) / G; }
+        v8i wf[4], xf[4];                                             // a lane's pieces of both chunks of the step: one K = 128 operand
 #pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            const int c = 2 * s + kc;
-            if (c >= KC) break;                                       // odd number of chunks: the clamped duplicate is not multiplied
-            if (c == next_b && grp + 1 < G) { regroup8<4, 4>(a, acc, M0, wm, r, grp); ++grp; next_b = (KC * (grp + 1)) / G; }
-            u4 wf[4], xf[4];
+        for (int nt = 0; nt < 4; ++nt) wf[nt] = pair8(base[((wn * 4 + nt) * 2 + 0) * 64 + lane], base[((wn * 4 + nt) * 2 + 1) * 64 + lane]);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) wf[nt] = base[((wn * 4 + nt) * 2 + kc) * 64 + lane];
+        for (int mt = 0; mt < 4; ++mt) xf[mt] = pair8(base[(16 + (wm * 4 + mt) * 2 + 0) * 64 + lane], base[(16 + (wm * 4 + mt) * 2 + 1) * 64 + lane]);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) xf[mt] = base[(16 + (wm * 4 + mt) * 2 + kc) * 64 + lane];
+        for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma8(wf[nt], xf[mt], acc[nt][mt]);
-        }
+            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = mfma8x2(wf[nt], xf[mt], acc[nt][mt]);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                   // everyone is done reading buf before it is re-staged
     }
     epilogue8<T, EPI, 4, 4>(a, acc, M0, N0, wm, wn, r, g);
 }
 
-// ---- 256 x 256 block, four-stage ring (the batched prefill: M = 5120) ---------------------------------------------------------------
-constexpr int G8B_NS = 4, G8B_MTW = 8;
+// ---- 256 x 256 block (the batched prefill: M = 5120) ---------------------------------------------------------------------------------
+// 8 waves as 2 x 4 with 128 x 64 wave tiles; a STEP is a pair of 64-deep chunks (K = 128: 64 KiB staged, 16 + 16 pieces per chunk), two LDS
+// buffers; per step a wave reads 8 weight and 16 activation pieces and issues 32 K = 128 MFMAs. The next step's 8 LDS-DMA pieces per wave are
+// issued one by one behind the MFMAs of this step (they cost 60-185 cycles of issue each, gemm_dma256_k).
+constexpr int G8B_MTW = 8;
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
-    constexpr int XS = 16, SUB = 32;                                    // activation sub-tiles / KiB per stage
-    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [stage 4][W 16 | X 16][lane 64]
+    constexpr int CH = 32 * 64;                                         // u4 per chunk image: [W 16 | X 16][lane 64]
+    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [buffer 2][chunk 2][W 16 | X 16][lane 64]
     const int MB = (a.M + 255) / 256, NB = (a.N + 255) / 256;
     const int nwg = MB * NB;
     int tile;
@@ -203,11 +208,11 @@ __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
     const int r = lane & 15, g = lane >> 4;
     const int wm = w >> 2, wn = w & 3;
     const int KC = a.K >> 6, NT16 = (a.N + 15) >> 4;
-    const int nsteps = KC;                                              // one 64-deep chunk per stage
+    const int nsteps = KC >> 1;                                         // pairs of chunks (K % 128 == 0)
     const unsigned char* X8 = reinterpret_cast<const unsigned char*>(a.X);
     const u4* Wp = reinterpret_cast<const u4*>(a.W8) + lane;
 
-    // this wave stages weight sub-tiles 2 w, 2 w + 1 and activation sub-tiles 2 w, 2 w + 1
+    // this wave stages weight sub-tiles 2 w, 2 w + 1 and activation sub-tiles 2 w, 2 w + 1 of both chunks of a step: 8 pieces
     const u4* wsrc[2];
     const unsigned char* xsrc[2];
 #pragma unroll
@@ -215,14 +220,11 @@ __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
         wsrc[j] = Wp + (size_t)min((N0 >> 4) + w * 2 + j, NT16 - 1) * KC * 64;
         xsrc[j] = X8 + (size_t)min(M0 + (w * 2 + j) * 16 + r, a.M - 1) * a.ldx + g * 16;
     }
-    auto stage1 = [&](int s, int slot, int j) {                         // piece j of this wave's 4 pieces of stage s (j compile-time at every call)
-        u4* base = lds + (size_t)slot * SUB * 64;
-        if (j < 2) __builtin_amdgcn_global_load_lds((gptr8_t)(wsrc[j] + (size_t)s * 64), (lptr8_t)(base + (w * 2 + j) * 64), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((gptr8_t)(xsrc[j - 2] + (size_t)s * 64), (lptr8_t)(base + (16 + w * 2 + j - 2) * 64), 16, 0, 0);
-    };
-    auto stage = [&](int s, int slot) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) stage1(s, slot, j);
+    auto stage1 = [&](int s, int buf, int j) {                          // piece j = 0..7 of step s: chunk j >> 2, operand / sub-tile j & 3
+        const int ch = j >> 2, q = j & 3, c = min(2 * s + ch, KC - 1);
+        u4* base = lds + ((size_t)buf * 2 + ch) * CH;
+        if (q < 2) __builtin_amdgcn_global_load_lds((gptr8_t)(wsrc[q] + (size_t)c * 64), (lptr8_t)(base + (w * 2 + q) * 64), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gptr8_t)(xsrc[q - 2] + (size_t)c * 64), (lptr8_t)(base + (16 + w * 2 + q - 2) * 64), 16, 0, 0);
     };
 
     v4f acc[4][G8B_MTW];
@@ -231,28 +233,30 @@ __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < G8B_MTW; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
     const int G = a.xgroups > 0 ? a.xgroups : 1;
-    int grp = 0, next_b = KC / G;
+    int grp = 0, next_b = nsteps / G;
 
 #pragma unroll
-    for (int p = 0; p < G8B_NS - 1; ++p) stage(min(p, nsteps - 1), p);   // stages 0..2 in flight
+    for (int j = 0; j < 8; ++j) stage1(0, 0, j);
     for (int s = 0; s < nsteps; ++s) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");               // this wave's 4 loads of stage s have landed (two younger stages may fly)
-        __builtin_amdgcn_s_barrier();                                   // ... everyone's have, and everyone finished stage s - 1
-        const int sn = min(s + G8B_NS - 1, nsteps - 1), slotn = (s + G8B_NS - 1) % G8B_NS;
-        if (s == next_b && grp + 1 < G) { regroup8<4, G8B_MTW>(a, acc, M0, wm, r, grp); ++grp; next_b = (KC * (grp + 1)) / G; }
-        const u4* base = lds + (size_t)(s % G8B_NS) * SUB * 64;
-        u4 wf[4];
+        const int buf = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's pieces of step s have landed
+        __builtin_amdgcn_s_barrier();                                   // ... everyone's have, and everyone finished reading the other buffer
+        const int sn = min(s + 1, nsteps - 1);                          // (past the end: the last step again, harmless)
+        if (s == next_b && grp + 1 < G) { regroup8<4, G8B_MTW>(a, acc, M0, wm, r, grp); ++grp; next_b = (nsteps * (grp + 1)) / G; }
+        const u4* b0 = lds + ((size_t)buf * 2 + 0) * CH;
+        const u4* b1 = lds + ((size_t)buf * 2 + 1) * CH;
+        v8i wf[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wf[nt] = base[(wn * 4 + nt) * 64 + lane];
+        for (int nt = 0; nt < 4; ++nt) wf[nt] = pair8(b0[(wn * 4 + nt) * 64 + lane], b1[(wn * 4 + nt) * 64 + lane]);
 #pragma unroll
         for (int mt = 0; mt < G8B_MTW; ++mt) {
-            const u4 xf = base[(16 + wm * G8B_MTW + mt) * 64 + lane];
+            const v8i xf = pair8(b0[(16 + wm * G8B_MTW + mt) * 64 + lane], b1[(16 + wm * G8B_MTW + mt) * 64 + lane]);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma8(wf[nt], xf, acc[nt][mt]);
-            // the next stage's LDS-DMA pieces one by one behind the MFMAs of row tiles 1, 3, 5, 7 (see gemm_dma256_k)
-            if ((mt & 1) == 1) { stage1(sn, slotn, mt >> 1); __builtin_amdgcn_sched_barrier(0); }
+            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma8x2(wf[nt], xf, acc[nt][mt]);
+            stage1(sn, buf ^ 1, mt);                                    // one LDS-DMA piece of the next step behind every row tile's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // LDS reads of this stage are done before the next barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // LDS reads of this step are done before the next barrier
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     epilogue8<T, EPI, 4, G8B_MTW>(a, acc, M0, N0, wm, wn, r, g);
@@ -260,7 +264,7 @@ __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
 
 bool gemm8_supported(const GemmArgs& a, int epi) {
     const int G = a.xgroups > 0 ? a.xgroups : 1;
-    return a.W8 && a.wscale && a.xscale && a.K % 64 == 0 && a.K / 64 >= G && G <= 4 && a.N % 16 == 0 && a.ldx % 16 == 0 && a.M >= 1 && !a.bias &&
+    return a.W8 && a.wscale && a.xscale && a.K % 128 == 0 && a.K / 128 >= G && G <= 4 && a.N % 16 == 0 && a.ldx % 16 == 0 && a.M >= 1 && !a.bias &&
            !a.norm_w && (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL);
 }
 
@@ -268,7 +272,7 @@ template <typename T, int EPI>
 static void launch_gemm8_epi(const GemmArgs& a, hipStream_t s) {
     const int MB2 = (a.M + 255) / 256, NB2 = (a.N + 255) / 256;
     if (a.M >= 1024 && a.K >= 512 && a.N >= 1024 && MB2 * NB2 >= 256) {
-        const size_t smem = (size_t)G8B_NS * 32 * 64 * sizeof(u4);      // 128 KiB
+        const size_t smem = (size_t)2 * 2 * 32 * 64 * sizeof(u4);       // 128 KiB
         static bool attr = false;
         if (!attr) { hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
         hipLaunchKernelGGL((gemm8_256_k<T, EPI>), dim3(MB2 * NB2), dim3(512), smem, s, a);

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
 // against the liveness rule of handoff.h; removed in round 2.)
 // A8 (with W8): the workgroup quantises ITS K range of the (model-dtype, fragment-packed) activations to e4m3 at start-up -- one absmax / 448
 // scale per row over the range (cross-wave maximum through LDS) -- and multiplies fp8 x fp8; the partial carries wscale[n] * that scale. The
-// ranges of the KGN groups are the `xgroups` K groups of the fp8 scheme (gemm8.hip): o_proj 2, down_proj 4.
+// ranges of the KGN groups are the `xgroups` K groups of the fp8 scheme (gemm8.hip; whole 128-deep blocks): o_proj 2, down_proj 4.
 template <typename T, int KC, int KGN, bool W8, int TPI, bool A8 = false>
 __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __restrict__ slab) {
     static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
@@ -251,7 +251,14 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 #define XS_T(i) do { if (trc) trc[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
     XS_T(0);
     const int slot = kg * XS_WAVES + wa;
-    const int c0 = (KC * slot) / SLOTS, cnt = (KC * (slot + 1)) / SLOTS - c0;      // wave-uniform
+    int c0 = (KC * slot) / SLOTS, cnt = (KC * (slot + 1)) / SLOTS - c0;      // wave-uniform
+    if (A8) {
+        // fp8 x fp8: the K range of group kg is the scheme's quantisation group -- whole 128-deep blocks [NB kg / KGN, NB (kg + 1) / KGN), NB = K / 128
+        // (gemm8.hip) -- split evenly over the 8 waves (KC counts 64-deep chunks here)
+        const int gs = 2 * (((KC >> 1) * kg) / KGN), ge = 2 * (((KC >> 1) * (kg + 1)) / KGN);
+        c0 = gs + ((ge - gs) * wa) / XS_WAVES;
+        cnt = gs + ((ge - gs) * (wa + 1)) / XS_WAVES - c0;
+    }
     const u4* wbase = reinterpret_cast<const u4*>(W8 ? a.W8 : a.W) + (size_t)c0 * 64;
     auto tile_ptr = [&](int t) { return wbase + (size_t)min(t, ntiles - 1) * KC * 64; };
 
