@@ -36,8 +36,11 @@ template <typename T> __device__ __forceinline__ float scale_score(float s);
 template <> __device__ __forceinline__ float scale_score<bf16>(float s) { return rnd<bf16>(s * 0.08838834764831845f); }
 template <> __device__ __forceinline__ float scale_score<f16>(float s) { return rnd<f16>(s / 11.313708498984761f); }
 
-template <typename T>
-__global__ __launch_bounds__(FL_WAVES * 64, 3) void flash_prefill_k(AttnArgs a) {
+// KPERM (compile time, like the key mask being mandatory): a run-time select between the two K layouts, or a null check of the mask pointer,
+// puts every K load of the tile loops into a basic block of its own -- hipcc then branches around each load and waits vmcnt(0) per load
+// (cdna_hip_programming.md 5, trap (c)): the first build of this kernel ran 112 us per layer, no faster than attention_k.
+template <typename T, bool KPERM>
+__global__ __launch_bounds__(FL_WAVES * 64, 4) void flash_prefill_k(AttnArgs a) {
     typedef typename Vec8<T>::type V8;
     typedef T T4 __attribute__((ext_vector_type(4)));
     typedef T T2 __attribute__((ext_vector_type(2)));
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(FL_WAVES * 64, 3) void flash_prefill_k(AttnArgs a) 
     const T* Q = reinterpret_cast<const T*>(a.Q) + b * a.q_bs + h * a.q_hs;
     const T* K = reinterpret_cast<const T*>(a.K) + b * a.k_bs + h * a.k_hs;
     const T* V = reinterpret_cast<const T*>(a.V) + b * a.v_bs + h * a.v_hs;
-    const uint8_t* km = a.key_mask ? a.key_mask + b * a.km_bs : nullptr;
+    const uint8_t* km = a.key_mask + b * a.km_bs;
     const int Tq = a.Tq, Tk = a.Tk, off = Tk - Tq;
     const int qw = q0 + w * 16, q = qw + r;               // this wave's first query, this lane's query
 
@@ -72,8 +75,8 @@ __global__ __launch_bounds__(FL_WAVES * 64, 3) void flash_prefill_k(AttnArgs a) 
         const int key = min(kt * 16 + r, Tk - 1);          // keys >= Tk are clamped here and masked in score()
 #pragma unroll
         for (int kc = 0; kc < FL_DC; ++kc)
-            kf[kc] = as_vec8<T>(ldg16(a.k_perm ? K + kperm(key, kc * 32 + g * 8) : K + (long)key * a.k_ts + kc * 32 + g * 8));
-        mw = km ? *reinterpret_cast<const unsigned*>(km + min(kt * 16 + g * 4, (int)a.km_bs - 4)) : 0x01010101u;
+            kf[kc] = as_vec8<T>(ldg16(KPERM ? K + kperm(key, kc * 32 + g * 8) : K + (long)key * a.k_ts + kc * 32 + g * 8));
+        mw = *reinterpret_cast<const unsigned*>(km + min(kt * 16 + g * 4, (int)a.km_bs - 4));
     };
     // the four scores of this lane for key tile kt (keys 16 kt + 4 g + e, query q): rounded like the reference, -inf where masked
     auto score = [&](int kt, const V8 (&kf)[FL_DC], unsigned mw, float (&sv)[4]) {
@@ -95,13 +98,11 @@ __global__ __launch_bounds__(FL_WAVES * 64, 3) void flash_prefill_k(AttnArgs a) 
         V8 ka[FL_DC], kb[FL_DC];
         unsigned ma = 0, mb = 0;
         float sv[4];
-        auto fold = [&]() {
-            const float tm = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-            if (tm > -INFINITY) {
-                const float mn = fmaxf(m, tm);
-                l = l * expf(m - mn) + ((expf(sv[0] - mn) + expf(sv[1] - mn)) + (expf(sv[2] - mn) + expf(sv[3] - mn)));   // exp(-inf) = 0
-                m = mn;
-            }
+        auto fold = [&]() {                                  // branch-free: an all-masked tile leaves (m, l) = (-inf, 0) through exp(-inf) = 0
+            const float mn = fmaxf(m, fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
+            const float ms = mn > -INFINITY ? mn : 0.f;
+            l = l * expf(m - ms) + ((expf(sv[0] - ms) + expf(sv[1] - ms)) + (expf(sv[2] - ms) + expf(sv[3] - ms)));
+            m = mn;
         };
         int kt = 0;
         if (kt < nkt_w) load_kt(kt, ka, ma);
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(FL_WAVES * 64, 3) void flash_prefill_k(AttnArgs a) 
 #pragma unroll
     for (int o = 16; o <= 32; o <<= 1) {
         const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
-        const float mn = fmaxf(m, mo);
-        l = (mn > -INFINITY) ? l * expf(m - mn) + lo * expf(mo - mn) : 0.f;
+        const float mn = fmaxf(m, mo), ms = mn > -INFINITY ? mn : 0.f;
+        l = l * expf(m - ms) + lo * expf(mo - ms);
         m = mn;
     }
     const bool any_key = (m > -INFINITY) && l > 0.f;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(FL_WAVES * 64, 3) void flash_prefill_k(AttnArgs a) 
         load_v(0, vr);
         load_kt(0, ka, ma); load_kt(min(1, last_t), kb, mb);
         stage_v(0, vr);
-        if (nch > 1) load_v(1, vr);
+        load_v(min(1, nch - 1), vr);
         __syncthreads();
         for (int c = 0; c < nch; ++c) {
             float s0[4], s1[4];
@@ -164,8 +165,8 @@ __global__ __launch_bounds__(FL_WAVES * 64, 3) void flash_prefill_k(AttnArgs a) 
             V8 pf;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                pf[e] = fromf<T>(s0[e] > -INFINITY ? expf(s0[e] - m_use) / l_use : 0.f);         // exp / sum like torch's softmax (a true division)
-                pf[4 + e] = fromf<T>(s1[e] > -INFINITY ? expf(s1[e] - m_use) / l_use : 0.f);
+                pf[e] = fromf<T>(expf(s0[e] - m_use) / l_use);         // exp / sum like torch's softmax (a true division); masked: exp(-inf) = 0
+                pf[4 + e] = fromf<T>(expf(s1[e] - m_use) / l_use);
             }
             const int buf = c & 1;
 #pragma unroll
@@ -177,9 +178,10 @@ __global__ __launch_bounds__(FL_WAVES * 64, 3) void flash_prefill_k(AttnArgs a) 
                 for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
                 acco[dt] = mfma16(vf, pf, acco[dt]);             // D[i = d_local = 4 g + e][j = q_local = r]
             }
-            // V of chunk c + 1 (already in registers) goes to the other buffer, chunk c + 2 is requested; one barrier per chunk
-            if (c + 1 < nch) stage_v((c + 1) & 1, vr);
-            if (c + 2 < nch) load_v(c + 2, vr);
+            // V of chunk c + 1 (already in registers) goes to the other buffer, chunk c + 2 is requested; one barrier per chunk. Unconditional
+            // (past the end: the last chunk again, into the buffer nobody reads any more): no load of the loop sits under a branch
+            stage_v((c + 1) & 1, vr);
+            load_v(min(c + 2, nch - 1), vr);
             __syncthreads();
         }
     }
@@ -209,12 +211,15 @@ bool flash_prefill_supported(int head_dim, const AttnArgs& a) {
     const int min_wgs = e ? atoi(e) : 512;
     const long wgs = (long)((a.Tq + FL_QB - 1) / FL_QB) * a.H * a.B;
     return min_wgs > 0 && head_dim == FL_D && wgs >= min_wgs && (a.v_ts & 7) == 0 && (a.q_ts & 7) == 0 && (a.k_perm || (a.k_ts & 7) == 0) &&
-           (!a.key_mask || (a.km_bs & 3) == 0);
+           a.key_mask && (a.km_bs & 3) == 0;
 }
 
 void launch_flash_prefill(int dtype, const AttnArgs& a, hipStream_t s) {
     dim3 grid((a.Tq + FL_QB - 1) / FL_QB, a.H, a.B), block(FL_WAVES * 64);
-    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((flash_prefill_k<T>), grid, block, 0, s, a));
+    RDX_DISPATCH_T(dtype, T, {
+        if (a.k_perm) hipLaunchKernelGGL((flash_prefill_k<T, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((flash_prefill_k<T, false>), grid, block, 0, s, a);
+    });
 }
 
 }  // namespace rdx

@@ -314,6 +314,12 @@ def _production_width_weights(layers):
 
 
 PROD_TOL = {"f16": 1e-2, "bf16": 8e-2}      # north_star: logits within 1e-2 in fp16; bf16 has 8x the ulp
+# fp8 x fp8 path (BASELINE configs[4]; the oracle is this repo's own fake-quantised restatement, the reference has no fp8 mode): the e4m3
+# quantiser is discontinuous -- an activation that differs by one model-dtype ulp between the two sides (accumulation order) can land on
+# the next e4m3 code, 2^-3 of its magnitude away, whatever the model dtype -- so the logit noise is set by the e4m3 grid, not by fp16 / bf16:
+# measured 0.17-0.26 per step at production width (one layer), 0.45 over 48 x 32 x 32 001 logits, 0.21-0.24 on the small config in fp16.
+# A wrong scale, group boundary or layout shows up as O(1-10); the token margin rule applies unchanged.
+FP8_TOL = 0.5
 
 
 def _prefix_err(scores, ref_scores, tok_a, tok_b, N):
@@ -362,8 +368,8 @@ prefill (gemm8.hip) and from batch 3 in decode (xstat32.hip); the oracle runs th
                      if with_exact else None)
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
         tol = PROD_TOL[dtype] * layers ** 0.5        # accumulation-order noise adds up layer by layer (two layers: 1.4e-2 in fp16)
-        if fp8:     # e4m3 activations (prefill; decode from batch 3): an input one model-dtype ulp apart can land on the next e4m3 code (6 % apart);
-            tol *= 3.0   # measured 0.17 at batch 32 in bf16 (the model-dtype path: 0.05-0.09)
+        if fp8:     # e4m3 activations (prefill; decode from batch 3): the noise is the e4m3 grid's (FP8_TOL above)
+            tol = FP8_TOL
         leg = check_greedy(toks, scores, ref, tol, MIN_COVER[dtype] if B * N >= 48 else 0.0, f"B={B} {dtype} fp8={fp8} layers={layers}")
         if B * N < 48:
             SMALL_LEGS[dtype].add(leg)
@@ -465,7 +471,7 @@ def test_production_width_decode_over_the_bench_positions_teacher_forced(B, N, d
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True, fp8=fp8).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
         eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=(T + N + 31) // 32 * 32, lora=True, vision=False, weights_fp8=fp8)
         eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
-        same, total, worst = _teacher_forced(eng, ref, ids, qf, N, PROD_TOL[dtype] * (3 if fp8 else 1), f"B={B} {dtype} fp8={fp8}")
+        same, total, worst = _teacher_forced(eng, ref, ids, qf, N, FP8_TOL if fp8 else PROD_TOL[dtype], f"B={B} {dtype} fp8={fp8}")
         eng.close()
         print(f"teacher-forced production width B={B} {dtype} fp8={fp8}: {same}/{total} argmax tokens identical over positions {T}..{T + N - 1}, "
               f"worst logit error {worst:.4g}")
@@ -607,8 +613,7 @@ def test_fp8_weight_decode_matches_fake_quantised_oracle(cfg, cpu_w, B):
         with torch.no_grad():
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True, fp8=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
-        tol = 2 * LOGIT_TOL[dtype]
-        SMALL_LEGS[dtype].add(check_greedy(toks, scores, ref, tol, 0.0, f"{dtype} fp8 B={B}"))
+        SMALL_LEGS[dtype].add(check_greedy(toks, scores, ref, FP8_TOL, 0.0, f"{dtype} fp8 B={B}"))
         eng.close()
 
 
