@@ -13,7 +13,7 @@
 // Two kernels, the LDS-DMA pipelines of gemm_dma.hip with twice the MFMAs per staged byte:
 //   gemm8_k      128 x 128 block, 4 waves (2 x 2), BK = 128 per step (32 KiB staged: 16 + 16 pieces of 1 KiB), two LDS buffers, counted
 //                vmcnt + raw s_barrier; any M, N % 16 == 0, K % 128 == 0;
-//   gemm8_256_k  256 x 256 block, 8 waves (2 x 4), a pair of chunks (K = 128) per step, two LDS buffers (M >= 1024 and >= 256 blocks).
+//   gemm8_256_k  256 (or 320) x 256 block, 8 waves (2 x 4), a pair of chunks (K = 128) per step, two LDS buffers (M >= 1024 and >= 256 blocks).
 // Both issue v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: K = 128 per instruction, twice the bf16 MFMA rate (the K groups are
 // whole 128-deep blocks, so a step never straddles a boundary).
 // Epilogues: NONE, RESID (out = resid + T(v)), SILU_MUL (gate / up rows interleaved 8 + 8 per tile).
@@ -189,13 +189,16 @@ __global__ __launch_bounds__(256) void gemm8_k(GemmArgs a) {
 // 8 waves as 2 x 4 with 128 x 64 wave tiles; a STEP is a pair of 64-deep chunks (K = 128: 64 KiB staged, 16 + 16 pieces per chunk), two LDS
 // buffers; per step a wave reads 8 weight and 16 activation pieces and issues 32 K = 128 MFMAs. The next step's 8 LDS-DMA pieces per wave are
 // issued one by one behind the MFMAs of this step (they cost 60-185 cycles of issue each, gemm_dma256_k).
-constexpr int G8B_MTW = 8;
-
-template <typename T, int EPI>
+// MTW row tiles per wave: 8 (256-row blocks) or 10 (320-row blocks, 72 KiB per step: taken when they save a round of workgroups on the 256
+// CUs -- the N = 4096 projections at M = 5120 are 320 blocks of 256 rows but 256 of 320, like gemm_dma256_k's 320-row variant).
+template <typename T, int EPI, int MTW>
 __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
-    constexpr int CH = 32 * 64;                                         // u4 per chunk image: [W 16 | X 16][lane 64]
-    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [buffer 2][chunk 2][W 16 | X 16][lane 64]
-    const int MB = (a.M + 255) / 256, NB = (a.N + 255) / 256;
+    constexpr int XS = 2 * MTW, XPW = (XS + 7) / 8;                     // activation sub-tiles per chunk; staged per wave (the last waves re-stage sub-tile XS - 1)
+    constexpr int PPC = 2 + XPW, PPS = 2 * PPC;                         // LDS-DMA pieces per wave: per chunk, per step
+    constexpr int CH = (16 + XS) * 64;                                  // u4 per chunk image: [W 16 | X XS][lane 64]
+    constexpr int BM = XS * 16;
+    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [buffer 2][chunk 2][W 16 | X XS][lane 64]
+    const int MB = (a.M + BM - 1) / BM, NB = (a.N + 255) / 256;
     const int nwg = MB * NB;
     int tile;
     {
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
         tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
     }
     const int bn = tile / MB, bm = tile - bn * MB;
-    const int M0 = bm * 256, N0 = bn * 256;
+    const int M0 = bm * BM, N0 = bn * 256;
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int wm = w >> 2, wn = w & 3;
@@ -212,54 +215,57 @@ __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
     const unsigned char* X8 = reinterpret_cast<const unsigned char*>(a.X);
     const u4* Wp = reinterpret_cast<const u4*>(a.W8) + lane;
 
-    // this wave stages weight sub-tiles 2 w, 2 w + 1 and activation sub-tiles 2 w, 2 w + 1 of both chunks of a step: 8 pieces
+    // this wave stages weight sub-tiles 2 w, 2 w + 1 and activation sub-tiles XPW w .. of both chunks of a step
     const u4* wsrc[2];
-    const unsigned char* xsrc[2];
+    const unsigned char* xsrc[XPW];
+    int xst[XPW];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        wsrc[j] = Wp + (size_t)min((N0 >> 4) + w * 2 + j, NT16 - 1) * KC * 64;
-        xsrc[j] = X8 + (size_t)min(M0 + (w * 2 + j) * 16 + r, a.M - 1) * a.ldx + g * 16;
+    for (int j = 0; j < 2; ++j) wsrc[j] = Wp + (size_t)min((N0 >> 4) + w * 2 + j, NT16 - 1) * KC * 64;
+#pragma unroll
+    for (int j = 0; j < XPW; ++j) {
+        xst[j] = min(w * XPW + j, XS - 1);
+        xsrc[j] = X8 + (size_t)min(M0 + xst[j] * 16 + r, a.M - 1) * a.ldx + g * 16;
     }
-    auto stage1 = [&](int s, int buf, int j) {                          // piece j = 0..7 of step s: chunk j >> 2, operand / sub-tile j & 3
-        const int ch = j >> 2, q = j & 3, c = min(2 * s + ch, KC - 1);
+    auto stage1 = [&](int s, int buf, int j) {                          // piece j of step s (j compile-time at every call): chunk j / PPC
+        const int ch = j / PPC, q = j % PPC, c = min(2 * s + ch, KC - 1);
         u4* base = lds + ((size_t)buf * 2 + ch) * CH;
         if (q < 2) __builtin_amdgcn_global_load_lds((gptr8_t)(wsrc[q] + (size_t)c * 64), (lptr8_t)(base + (w * 2 + q) * 64), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((gptr8_t)(xsrc[q - 2] + (size_t)c * 64), (lptr8_t)(base + (16 + w * 2 + q - 2) * 64), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gptr8_t)(xsrc[q - 2] + (size_t)c * 64), (lptr8_t)(base + (16 + xst[q - 2]) * 64), 16, 0, 0);
     };
 
-    v4f acc[4][G8B_MTW];
+    v4f acc[4][MTW];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < G8B_MTW; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MTW; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
     const int G = a.xgroups > 0 ? a.xgroups : 1;
     int grp = 0, next_b = nsteps / G;
 
 #pragma unroll
-    for (int j = 0; j < 8; ++j) stage1(0, 0, j);
+    for (int j = 0; j < PPS; ++j) stage1(0, 0, j);
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's pieces of step s have landed
         __builtin_amdgcn_s_barrier();                                   // ... everyone's have, and everyone finished reading the other buffer
         const int sn = min(s + 1, nsteps - 1);                          // (past the end: the last step again, harmless)
-        if (s == next_b && grp + 1 < G) { regroup8<4, G8B_MTW>(a, acc, M0, wm, r, grp); ++grp; next_b = (nsteps * (grp + 1)) / G; }
+        if (s == next_b && grp + 1 < G) { regroup8<4, MTW>(a, acc, M0, wm, r, grp); ++grp; next_b = (nsteps * (grp + 1)) / G; }
         const u4* b0 = lds + ((size_t)buf * 2 + 0) * CH;
         const u4* b1 = lds + ((size_t)buf * 2 + 1) * CH;
         v8i wf[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) wf[nt] = pair8(b0[(wn * 4 + nt) * 64 + lane], b1[(wn * 4 + nt) * 64 + lane]);
 #pragma unroll
-        for (int mt = 0; mt < G8B_MTW; ++mt) {
-            const v8i xf = pair8(b0[(16 + wm * G8B_MTW + mt) * 64 + lane], b1[(16 + wm * G8B_MTW + mt) * 64 + lane]);
+        for (int mt = 0; mt < MTW; ++mt) {
+            const v8i xf = pair8(b0[(16 + wm * MTW + mt) * 64 + lane], b1[(16 + wm * MTW + mt) * 64 + lane]);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma8x2(wf[nt], xf, acc[nt][mt]);
-            stage1(sn, buf ^ 1, mt);                                    // one LDS-DMA piece of the next step behind every row tile's MFMAs
-            __builtin_amdgcn_sched_barrier(0);
+            // the next step's LDS-DMA pieces one by one behind the row tiles' MFMAs (60-185 cycles of issue each)
+            if (mt < PPS) { stage1(sn, buf ^ 1, mt); __builtin_amdgcn_sched_barrier(0); }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // LDS reads of this step are done before the next barrier
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    epilogue8<T, EPI, 4, G8B_MTW>(a, acc, M0, N0, wm, wn, r, g);
+    epilogue8<T, EPI, 4, MTW>(a, acc, M0, N0, wm, wn, r, g);
 }
 
 bool gemm8_supported(const GemmArgs& a, int epi) {
@@ -272,10 +278,17 @@ template <typename T, int EPI>
 static void launch_gemm8_epi(const GemmArgs& a, hipStream_t s) {
     const int MB2 = (a.M + 255) / 256, NB2 = (a.N + 255) / 256;
     if (a.M >= 1024 && a.K >= 512 && a.N >= 1024 && MB2 * NB2 >= 256) {
-        const size_t smem = (size_t)2 * 2 * 32 * 64 * sizeof(u4);       // 128 KiB
+        // 320-row blocks when they save rounds on the 256 CUs (cost = rounds x rows per block, 15 % handicap for the bigger tile, as gemm_dma256_k)
+        const int MB3 = (a.M + 319) / 320;
+        const long c256 = (long)((MB2 * NB2 + 255) / 256) * 256, c320 = (long)((MB3 * NB2 + 255) / 256) * 320;
         static bool attr = false;
-        if (!attr) { hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-        hipLaunchKernelGGL((gemm8_256_k<T, EPI>), dim3(MB2 * NB2), dim3(512), smem, s, a);
+        if (!attr) {
+            hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 32 * 64 * 16);
+            hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 36 * 64 * 16);
+            attr = true;
+        }
+        if (c320 * 115 < c256 * 100) hipLaunchKernelGGL((gemm8_256_k<T, EPI, 10>), dim3(MB3 * NB2), dim3(512), (size_t)2 * 2 * 36 * 64 * 16, s, a);   // 144 KiB
+        else hipLaunchKernelGGL((gemm8_256_k<T, EPI, 8>), dim3(MB2 * NB2), dim3(512), (size_t)2 * 2 * 32 * 64 * 16, s, a);                              // 128 KiB
         return;
     }
     const int MB = (a.M + G8_BM - 1) / G8_BM, NB = (a.N + G8_BN - 1) / G8_BN;
