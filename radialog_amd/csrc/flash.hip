@@ -5,8 +5,8 @@
 // per-workgroup fixed costs -- 107 us per layer for 0.1 us of MFMA work (profiles/r02_bench_b32_kernel_stats.md). Here a WAVE owns 16
 // queries for their whole key range, so nothing but V crosses waves and the softmax statistics never leave registers:
 //
-//   pass 1  S^T = K Q^T per 16-key tile on the matrix cores (A = K fragment straight from the cache layout, B = the wave's Q
-//           fragments; D[key][query]: a lane holds 4 keys of ONE query), scores rounded like the reference, running row maximum and
+//   pass 1  S^T = K Q^T per 16-key tile on the matrix cores (A = K fragment, staged once per workgroup and 32-key chunk in LDS in the
+//           fragment order; B = the wave's Q fragments; D[key][query]: a lane holds 4 keys of ONE query), scores rounded like the reference, running row maximum and
 //           sum of exponentials per lane, combined over the four lane groups of a query once at the end;
 //   pass 2  S^T again (the reference rounds the probabilities AFTER normalising by the whole-row sum -- `softmax(..., dtype=float32)
 //           .to(query_states.dtype)`, modeling_llama_imgemb.py:229-233 -- so P needs the row statistics first; recomputing 4 MFMAs
@@ -38,12 +38,16 @@ template <> __device__ __forceinline__ float scale_score<f16>(float s) { return 
 
 // KPERM (compile time, like the key mask being mandatory): a run-time select between the two K layouts, or a null check of the mask pointer,
 // puts every K load of the tile loops into a basic block of its own -- hipcc then branches around each load and waits vmcnt(0) per load
-// (cdna_hip_programming.md 5, trap (c)): the first build of this kernel ran 112 us per layer, no faster than attention_k.
+// (cdna_hip_programming.md 5, trap (c)).
+// K goes through LDS once per workgroup and chunk, in the MFMA A-fragment order (a 16-key x 32-dim piece is one KiB, written lane-linear, read back
+// with one ds_read_b128 per fragment): in the first build every wave fetched its own K fragments from L2 in both passes -- 24 readers of each K
+// row per (row, head) against attention_k's 10 -- and ran 106-112 us per layer, no faster than the kernel it was to replace.
 template <typename T, bool KPERM>
 __global__ __launch_bounds__(FL_WAVES * 64, 4) void flash_prefill_k(AttnArgs a) {
     typedef typename Vec8<T>::type V8;
     typedef T T4 __attribute__((ext_vector_type(4)));
     typedef T T2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) u4 Kl[2][8][64];                 // two chunks of 32 keys: pieces (key tile kt, dim chunk kc) = 4 kt + kc
     __shared__ __attribute__((aligned(16))) T Vt[2][FL_D][FL_VTP];           // two chunks of 32 keys, transposed
 
     const int q0 = blockIdx.x * FL_QB, h = blockIdx.y, b = blockIdx.z;
@@ -65,71 +69,27 @@ __global__ __launch_bounds__(FL_WAVES * 64, 4) void flash_prefill_k(AttnArgs a) 
             for (int j = 0; j < 8; ++j) qf[kc][j] = fromf<T>(0.f);
         }
     }
-    // keys this wave / this workgroup can see (causal: query i attends keys j <= i + off); whole 16-key tiles / 32-key chunks
+    // keys this wave / this workgroup can see (causal: query i attends keys j <= i + off); the workgroup walks whole 32-key chunks
     const int kmax_w = qw < Tq ? (a.causal ? min(Tk, qw + 16 + off) : Tk) : 0;
     const int kmax_g = a.causal ? min(Tk, min(q0 + FL_QB, Tq) + off) : Tk;
-    const int nkt_w = (kmax_w + 15) >> 4;
     const int nch = (max(kmax_g, 1) + 31) >> 5;
 
-    auto load_kt = [&](int kt, V8 (&kf)[FL_DC], unsigned& mw) {
-        const int key = min(kt * 16 + r, Tk - 1);          // keys >= Tk are clamped here and masked in score()
-#pragma unroll
-        for (int kc = 0; kc < FL_DC; ++kc)
-            kf[kc] = as_vec8<T>(ldg16(KPERM ? K + kperm(key, kc * 32 + g * 8) : K + (long)key * a.k_ts + kc * 32 + g * 8));
-        mw = *reinterpret_cast<const unsigned*>(km + min(kt * 16 + g * 4, (int)a.km_bs - 4));
-    };
-    // the four scores of this lane for key tile kt (keys 16 kt + 4 g + e, query q): rounded like the reference, -inf where masked
-    auto score = [&](int kt, const V8 (&kf)[FL_DC], unsigned mw, float (&sv)[4]) {
-        v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kc = 0; kc < FL_DC; ++kc) acc = mfma16(kf[kc], qf[kc], acc);      // D[i = key_local = 4 g + e][j = q_local = r]
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int kj = kt * 16 + g * 4 + e;
-            bool ok = (kj < Tk) && (q < Tq) && ((mw >> (8 * e)) & 0xffu) != 0;
-            if (a.causal) ok = ok && kj <= q + off;
-            sv[e] = ok ? scale_score<T>(rnd<T>(acc[e])) : -INFINITY;
-        }
-    };
-
-    // ---- pass 1: row maximum and sum of exponentials ---------------------------------------------------------------------------------
-    float m = -INFINITY, l = 0.f;
-    {
-        V8 ka[FL_DC], kb[FL_DC];
-        unsigned ma = 0, mb = 0;
-        float sv[4];
-        auto fold = [&]() {                                  // branch-free: an all-masked tile leaves (m, l) = (-inf, 0) through exp(-inf) = 0
-            const float mn = fmaxf(m, fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
-            const float ms = mn > -INFINITY ? mn : 0.f;
-            l = l * expf(m - ms) + ((expf(sv[0] - ms) + expf(sv[1] - ms)) + (expf(sv[2] - ms) + expf(sv[3] - ms)));
-            m = mn;
-        };
-        int kt = 0;
-        if (kt < nkt_w) load_kt(kt, ka, ma);
-        while (kt < nkt_w) {
-            load_kt(min(kt + 1, nkt_w - 1), kb, mb);
-            score(kt, ka, ma, sv); fold();
-            if (++kt >= nkt_w) break;
-            load_kt(min(kt + 1, nkt_w - 1), ka, ma);
-            score(kt, kb, mb, sv); fold();
-            ++kt;
-        }
-    }
-    // the four lane groups of a query hold disjoint keys: combine (m, l) over lanes r, r + 16, r + 32, r + 48
-#pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-        const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
-        const float mn = fmaxf(m, mo), ms = mn > -INFINITY ? mn : 0.f;
-        l = l * expf(m - ms) + lo * expf(mo - ms);
-        m = mn;
-    }
-    const bool any_key = (m > -INFINITY) && l > 0.f;
-    const float m_use = any_key ? m : 0.f, l_use = any_key ? l : 1.f;
-
-    // ---- pass 2: P = T(softmax), O^T += V^T P^T over 32-key chunks; V staged transposed through LDS once per workgroup -----------------
-    // staging: thread t takes key pair kp = t / 16 (keys 2 kp, 2 kp + 1 of the chunk) and 8 dims d0 = 8 (t % 16): two 16-byte row pieces,
-    // written as 8 (key, key + 1) pairs -> Vt[d0 + j][2 kp .. + 1]
+    // staging roles: wave w fetches K pieces 2 w, 2 w + 1 of a chunk (lane (g, r): 16 bytes of key 16 kt + r, dims 32 kc + 8 g ..) and every thread
+    // two 16-byte pieces of V rows (key pair kp, dims d0 ..), written transposed
     const int kp = threadIdx.x >> 4, d0 = (threadIdx.x & 15) * 8;
+    auto load_k = [&](int c, u4 (&kr)[2], unsigned (&mw)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = 2 * w + j, kt = i >> 2, kc = i & 3;
+            const int key = min(c * 32 + kt * 16 + r, Tk - 1);          // keys >= Tk are clamped here and masked in score()
+            kr[j] = ldg16(KPERM ? K + kperm(key, kc * 32 + g * 8) : K + (long)key * a.k_ts + kc * 32 + g * 8);
+            mw[j] = *reinterpret_cast<const unsigned*>(km + min(c * 32 + j * 16 + g * 4, (int)a.km_bs - 4));     // mask bytes of keys 16 j + 4 g .. + 3
+        }
+    };
+    auto stage_k = [&](int buf, const u4 (&kr)[2]) {
+        Kl[buf][2 * w][lane] = kr[0];
+        Kl[buf][2 * w + 1][lane] = kr[1];
+    };
     auto load_v = [&](int c, u4 (&vr)[2]) {
         const int k0 = min(c * 32 + 2 * kp, Tk - 1), k1 = min(c * 32 + 2 * kp + 1, Tk - 1);   // clamped rows: finite values, probability exactly 0
         vr[0] = ldg16(V + (long)k0 * a.v_ts + d0);
@@ -143,44 +103,101 @@ __global__ __launch_bounds__(FL_WAVES * 64, 4) void flash_prefill_k(AttnArgs a) 
             *reinterpret_cast<T2*>(&Vt[buf][d0 + j][2 * kp]) = pr;
         }
     };
+    // the four scores of this lane for key tile kt of chunk c (keys 32 c + 16 kt + 4 g + e, query q): rounded like the reference, -inf where masked
+    auto score = [&](int c, int kt, int buf, unsigned mw, float (&sv)[4]) {
+        v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < FL_DC; ++kc) acc = mfma16(as_vec8<T>(Kl[buf][kt * 4 + kc][lane]), qf[kc], acc);      // D[i = key_local = 4 g + e][j = q_local = r]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int kj = c * 32 + kt * 16 + g * 4 + e;
+            bool ok = (kj < Tk) && (q < Tq) && ((mw >> (8 * e)) & 0xffu) != 0;
+            if (a.causal) ok = ok && kj <= q + off;
+            sv[e] = ok ? scale_score<T>(rnd<T>(acc[e])) : -INFINITY;
+        }
+    };
+
+    // ---- pass 1: row maximum and sum of exponentials ---------------------------------------------------------------------------------
+    float m = -INFINITY, l = 0.f;
+    {
+        u4 kr[2];
+        unsigned mnext[2], mcur[2];
+        load_k(0, kr, mcur);
+        stage_k(0, kr);
+        load_k(min(1, nch - 1), kr, mnext);
+        __syncthreads();
+        for (int c = 0; c < nch; ++c) {
+            if (c * 32 < kmax_w) {                          // wave-uniform: chunks past this wave's causal range hold no visible key
+                float sv[4];
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    score(c, kt, c & 1, mcur[kt], sv);
+                    // branch-free fold: an all-masked tile leaves (m, l) = (-inf, 0) through exp(-inf) = 0
+                    const float mn = fmaxf(m, fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
+                    const float ms = mn > -INFINITY ? mn : 0.f;
+                    l = l * expf(m - ms) + ((expf(sv[0] - ms) + expf(sv[1] - ms)) + (expf(sv[2] - ms) + expf(sv[3] - ms)));
+                    m = mn;
+                }
+            }
+            // the next chunk (already in registers) goes to the other buffer, the one after is requested; unconditional (past the end: the last
+            // chunk again, into the buffer nobody reads any more), so that no load of the loop sits under a branch
+            stage_k((c + 1) & 1, kr);
+            mcur[0] = mnext[0]; mcur[1] = mnext[1];
+            load_k(min(c + 2, nch - 1), kr, mnext);
+            __syncthreads();
+        }
+    }
+    // the four lane groups of a query hold disjoint keys: combine (m, l) over lanes r, r + 16, r + 32, r + 48
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
+        const float mn = fmaxf(m, mo), ms = mn > -INFINITY ? mn : 0.f;
+        l = l * expf(m - ms) + lo * expf(mo - ms);
+        m = mn;
+    }
+    const bool any_key = (m > -INFINITY) && l > 0.f;
+    const float m_use = any_key ? m : 0.f, l_use = any_key ? l : 1.f;
+
+    // ---- pass 2: P = T(softmax), O^T += V^T P^T over the same chunks; V staged transposed once per workgroup -----------------------------
     v4f acco[FL_D / 16];
 #pragma unroll
     for (int i = 0; i < FL_D / 16; ++i) acco[i] = (v4f){0.f, 0.f, 0.f, 0.f};
     {
-        u4 vr[2];
-        V8 ka[FL_DC], kb[FL_DC];                  // even / odd key tile: each set is re-requested for the next chunk right after its MFMAs
-        unsigned ma = 0, mb = 0;
-        const int last_t = 2 * nch - 1;
+        u4 kr[2], vr[2];
+        unsigned mnext[2], mcur[2];
+        load_k(0, kr, mcur);
         load_v(0, vr);
-        load_kt(0, ka, ma); load_kt(min(1, last_t), kb, mb);
+        stage_k(0, kr);
         stage_v(0, vr);
+        load_k(min(1, nch - 1), kr, mnext);
         load_v(min(1, nch - 1), vr);
         __syncthreads();
         for (int c = 0; c < nch; ++c) {
-            float s0[4], s1[4];
-            score(2 * c, ka, ma, s0);
-            load_kt(min(2 * c + 2, last_t), ka, ma);
-            score(2 * c + 1, kb, mb, s1);
-            load_kt(min(2 * c + 3, last_t), kb, mb);
-            V8 pf;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                pf[e] = fromf<T>(expf(s0[e] - m_use) / l_use);         // exp / sum like torch's softmax (a true division); masked: exp(-inf) = 0
-                pf[4 + e] = fromf<T>(expf(s1[e] - m_use) / l_use);
-            }
             const int buf = c & 1;
+            if (c * 32 < kmax_w) {
+                float s0[4], s1[4];
+                score(c, 0, buf, mcur[0], s0);
+                score(c, 1, buf, mcur[1], s1);
+                V8 pf;
 #pragma unroll
-            for (int dt = 0; dt < FL_D / 16; ++dt) {
-                const T4 lo = *reinterpret_cast<const T4*>(&Vt[buf][dt * 16 + r][4 * g]);
-                const T4 hi = *reinterpret_cast<const T4*>(&Vt[buf][dt * 16 + r][16 + 4 * g]);
-                V8 vf;
+                for (int e = 0; e < 4; ++e) {
+                    pf[e] = fromf<T>(expf(s0[e] - m_use) / l_use);         // exp / sum like torch's softmax (a true division); masked: exp(-inf) = 0
+                    pf[4 + e] = fromf<T>(expf(s1[e] - m_use) / l_use);
+                }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
-                acco[dt] = mfma16(vf, pf, acco[dt]);             // D[i = d_local = 4 g + e][j = q_local = r]
+                for (int dt = 0; dt < FL_D / 16; ++dt) {
+                    const T4 lo = *reinterpret_cast<const T4*>(&Vt[buf][dt * 16 + r][4 * g]);
+                    const T4 hi = *reinterpret_cast<const T4*>(&Vt[buf][dt * 16 + r][16 + 4 * g]);
+                    V8 vf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { vf[j] = lo[j]; vf[4 + j] = hi[j]; }
+                    acco[dt] = mfma16(vf, pf, acco[dt]);             // D[i = d_local = 4 g + e][j = q_local = r]
+                }
             }
-            // V of chunk c + 1 (already in registers) goes to the other buffer, chunk c + 2 is requested; one barrier per chunk. Unconditional
-            // (past the end: the last chunk again, into the buffer nobody reads any more): no load of the loop sits under a branch
+            stage_k((c + 1) & 1, kr);
             stage_v((c + 1) & 1, vr);
+            mcur[0] = mnext[0]; mcur[1] = mnext[1];
+            load_k(min(c + 2, nch - 1), kr, mnext);
             load_v(min(c + 2, nch - 1), vr);
             __syncthreads();
         }

@@ -13,9 +13,9 @@
 // Two kernels, the LDS-DMA pipelines of gemm_dma.hip with twice the MFMAs per staged byte:
 //   gemm8_k      128 x 128 block, 4 waves (2 x 2), BK = 128 per step (32 KiB staged: 16 + 16 pieces of 1 KiB), two LDS buffers, counted
 //                vmcnt + raw s_barrier; any M, N % 16 == 0, K % 128 == 0;
-//   gemm8_256_k  256 (or 320) x 256 block, 8 waves (2 x 4), a pair of chunks (K = 128) per step, two LDS buffers (M >= 1024 and >= 256 blocks).
-// Both issue v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales: K = 128 per instruction, twice the bf16 MFMA rate (the K groups are
-// whole 128-deep blocks, so a step never straddles a boundary).
+//   gemm8_256_k  256 (or 320) x 256 block, 8 waves (2 x 4), one 64-deep chunk per stage, four-stage ring (M >= 1024 and >= 256 blocks).
+// gemm8_k issues v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (K = 128 per instruction, twice the bf16 MFMA rate; the K groups are
+// whole 128-deep blocks, so a step never straddles a boundary), gemm8_256_k v_mfma_f32_16x16x32_fp8_fp8 (see there).
 // Epilogues: NONE, RESID (out = resid + T(v)), SILU_MUL (gate / up rows interleaved 8 + 8 per tile).
 #include <algorithm>
 #include <stdlib.h>
@@ -28,6 +28,14 @@ namespace rdx {
 
 typedef __attribute__((address_space(1))) const void* gptr8_t;
 typedef __attribute__((address_space(3))) void* lptr8_t;
+
+// one 16-byte piece of each operand = two v_mfma_f32_16x16x32_fp8_fp8 (bytes 0..7 and 8..15 of every lane)
+__device__ __forceinline__ v4f mfma8(const u4& a, const u4& b, v4f c) {
+    const long a0 = (long)(((unsigned long long)a.y << 32) | a.x), a1 = (long)(((unsigned long long)a.w << 32) | a.z);
+    const long b0 = (long)(((unsigned long long)b.y << 32) | b.x), b1 = (long)(((unsigned long long)b.w << 32) | b.z);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, c, 0, 0, 0);
+}
 
 // Two consecutive 64-deep pieces of each operand at once on the block-scaled instruction v_mfma_scale_f32_16x16x128_f8f6f4 (formats e4m3 x e4m3,
 // every E8M0 block scale = 2^0): one MFMA of K = 128 at TWICE the bf16 rate (MI355X_MICROARCH.md: the non-scaled fp8 16x16x32 runs at the
@@ -189,15 +197,20 @@ __global__ __launch_bounds__(256) void gemm8_k(GemmArgs a) {
 // 8 waves as 2 x 4 with 128 x 64 wave tiles; a STEP is a pair of 64-deep chunks (K = 128: 64 KiB staged, 16 + 16 pieces per chunk), two LDS
 // buffers; per step a wave reads 8 weight and 16 activation pieces and issues 32 K = 128 MFMAs. The next step's 8 LDS-DMA pieces per wave are
 // issued one by one behind the MFMAs of this step (they cost 60-185 cycles of issue each, gemm_dma256_k).
-// MTW row tiles per wave: 8 (256-row blocks) or 10 (320-row blocks, 72 KiB per step: taken when they save a round of workgroups on the 256
-// CUs -- the N = 4096 projections at M = 5120 are 320 blocks of 256 rows but 256 of 320, like gemm_dma256_k's 320-row variant).
+// 256 x 256 block (the batched prefill), 8 waves as 2 x 4 with 128 x 64 wave tiles: gemm_dma256_k's four-stage ring of 32-KiB stages, a stage
+// being ONE 64-deep e4m3 chunk (16 + XS pieces) -- twice the K of a bf16 stage for the same bytes -- multiplied with v_mfma_f32_16x16x32_fp8_fp8.
+// (Round 3 also built it as K = 128 steps on the block-scaled instruction: two 64-KiB buffers are all the LDS holds then, one step of DMA lead
+// instead of three stages, and it measured SLOWER -- gate/up at M = 5120 766 us against 652 us, bf16 865 us)
+// MTW row tiles per wave: 8 (256-row blocks) or 10 (320-row blocks: taken when they save a round of workgroups on the 256 CUs -- the N = 4096
+// projections at M = 5120 are 320 blocks of 256 rows but 256 of 320, like gemm_dma256_k's 320-row variant).
+constexpr int G8B_NS = 4;
+
 template <typename T, int EPI, int MTW>
 __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
-    constexpr int XS = 2 * MTW, XPW = (XS + 7) / 8;                     // activation sub-tiles per chunk; staged per wave (the last waves re-stage sub-tile XS - 1)
-    constexpr int PPC = 2 + XPW, PPS = 2 * PPC;                         // LDS-DMA pieces per wave: per chunk, per step
-    constexpr int CH = (16 + XS) * 64;                                  // u4 per chunk image: [W 16 | X XS][lane 64]
-    constexpr int BM = XS * 16;
-    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [buffer 2][chunk 2][W 16 | X XS][lane 64]
+    constexpr int XS = 2 * MTW, XPW = (XS + 7) / 8;                     // activation sub-tiles per stage; staged per wave (the last waves re-stage sub-tile XS - 1)
+    constexpr int LPS = 2 + XPW;                                        // LDS-DMA pieces per wave per stage
+    constexpr int SUB = 16 + XS, BM = XS * 16;
+    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [stage 4][W 16 | X XS][lane 64]
     const int MB = (a.M + BM - 1) / BM, NB = (a.N + 255) / 256;
     const int nwg = MB * NB;
     int tile;
@@ -211,11 +224,10 @@ __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
     const int r = lane & 15, g = lane >> 4;
     const int wm = w >> 2, wn = w & 3;
     const int KC = a.K >> 6, NT16 = (a.N + 15) >> 4;
-    const int nsteps = KC >> 1;                                         // pairs of chunks (K % 128 == 0)
+    const int nsteps = KC;                                              // one 64-deep chunk per stage
     const unsigned char* X8 = reinterpret_cast<const unsigned char*>(a.X);
     const u4* Wp = reinterpret_cast<const u4*>(a.W8) + lane;
 
-    // this wave stages weight sub-tiles 2 w, 2 w + 1 and activation sub-tiles XPW w .. of both chunks of a step
     const u4* wsrc[2];
     const unsigned char* xsrc[XPW];
     int xst[XPW];
@@ -226,11 +238,14 @@ __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
         xst[j] = min(w * XPW + j, XS - 1);
         xsrc[j] = X8 + (size_t)min(M0 + xst[j] * 16 + r, a.M - 1) * a.ldx + g * 16;
     }
-    auto stage1 = [&](int s, int buf, int j) {                          // piece j of step s (j compile-time at every call): chunk j / PPC
-        const int ch = j / PPC, q = j % PPC, c = min(2 * s + ch, KC - 1);
-        u4* base = lds + ((size_t)buf * 2 + ch) * CH;
-        if (q < 2) __builtin_amdgcn_global_load_lds((gptr8_t)(wsrc[q] + (size_t)c * 64), (lptr8_t)(base + (w * 2 + q) * 64), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((gptr8_t)(xsrc[q - 2] + (size_t)c * 64), (lptr8_t)(base + (16 + xst[q - 2]) * 64), 16, 0, 0);
+    auto stage1 = [&](int s, int slot, int j) {                         // piece j of this wave's LPS pieces of stage s (j compile-time at every call)
+        u4* base = lds + (size_t)slot * SUB * 64;
+        if (j < 2) __builtin_amdgcn_global_load_lds((gptr8_t)(wsrc[j] + (size_t)s * 64), (lptr8_t)(base + (w * 2 + j) * 64), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gptr8_t)(xsrc[j - 2] + (size_t)s * 64), (lptr8_t)(base + (16 + xst[j - 2]) * 64), 16, 0, 0);
+    };
+    auto stage = [&](int s, int slot) {
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) stage1(s, slot, j);
     };
 
     v4f acc[4][MTW];
@@ -238,31 +253,30 @@ __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < MTW; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
-    const int G = a.xgroups > 0 ? a.xgroups : 1;
-    int grp = 0, next_b = nsteps / G;
+    const int G = a.xgroups > 0 ? a.xgroups : 1, NBK = KC >> 1;        // K groups are whole 128-deep blocks = pairs of stages
+    int grp = 0, next_b = 2 * (NBK / G);
 
 #pragma unroll
-    for (int j = 0; j < PPS; ++j) stage1(0, 0, j);
+    for (int p = 0; p < G8B_NS - 1; ++p) stage(min(p, nsteps - 1), p);   // stages 0..2 in flight
     for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's pieces of step s have landed
-        __builtin_amdgcn_s_barrier();                                   // ... everyone's have, and everyone finished reading the other buffer
-        const int sn = min(s + 1, nsteps - 1);                          // (past the end: the last step again, harmless)
-        if (s == next_b && grp + 1 < G) { regroup8<4, MTW>(a, acc, M0, wm, r, grp); ++grp; next_b = (nsteps * (grp + 1)) / G; }
-        const u4* b0 = lds + ((size_t)buf * 2 + 0) * CH;
-        const u4* b1 = lds + ((size_t)buf * 2 + 1) * CH;
-        v8i wf[4];
+        if (LPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // this wave's loads of stage s have landed (two younger stages may fly)
+        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                   // ... everyone's have, and everyone finished stage s - 1
+        const int sn = min(s + G8B_NS - 1, nsteps - 1), slotn = (s + G8B_NS - 1) % G8B_NS;
+        if (s == next_b && grp + 1 < G) { regroup8<4, MTW>(a, acc, M0, wm, r, grp); ++grp; next_b = 2 * ((NBK * (grp + 1)) / G); }
+        const u4* base = lds + (size_t)(s % G8B_NS) * SUB * 64;
+        u4 wf[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wf[nt] = pair8(b0[(wn * 4 + nt) * 64 + lane], b1[(wn * 4 + nt) * 64 + lane]);
+        for (int nt = 0; nt < 4; ++nt) wf[nt] = base[(wn * 4 + nt) * 64 + lane];
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
-            const v8i xf = pair8(b0[(16 + wm * MTW + mt) * 64 + lane], b1[(16 + wm * MTW + mt) * 64 + lane]);
+            const u4 xf = base[(16 + wm * MTW + mt) * 64 + lane];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma8x2(wf[nt], xf, acc[nt][mt]);
-            // the next step's LDS-DMA pieces one by one behind the row tiles' MFMAs (60-185 cycles of issue each)
-            if (mt < PPS) { stage1(sn, buf ^ 1, mt); __builtin_amdgcn_sched_barrier(0); }
+            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma8(wf[nt], xf, acc[nt][mt]);
+            // stage s + 3 goes into the slot stage s - 1 was read from; its LDS-DMA pieces one by one behind the MFMAs of row tiles 1, 3, 5, ...
+            if ((mt & 1) == 1 && (mt >> 1) < LPS) { stage1(sn, slotn, mt >> 1); __builtin_amdgcn_sched_barrier(0); }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // LDS reads of this step are done before the next barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // LDS reads of this stage are done before the next barrier
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     epilogue8<T, EPI, 4, MTW>(a, acc, M0, N0, wm, wn, r, g);
@@ -283,12 +297,12 @@ static void launch_gemm8_epi(const GemmArgs& a, hipStream_t s) {
         const long c256 = (long)((MB2 * NB2 + 255) / 256) * 256, c320 = (long)((MB3 * NB2 + 255) / 256) * 320;
         static bool attr = false;
         if (!attr) {
-            hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 32 * 64 * 16);
-            hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 36 * 64 * 16);
+            hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G8B_NS * 32 * 64 * 16);
+            hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, G8B_NS * 36 * 64 * 16);
             attr = true;
         }
-        if (c320 * 115 < c256 * 100) hipLaunchKernelGGL((gemm8_256_k<T, EPI, 10>), dim3(MB3 * NB2), dim3(512), (size_t)2 * 2 * 36 * 64 * 16, s, a);   // 144 KiB
-        else hipLaunchKernelGGL((gemm8_256_k<T, EPI, 8>), dim3(MB2 * NB2), dim3(512), (size_t)2 * 2 * 32 * 64 * 16, s, a);                              // 128 KiB
+        if (c320 * 115 < c256 * 100) hipLaunchKernelGGL((gemm8_256_k<T, EPI, 10>), dim3(MB3 * NB2), dim3(512), (size_t)G8B_NS * 36 * 64 * 16, s, a);   // 144 KiB
+        else hipLaunchKernelGGL((gemm8_256_k<T, EPI, 8>), dim3(MB2 * NB2), dim3(512), (size_t)G8B_NS * 32 * 64 * 16, s, a);                              // 128 KiB
         return;
     }
     const int MB = (a.M + G8_BM - 1) / G8_BM, NB = (a.N + G8_BN - 1) / G8_BN;
