@@ -15,7 +15,8 @@
 //           16 (j / 4) + 4 g + (j % 4) of the 32-key chunk, which is exactly what the lane already holds from the two score tiles --
 //           no cross-lane traffic between the two products. V (stored [key][d]) is staged ONCE per workgroup and chunk, transposed
 //           in LDS ([d][key]), so that a lane's A fragment (8 keys of one d) is two 8-byte LDS reads.
-//   Rounding points as in attention_k (modeling_llama_imgemb.py:216-234): T(q.k), T(. / sqrt(d)), fp32 softmax, T(p), T(o). Masked keys
+//   Rounding points as in attention_k (modeling_llama_imgemb.py:216-234): T(q.k), T(. / sqrt(d)), fp32 softmax (v_exp_f32-based exp and a
+//   reciprocal multiply: see fexp), T(p), T(o). Masked keys
 //   (padding, causal, beyond Tk) score -inf; a query without any visible key gets zeros (nothing reads such rows).
 //
 // 64 queries (4 waves) per workgroup: grid (ceil(Tq / 64), heads, batch). Taken when that grid fills the chip (launch_flash_prefill
@@ -29,6 +30,11 @@ namespace rdx {
 
 constexpr int FL_D = 128, FL_DC = FL_D / 32, FL_WAVES = 4, FL_QB = FL_WAVES * 16;
 constexpr int FL_VTP = 36;                       // keys per transposed V row in LDS (72 B: the two 4-key halves of a lane land 16 banks apart)
+
+// exp of a non-positive fp32 argument as v_exp_f32(x log2 e): within 2 ulp of expf. The fp32 softmax is rounded to the model dtype right
+// after (2^-8 / 2^-11 relative), so a probability changes -- by one model-dtype ulp -- only when it sits within 2^-22 of a rounding boundary;
+// expf's range handling and the IEEE division of the normalisation were ~40 % of this kernel's vector instructions.
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
 
 template <typename T> __device__ __forceinline__ float scale_score(float s);
 // "/ math.sqrt(head_dim)" on a model-dtype value, rounded to the model dtype. bf16: the product with the fp32 reciprocal rounds to the same bf16
@@ -70,8 +76,8 @@ __global__ __launch_bounds__(FL_WAVES * 64, 4) void flash_prefill_k(AttnArgs a) 
         }
     }
     // keys this wave / this workgroup can see (causal: query i attends keys j <= i + off); the workgroup walks whole 32-key chunks
-    const int kmax_w = qw < Tq ? (a.causal ? min(Tk, qw + 16 + off) : Tk) : 0;
-    const int kmax_g = a.causal ? min(Tk, min(q0 + FL_QB, Tq) + off) : Tk;
+    const int kmax_w = qw < Tq ? min(Tk, qw + 16 + off) : 0;
+    const int kmax_g = min(Tk, min(q0 + FL_QB, Tq) + off);
     const int nch = (max(kmax_g, 1) + 31) >> 5;
 
     // staging roles: wave w fetches K pieces 2 w, 2 w + 1 of a chunk (lane (g, r): 16 bytes of key 16 kt + r, dims 32 kc + 8 g ..) and every thread
@@ -111,8 +117,7 @@ __global__ __launch_bounds__(FL_WAVES * 64, 4) void flash_prefill_k(AttnArgs a) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int kj = c * 32 + kt * 16 + g * 4 + e;
-            bool ok = (kj < Tk) && (q < Tq) && ((mw >> (8 * e)) & 0xffu) != 0;
-            if (a.causal) ok = ok && kj <= q + off;
+            const bool ok = (kj < Tk) && (q < Tq) && ((mw >> (8 * e)) & 0xffu) != 0 && kj <= q + off;      // padding, range, causal
             sv[e] = ok ? scale_score<T>(rnd<T>(acc[e])) : -INFINITY;
         }
     };
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(FL_WAVES * 64, 4) void flash_prefill_k(AttnArgs a) 
                     // branch-free fold: an all-masked tile leaves (m, l) = (-inf, 0) through exp(-inf) = 0
                     const float mn = fmaxf(m, fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
                     const float ms = mn > -INFINITY ? mn : 0.f;
-                    l = l * expf(m - ms) + ((expf(sv[0] - ms) + expf(sv[1] - ms)) + (expf(sv[2] - ms) + expf(sv[3] - ms)));
+                    l = l * fexp(m - ms) + ((fexp(sv[0] - ms) + fexp(sv[1] - ms)) + (fexp(sv[2] - ms) + fexp(sv[3] - ms)));
                     m = mn;
                 }
             }
@@ -152,11 +157,11 @@ __global__ __launch_bounds__(FL_WAVES * 64, 4) void flash_prefill_k(AttnArgs a) 
     for (int o = 16; o <= 32; o <<= 1) {
         const float mo = __shfl_xor(m, o, 64), lo = __shfl_xor(l, o, 64);
         const float mn = fmaxf(m, mo), ms = mn > -INFINITY ? mn : 0.f;
-        l = l * expf(m - ms) + lo * expf(mo - ms);
+        l = l * fexp(m - ms) + lo * fexp(mo - ms);
         m = mn;
     }
     const bool any_key = (m > -INFINITY) && l > 0.f;
-    const float m_use = any_key ? m : 0.f, l_use = any_key ? l : 1.f;
+    const float m_use = any_key ? m : 0.f, inv_l = any_key ? 1.0f / l : 0.f;
 
     // ---- pass 2: P = T(softmax), O^T += V^T P^T over the same chunks; V staged transposed once per workgroup -----------------------------
     v4f acco[FL_D / 16];
@@ -181,8 +186,8 @@ __global__ __launch_bounds__(FL_WAVES * 64, 4) void flash_prefill_k(AttnArgs a) 
                 V8 pf;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    pf[e] = fromf<T>(expf(s0[e] - m_use) / l_use);         // exp / sum like torch's softmax (a true division); masked: exp(-inf) = 0
-                    pf[4 + e] = fromf<T>(expf(s1[e] - m_use) / l_use);
+                    pf[e] = fromf<T>(fexp(s0[e] - m_use) * inv_l);         // masked: exp(-inf) = 0
+                    pf[4 + e] = fromf<T>(fexp(s1[e] - m_use) * inv_l);
                 }
 #pragma unroll
                 for (int dt = 0; dt < FL_D / 16; ++dt) {
@@ -227,7 +232,7 @@ bool flash_prefill_supported(int head_dim, const AttnArgs& a) {
     const char* e = getenv("RDX_FLASH_MIN");                   // read per launch: tests toggle it (0 = never, 1 = always: A / B against attention_k)
     const int min_wgs = e ? atoi(e) : 512;
     const long wgs = (long)((a.Tq + FL_QB - 1) / FL_QB) * a.H * a.B;
-    return min_wgs > 0 && head_dim == FL_D && wgs >= min_wgs && (a.v_ts & 7) == 0 && (a.q_ts & 7) == 0 && (a.k_perm || (a.k_ts & 7) == 0) &&
+    return min_wgs > 0 && head_dim == FL_D && a.causal && wgs >= min_wgs && (a.v_ts & 7) == 0 && (a.q_ts & 7) == 0 && (a.k_perm || (a.k_ts & 7) == 0) &&
            a.key_mask && (a.km_bs & 3) == 0;
 }
 
