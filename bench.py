@@ -18,13 +18,15 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; WORLD_SIZE must 
 
 Rank 0 prints ONE JSON line. `value` = reports/s of the whole job with inputs resident in HBM. Added objects:
   roofline     bound "hbm": the kernel rocprofv3 ranks first in the decode loop -- at batch <= 2 the chained down(l) -> QKV(l+1)
-               launch `decode_layers_k` (profiles/r02_bench_kernel_stats.md), at batch 3-32 the gate/up SwiGLU `xstat32_k`:
+               launch `decode_chain_k` (profiles/r03_bench_b1_kernel_stats.md), at batch 3-32 the gate/up SwiGLU `xstat32_k`:
                algorithmic bytes per launch / its average launch duration measured live with HIP events on the library's stream
                (rdx_time; the chained launch is bracketed in situ inside real decode steps); `traffic` = HBM bytes per launch
-               from the rocprofv3 PMC passes of this same command (profiles/r02_pmc.json; counters cannot be read in-process).
+               from the rocprofv3 PMC passes of this same command (profiles/r03_pmc.json; counters cannot be read in-process).
                Also the whole-step fractions and the MFMA-side fractions north_star targets (`mfma`: encode and prefill
                TFLOP/s over the 2.5 PFLOP/s dense bf16 peak).
-  b32          (batch-1 runs on one GPU) BASELINE configs[2] timed in the same process: batch 32, hipGraph decode step.
+  b32          (batch-1 runs) BASELINE configs[2] / [3] timed in the same process at every world size: per-GPU batch 32, hipGraph step.
+  fp8_b32      (batch-1 runs) BASELINE configs[4]: e4m3 decoder weights AND activations on the fp8 MFMA, per-GPU batch 32.
+  token_check  the first 8 greedy tokens of row 0 of every timed configuration against tests/golden/bench_tokens.json (exit 3 on a miss).
   cpu_baseline the CPU oracle (oracle/ref_cpu.py, kind "port") running BASELINE configs[0] for real on the host cores: one
                448 px image through the full-size encoder, the 160-token prefill and 32 greedy tokens through all 32 layers.
 """
@@ -104,10 +106,10 @@ def prefill_flops(lc, T, B):
 
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs of
-    this command, FETCH doubled per the gfx950 correction; profiles/r02_pmc_hbm_traffic.md, machine-readable twin r02_pmc.json).
+    this command, FETCH doubled per the gfx950 correction; profiles/r03_pmc_hbm_traffic.md, machine-readable twin r03_pmc.json).
     Only for configurations that were profiled -> null otherwise."""
     try:
-        with open(os.path.join(REPO, "profiles", "r02_pmc.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r03_pmc.json")) as f:
             return json.load(f).get(kernel_key, {}).get("traffic_bytes")
     except Exception:
         return None
@@ -245,7 +247,7 @@ def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms
             ms = eng.time_unit(7, 8)               # in situ: 8 eager decode steps, an event pair around each of the 32 chained launches
             nb = H_ * I_ * wbytes(H_, I_) + (3 * H_ + 2 * lc.lora_r) * H_ * wbytes(3 * H_ + 16, H_) + B * (I_ + 2 * H_ + 3 * H_ + 16) * 2 + H_ * 2
             dom = (f"decode_chain_k<{args.dtype}{',W8' if wbytes(H_, I_) == 1 else ''}> (chained down_proj(l) -> RMSNorm+QKV(l+1) launch, fence-free hand-off)",
-                   ms, nb, f"decode_layers_k B={B} {args.dtype}{' fp8' if args.fp8 else ''}")
+                   ms, nb, f"decode_chain_k B={B} {args.dtype}{' fp8' if args.fp8 else ''}")
         except Exception:
             dom = None
     if dom is None:

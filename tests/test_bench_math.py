@@ -57,7 +57,7 @@ def test_prefill_and_encode_flops():
 
 def test_committed_bench_line_is_self_consistent():
     """The round's committed driver-style line: value = 1 / step time, decode fraction recomputed from its own fields."""
-    with open(os.path.join(REPO, "profiles", "r02_bench.json")) as f:
+    with open(os.path.join(REPO, "profiles", "r03_bench.json")) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
     assert d["unit"] == "reports/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert abs(d["value"] - 1000.0 / d["ms_per_step"] * d["config"]["global_batch"]) < 1e-6
@@ -66,7 +66,9 @@ def test_committed_bench_line_is_self_consistent():
     assert abs(r["achieved"] - r["bytes_per_launch"] / r["us_per_launch"] / 1e3) < 1.0            # GB/s = bytes / us / 1e3
     assert 0.95 < r["traffic"] / r["bytes_per_launch"] < 1.05                                      # PMC traffic ~ algorithmic bytes: no re-reads
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
-    assert d["b32"]["value"] > d["value"]
+    assert d["b32"]["value"] > d["value"] and d["fp8_b32"]["value"] > d["b32"]["value"]
+    assert d["token_check"]["ok"] and d["b32"]["token_check"]["ok"] and d["fp8_b32"]["token_check"]["ok"] and d["results_verified"] is True
+    assert d["cpu_baseline"]["parity"]["ok"] is True
 
 
 def test_oracle_check_rule_of_the_bench_line():
