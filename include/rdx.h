@@ -25,9 +25,11 @@ enum { RDX_DTYPE_F16 = 0, RDX_DTYPE_BF16 = 1 };
 enum { RDX_W_GEMM = 0,   /* [rows=N][cols=K] fp32 -> model dtype, re-laid-out into MFMA fragment order            */
        RDX_W_TENSOR = 1, /* [rows][cols] fp32 -> model dtype, row-major (embeddings, norm weights, LoRA B, RoPE)    */
        RDX_W_F32 = 2,    /* [rows][cols] fp32 kept as fp32 (biases, LayerNorm gamma/beta)                           */
-       RDX_W_GEMM_FP8 = 3 }; /* like RDX_W_GEMM, additionally quantised to OCP e4m3 with one absmax/448 scale per row:
-                            * the weight-streaming decode kernels (batch <= 4) read the fp8 bytes, everything else the
-                            * dequantised model-dtype copy T(q * scale) (BASELINE configs[4])                       */
+       RDX_W_GEMM_FP8 = 3 }; /* quantised to OCP e4m3 with one absmax/448 scale per output row and stored ONLY in that
+                            * form (64-deep MFMA fragment order): prefill and batch >= 3 decode multiply fp8 x fp8
+                            * (activations e4m3 with a scale per row and K group), batch <= 2 expands the bytes in
+                            * registers; a shape without an fp8 kernel makes the call return -8, there is no
+                            * dequantised copy to fall back to (BASELINE configs[4])                                */
 
 typedef struct rdx_config {
     int dtype;                                     /* RDX_DTYPE_* : arithmetic type of weights/activations         */

@@ -149,7 +149,7 @@ static void launch_skinny_T(const GemmArgs& a, int epi, hipStream_t s) {
     // few output tiles (N <= 4096 -> at most one workgroup per CU): 16 waves per workgroup put twice as many
     // weight loads in flight per CU
     constexpr bool wide = true;
-    const bool w8 = a.W8 && a.wscale && skinny_fits_lds(a.M, a.K) && a.K % 64 == 0;   // fp8 weight stream (else: the dequantised copy)
+    const bool w8 = a.W8 && a.wscale && skinny_fits_lds(a.M, a.K) && a.K % 64 == 0;   // fp8 weight stream (else: W, which only the test hooks provide)
     if (wide && skinny_fits_lds(a.M, a.K) && (a.N + 15) / 16 <= 256 && a.K >= 4096) {
         if (w8) { if (norm) launch_skinny_epi<T, 1, true, 16, true, true>(a, epi, s); else launch_skinny_epi<T, 1, false, 16, true, true>(a, epi, s); return; }
         if (norm) launch_skinny_epi<T, 1, true, 16, true>(a, epi, s); else launch_skinny_epi<T, 1, false, 16, true>(a, epi, s);

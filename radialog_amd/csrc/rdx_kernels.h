@@ -26,8 +26,8 @@ struct GemmArgs {
     float* part_val; int* part_idx;  // EPI_LOGITS: [M][n_tiles]
     int n_valid;                     // EPI_LOGITS: real vocab size (N is padded to 16)
     const int* out_step; long out_step_stride;   // optional: out += (*out_step) * stride elements (per-step score rows)
-    // fp8 weights (skinny / fused decode paths only): e4m3 bytes in the 64-deep fragment order (gemm.hip) + one fp32 scale per
-    // output row; `W` then holds the dequantised model-dtype copy the other kernels use
+    // fp8 weights: e4m3 bytes in the 64-deep fragment order (gemm.hip) + one fp32 scale per output row; `W` is null in the engine (no
+    // model-dtype copy exists: api_dispatch.hip refuses shapes without an fp8 kernel), only the kernel test hooks set both
     const void* W8; const float* wscale;
     int out_packed;                  // xstat32_k, EPI_SILU_MUL: write the output fragment-packed (input of xsplit32_k)
     int xpacked;                     // xstat32_k: X is the fragment-packed 32-row block written by launch_rmsnorm_packed32 (1 / 2);
@@ -70,8 +70,8 @@ struct LlamaDims {
 };
 
 void launch_pack_weight(int dtype, const float* src, void* dst, int N, int K, int Npad, const int* rowmap, hipStream_t s);
-// per-row absmax e4m3 quantisation: dst8 = fp8 bytes in the 64-deep fragment order, scale[Npad], dst = the dequantised weights in
-// the model dtype, standard fragment order (K % 64 == 0)
+// per-row absmax e4m3 quantisation: dst8 = fp8 bytes in the 64-deep fragment order, scale[Npad]; dst (nullable; test hooks only) = the
+// dequantised weights in the model dtype, standard fragment order (K % 64 == 0)
 void launch_pack_weight_fp8(int dtype, const float* src, void* dst8, float* scale, void* dst, int N, int K, int Npad, hipStream_t s);
 // skinny GEMM. A fused RMSNorm (a.norm_w != null) is only honoured when skinny_fits_lds(M, K); otherwise the caller
 // must normalise first (launch_rmsnorm) and pass norm_w = null.
