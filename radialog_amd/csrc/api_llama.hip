@@ -408,7 +408,7 @@ extern "C" int rdx_beam_search(rdx_ctx* c, const int32_t* ids, const int32_t* ma
         c->bm_rows = 0;
         ALLOC(c, c->bm_logits, (size_t)R * V * 2); ALLOC(c, c->bm_scores, (size_t)R * 4);
         ALLOC(c, c->bm_cand_s, (size_t)R * 2 * 4); ALLOC(c, c->bm_cand_i, (size_t)R * 2 * 4);
-        ALLOC(c, c->bm_tok, (size_t)R * 4); ALLOC(c, c->bm_src, (size_t)R * 4); ALLOC(c, c->bm_out, (size_t)R * N * 4);
+        ALLOC(c, c->bm_tok, (size_t)R * 4); ALLOC(c, c->bm_src, (size_t)R * 2 * 4); ALLOC(c, c->bm_out, (size_t)R * N * 4);       // bm_src: src[R] | start[R]
         c->bm_rows = R; c->bm_new = N;
     }
     const size_t need = (size_t)f.layers * 2 * rows * f.heads * span * 256;
@@ -427,11 +427,12 @@ extern "C" int rdx_beam_search(rdx_ctx* c, const int32_t* ids, const int32_t* ma
 
     std::vector<float> beam_scores(rows, -1e9f), cs((size_t)groups * K2);
     for (int g = 0; g < groups; ++g) beam_scores[(size_t)g * num_beams] = 0.f;
-    std::vector<int> ci((size_t)groups * K2), next_tok(rows), src(rows);
+    std::vector<int> ci((size_t)groups * K2), next_tok(rows), src(2 * (size_t)rows);       // src[rows] | first differing cache position[rows]
     std::vector<std::vector<int>> hist(rows), nh(rows);
     std::vector<BeamHyps> hyps(groups);
     for (BeamHyps& h : hyps) { h.num_beams = num_beams; h.length_penalty = length_penalty; h.early_stopping = early_stopping; }
     std::vector<char> done(groups, 0);
+    const bool full_copy = getenv("RDX_BEAM_FULLCOPY") && atoi(getenv("RDX_BEAM_FULLCOPY"));     // tests: move every generated position (A/B leg)
     int cur_len = T, steps = 0;
     for (int step = 0; step < max_new; ++step) {
         HIPCHK(c, hipMemcpyAsync(c->bm_scores, beam_scores.data(), rows * sizeof(float), hipMemcpyHostToDevice, s));
@@ -463,6 +464,15 @@ extern "C" int rdx_beam_search(rdx_ctx* c, const int32_t* ids, const int32_t* ma
             if (nb < num_beams) return fail(c, -7, "rdx_beam_search: fewer than %d live candidates in group %d (eos-only top-2k)", num_beams, g);
             done[g] = done[g] || hyps[g].is_done(cs[(size_t)g * K2], cur_len);
         }
+        // _reorder_cache moves only what differs: row r's cache holds the positions of hist[r], its new parent's those of hist[src[r]];
+        // both are token paths from the same prompt, so the common prefix is already in place (same tokens, same kernels, same launch)
+        for (int r = 0; r < rows; ++r) {
+            const std::vector<int>& mine = hist[r];
+            const std::vector<int>& par = hist[src[r]];
+            size_t cpre = 0;
+            while (cpre < mine.size() && cpre < par.size() && mine[cpre] == par[cpre]) ++cpre;
+            src[rows + r] = full_copy ? 0 : (T + (int)cpre) / 16 * 16;
+        }
         for (int r = 0; r < rows; ++r) { nh[r] = hist[src[r]]; nh[r].push_back(next_tok[r]); }
         hist.swap(nh);
         ++cur_len;
@@ -470,12 +480,12 @@ extern "C" int rdx_beam_search(rdx_ctx* c, const int32_t* ids, const int32_t* ma
         for (int g = 0; g < groups; ++g) all_done = all_done && done[g];
         if (all_done || cur_len >= T + max_new) break;
         // next forward: _reorder_cache (generated slots only -- the beams of a group share their prompt), chosen tokens in
-        HIPCHK(c, hipMemcpyAsync(c->bm_src, src.data(), rows * sizeof(int), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->bm_src, src.data(), 2 * rows * sizeof(int), hipMemcpyHostToDevice, s));
         HIPCHK(c, hipMemcpyAsync(c->bm_tok, next_tok.data(), rows * sizeof(int), hipMemcpyHostToDevice, s));
         bool identity = true;
         for (int r = 0; r < rows; ++r) identity = identity && src[r] == r;
         if (step > 0 && !identity)
-            launch_kv_beam_reorder(c->kcache, c->vcache, c->bm_scratch, c->bm_src, rows, f.heads, f.layers, f.max_len, c->kv_layer_elems * 2,
+            launch_kv_beam_reorder(c->kcache, c->vcache, c->bm_scratch, c->bm_src, c->bm_src + rows, rows, f.heads, f.layers, f.max_len, c->kv_layer_elems * 2,
                                    p_lo, std::min((T + step + 15) / 16 * 16, p_lo + span), s);
         launch_embed_rows(f.dtype, c->bm_tok, c->embed, V, c->dx, rows, f.hidden, s);
         HIPCHK(c, hipGraphLaunch(c->graph, s));

@@ -79,31 +79,35 @@ void launch_beam_topk(int dtype, const void* logits, const float* beam_scores, i
                                                 vocab, cand_score, cand_idx, (T*)logp_out));
 }
 
-// KV cache [layer][K|V is a separate base][row][head][max_len][128] (2-byte elements); positions [p0, p1) (multiples of 16, so a K
+// KV cache [layer][K|V is a separate base][row][head][max_len][128] (2-byte elements); positions [start[r], p1) (multiples of 16, so a K
 // slab's 16-position fragment groups move whole) of row `src[r]` -> scratch row r, then scratch -> cache, all layers, K and V.
+// start[r] = the first position at which row r's history differs from its new parent's (rounded down to 16): the beams of a prompt share
+// long prefixes, and what both rows already hold -- the same tokens run through the same kernels -- is not moved (the round-2 version
+// copied every generated position of every re-parented row on every step: O(steps^2) bytes, GBs per step late in a 7B report).
 // grid: (rows * heads, layers, 2). 16 bytes per thread per trip.
 __global__ __launch_bounds__(256) void kv_beam_copy_k(char* __restrict__ kcache, char* __restrict__ vcache, char* __restrict__ scratch,
-                                                      const int* __restrict__ src, int rows, int heads, int max_len, size_t layer_bytes,
-                                                      int p0, int p1, int to_scratch) {
+                                                      const int* __restrict__ src, const int* __restrict__ start, int rows, int heads, int max_len,
+                                                      size_t layer_bytes, int p0, int p1, int to_scratch) {
     const int rh = blockIdx.x, r = rh / heads, h = rh % heads, layer = blockIdx.y, kv = blockIdx.z;
-    const int sr = src[r];
-    if (sr == r) return;                                   // this row keeps its own history: nothing to move, either way
-    const size_t span = (size_t)(p1 - p0) * 256;           // bytes of one (row, head) piece
+    const int sr = src[r], ps = max(start[r], p0);
+    if (sr == r || ps >= p1) return;                       // this row keeps its own history, or shares all of it with its parent
+    const size_t stride = (size_t)(p1 - p0) * 256;         // scratch bytes of one (row, head) piece
+    const size_t off = (size_t)(ps - p0) * 256, span = (size_t)(p1 - ps) * 256;
     char* base = (kv ? vcache : kcache) + (size_t)layer * layer_bytes;
-    char* sc = scratch + ((((size_t)layer * 2 + kv) * rows + r) * heads + h) * span;
-    char* cache_src = base + (((size_t)sr * heads + h) * max_len + p0) * 256;
-    char* cache_dst = base + (((size_t)r * heads + h) * max_len + p0) * 256;
+    char* sc = scratch + ((((size_t)layer * 2 + kv) * rows + r) * heads + h) * stride + off;
+    char* cache_src = base + (((size_t)sr * heads + h) * max_len + ps) * 256;
+    char* cache_dst = base + (((size_t)r * heads + h) * max_len + ps) * 256;
     const char* from = to_scratch ? cache_src : sc;
     char* to = to_scratch ? sc : cache_dst;
     for (size_t i = (size_t)threadIdx.x * 16; i < span; i += (size_t)blockDim.x * 16) stg16(to + i, ldg16(from + i));
 }
 
-void launch_kv_beam_reorder(void* kcache, void* vcache, void* scratch, const int* src, int rows, int heads, int layers, int max_len,
+void launch_kv_beam_reorder(void* kcache, void* vcache, void* scratch, const int* src, const int* start, int rows, int heads, int layers, int max_len,
                             size_t layer_bytes, int p0, int p1, hipStream_t s) {
     if (p1 <= p0) return;
     dim3 grid(rows * heads, layers, 2), block(256);
-    hipLaunchKernelGGL(kv_beam_copy_k, grid, block, 0, s, (char*)kcache, (char*)vcache, (char*)scratch, src, rows, heads, max_len, layer_bytes, p0, p1, 1);
-    hipLaunchKernelGGL(kv_beam_copy_k, grid, block, 0, s, (char*)kcache, (char*)vcache, (char*)scratch, src, rows, heads, max_len, layer_bytes, p0, p1, 0);
+    hipLaunchKernelGGL(kv_beam_copy_k, grid, block, 0, s, (char*)kcache, (char*)vcache, (char*)scratch, src, start, rows, heads, max_len, layer_bytes, p0, p1, 1);
+    hipLaunchKernelGGL(kv_beam_copy_k, grid, block, 0, s, (char*)kcache, (char*)vcache, (char*)scratch, src, start, rows, heads, max_len, layer_bytes, p0, p1, 0);
 }
 
 template <typename T>

@@ -211,7 +211,7 @@ void launch_greedy_step(int dtype, const float* part_val, const int* part_idx, i
 #define RDX_MAX_BEAMS 8
 void launch_beam_topk(int dtype, const void* logits, const float* beam_scores, int groups, int beams, int vocab, float* cand_score,
                       int* cand_idx, void* logp_out, hipStream_t s);
-void launch_kv_beam_reorder(void* kcache, void* vcache, void* scratch, const int* src, int rows, int heads, int layers, int max_len,
+void launch_kv_beam_reorder(void* kcache, void* vcache, void* scratch, const int* src, const int* start, int rows, int heads, int layers, int max_len,
                             size_t layer_bytes, int p0, int p1, hipStream_t s);
 void launch_embed_rows(int dtype, const int* tokens, const void* embed, int vocab, void* x, int rows, int H, hipStream_t s);
 

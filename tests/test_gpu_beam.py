@@ -57,6 +57,35 @@ def test_beam_search_matches_oracle(k, B):
     lm._engine.close()
 
 
+def test_beam_reorder_moves_only_the_diverging_suffix_and_changes_nothing(monkeypatch):
+    """_reorder_cache (modeling_llama_imgemb.py:838-843) is `past[:, beam_idx]`; rdx_beam_search moves, per re-parented row, only the cache
+    positions from the first token at which the row's old history and its new parent's differ (rounded down to the 16-position group) --
+    ADVICE r2: the whole generated span on every step was O(steps^2) traffic. 40 steps from T = 48 cross three 16-position groups, so most
+    copies start past p_lo; the run must be bit-identical (sequences, hypothesis scores, every step's processed scores) to the A/B leg
+    that moves every generated position (RDX_BEAM_FULLCOPY=1)."""
+    from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM
+    cfg = small_cfg()
+    k, B, T, N = 3, 2, 48, 40
+    outs = []
+    for full in ("1", "0"):
+        monkeypatch.setenv("RDX_BEAM_FULLCOPY", full)
+        lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.bfloat16, cfg=cfg.llama, max_batch=B * k, max_len=128, synthetic=True).eval()
+        runs = []
+        for seed in (61, 62, 63):
+            ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, seed=seed)
+            ids[1] = torch.cat([torch.zeros(5, dtype=torch.long), ids[1, : T - 5]])
+            qf = synth.synth(f"t.qfr{seed}", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+            out = lm.generate(input_ids=ids, qformer_embs=qf, num_beams=k, max_new_tokens=N, eos_token_id=-1, pad_token_id=0,
+                              return_dict_in_generate=True, output_scores=True)
+            runs.append((out.sequences.cpu(), out.sequences_scores.cpu(), torch.stack([x.float().cpu() for x in out.scores])))
+        outs.append(runs)
+        lm._engine.close()
+    for (s_full, sc_full, st_full), (s_part, sc_part, st_part) in zip(*outs):
+        assert s_full.shape[1] == T + N
+        assert torch.equal(s_full, s_part) and torch.equal(sc_full, sc_part) and torch.equal(st_full, st_part)
+    assert any(len(set(map(tuple, r[0][:, T:].tolist()))) > 1 for r in outs[0])        # the prompts do produce different reports
+
+
 def test_beam_search_argument_errors():
     from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM
     cfg = small_cfg()
