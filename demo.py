@@ -34,6 +34,7 @@ def parse_args():
     p.add_argument("--lora_model", default=None, help="adapter dir (adapter_model.bin incl. img_proj_layer)")
     p.add_argument("--max_new_tokens", type=int, default=300)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    p.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: decoder GEMMs in OCP e4m3 on the fp8 MFMA (weights_fp8=True)")
     p.add_argument("--synthetic", action="store_true", help="run on the deterministic random-init weights (no checkpoints are "
                    "reachable without a network); without it every missing weight file is an error")
     args = p.parse_args()
@@ -58,7 +59,7 @@ def init_vicuna(args):
     tok = load_tokenizer(args.vicuna)
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=dt, device_map="auto", max_batch=1, max_len=1024,
-                                                  synthetic=args.synthetic)
+                                                  synthetic=args.synthetic, weights_fp8=args.fp8)
     if args.lora_model:
         lang_model = PeftModelForCausalLM.from_pretrained(lang_model, args.lora_model, torch_dtype=dt)
     lang_model.reuse_prefix_kv = True       # chat turns re-send the whole conversation: keep the KV rows of the shared token prefix

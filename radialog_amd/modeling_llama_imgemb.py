@@ -56,7 +56,7 @@ class _BaseModel:
 
 class LlamaForCausalLM:
     def __init__(self, cfg: Optional[LlamaCfg] = None, dtype: str = "bf16", max_batch: int = 12, max_len: int = 1024,
-                 lora: bool = True, device: int = 0):
+                 lora: bool = True, device: int = 0, weights_fp8: bool = False):
         self.lcfg = cfg or LlamaCfg()
         self.config = SimpleNamespace(hidden_size=self.lcfg.hidden, vocab_size=self.lcfg.vocab,
                                       num_hidden_layers=self.lcfg.layers, pad_token_id=0, eos_token_id=2)
@@ -65,6 +65,9 @@ class LlamaForCausalLM:
         self.base_model = self.model
         self.dtype, self.lora = dtype, lora
         self.max_batch, self.max_len = max_batch, max_len
+        # BASELINE configs[4]: the decoder's GEMM weights (and, in the prefill / from batch 3, the activations) in OCP e4m3 on the fp8 MFMA; LoRA
+        # stays an un-merged model-dtype epilogue. No reference counterpart: `from_pretrained(..., weights_fp8=True)` is this build's extra kwarg
+        self.weights_fp8 = bool(weights_fp8)
         self.device = torch.device("cuda", device)
         self._engine = None
         self._state = None            # reference-named tensors (dict, stored dtype); with _synthetic they overlay the random-init generator
@@ -151,7 +154,7 @@ class LlamaForCausalLM:
         from .engine import RdxEngine, synth_getter
         cfg = RaDialogCfg(llama=self.lcfg)
         eng = RdxEngine(cfg, dtype=self.dtype, device=self.device.index or 0, max_batch=self.max_batch, max_len=self.max_len,
-                        lora=self.lora, vision=False, llama=True)
+                        lora=self.lora, vision=False, llama=True, weights_fp8=self.weights_fp8)
         if self._state is None and not self._synthetic:
             eng.close()
             raise RuntimeError("LlamaForCausalLM has no weights: build it with from_pretrained(local_dir) or from_pretrained(synthetic=True)")

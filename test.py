@@ -36,6 +36,7 @@ def main():
     p.add_argument("--max_new_tokens", type=int, default=300)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     p.add_argument("--synthetic", action="store_true", help="deterministic random-init weights (no checkpoints reachable offline)")
+    p.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: decoder GEMMs in OCP e4m3 on the fp8 MFMA (weights_fp8=True)")
     p.add_argument("--do_corr", action="store_true", help="automatic prompt correction on top of the reports (test.py:437-500)")
     p.add_argument("--do_cp_bin_qa", action="store_true", help="14 yes/no CheXpert questions per study (test.py:545-590)")
     p.add_argument("--do_cp_all_qa", action="store_true", help="'List all the findings' follow-up (test.py:608-650)")
@@ -64,7 +65,7 @@ def main():
     qa_batch = max(1, min(5, 32 // beams))
     max_batch = max(args.batch_size * beams, 14 if args.do_cp_bin_qa else 0, qa_batch * beams if args.do_cp_all_qa else 0, beams, 1)
     lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=dt, device_map="auto", max_batch=max_batch,
-                                                  max_len=1024, device=local, synthetic=args.synthetic)
+                                                  max_len=1024, device=local, synthetic=args.synthetic, weights_fp8=args.fp8)
     if args.lora_model:
         lang_model = PeftModelForCausalLM.from_pretrained(lang_model, args.lora_model, torch_dtype=dt, use_ram_optimized_load=False).half()
     lang_model.eval()

@@ -178,3 +178,30 @@ def test_set_weight_typed_is_bit_identical_to_the_widened_fp32_upload():
             outs.append((toks.cpu().clone(), sc.cpu().clone()))
             eng.close()
         assert torch.equal(outs[-2][0], outs[-1][0]) and torch.equal(outs[-2][1].view(torch.int16), outs[-1][1].view(torch.int16))
+
+
+def test_public_surface_fp8_configuration_matches_the_engine_run_directly():
+    """BASELINE configs[4] through the reference's call surface: `LlamaForCausalLM.from_pretrained(..., weights_fp8=True)` (this build's one
+    extra kwarg; the adapter stays the un-merged model-dtype epilogue of demo.py:232-234) must drive the same fp8 engine as
+    RdxEngine(weights_fp8=True): identical tokens and score bits; and it must differ from the bf16 engine's logits (the flag is not ignored)."""
+    from radialog_amd.engine import RdxEngine, synth_getter
+    from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM
+    cfg = small_cfg()
+    B, T, N = 2, 48, 6
+    ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=4)
+    qf = synth.synth("t.pubfp8", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    outs = {}
+    for fp8 in (True, False):
+        lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.bfloat16, cfg=cfg.llama, max_batch=B, max_len=128, synthetic=True,
+                                              weights_fp8=fp8).eval()
+        o = lm.generate(input_ids=ids, qformer_embs=qf, return_dict_in_generate=True, output_scores=True, max_new_tokens=N, eos_token_id=-1)
+        assert lm._engine.weights_fp8 is fp8
+        outs[fp8] = (o.sequences.cpu().clone(), torch.stack([s.cpu() for s in o.scores]))
+        lm._engine.close()
+    eng = RdxEngine(cfg, dtype="bf16", device=0, max_batch=B, max_len=128, lora=True, vision=False, weights_fp8=True)
+    eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+    toks, sc, n = eng.generate(ids, qf, max_new=N, eos_id=-1, output_scores=True)
+    assert torch.equal(outs[True][0][:, T:], toks.cpu().long()[:, :N])
+    assert torch.equal(outs[True][1].view(torch.int16), sc.cpu()[:N].view(torch.int16))
+    assert not torch.equal(outs[True][1], outs[False][1])
+    eng.close()
