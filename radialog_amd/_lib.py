@@ -11,7 +11,8 @@ import os
 import torch  # noqa: F401  -- must be imported BEFORE librdx.so is loaded so both share torch's HIP runtime
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librdx.so")
+# RDX_LIB_PATH: a differently-built librdx of the same sources (tools/sanitize_host.sh: the host side under ASan / UBSan); never a fallback
+LIB_PATH = os.environ.get("RDX_LIB_PATH") or os.path.join(HERE, "librdx.so")
 
 RDX_DTYPE_F16, RDX_DTYPE_BF16 = 0, 1
 RDX_W_GEMM, RDX_W_TENSOR, RDX_W_F32, RDX_W_GEMM_FP8 = 0, 1, 2, 3
