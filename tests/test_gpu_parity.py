@@ -346,7 +346,7 @@ def test_production_width_layers_match_oracle(B, fp8, layers, dtypes):
     the row-major K cache and the full 32-row block, hipGraph replay. Per-step logits within the north_star tolerance of the oracle,
     tokens identical (tests/_parity.py), and -- accumulation-order noise being what separates any two fp16 implementations -- the
     HIP logits must be no further from the exactly-accumulated (fp64) evaluation of the same rounding points than the torch-CPU
-    oracle is, up to a factor 3 (measured: the MFMA pipeline's fp32 accumulation leaves ~1 % of the bf16-rounded K / V elements one ulp
+    oracle is, up to a factor 2 (round 3: tightened from 3; measured ratios 0.7 ... 1.45. Cause: the MFMA pipeline's fp32 accumulation leaves ~1 % of the bf16-rounded K / V elements one ulp
 off the exact value where torch's CPU FMA chain leaves 0.03 %, tests/diag/mfma_round.py; the worst of 5 million logits then sits
 2-3 ulps out instead of 1). fp8 = BASELINE configs[4]: e4m3 weights everywhere, e4m3 activations on v_mfma_f32_16x16x32_fp8_fp8 in the
 prefill (gemm8.hip) and from batch 3 in decode (xstat32.hip); the oracle runs the reference math on the same fake-quantised operands
@@ -385,7 +385,7 @@ prefill (gemm8.hip) and from batch 3 in decode (xstat32.hip); the oracle runs th
               f"|hip-exact| {e_ht:.4g}, |oracle-exact| {e_ot:.4g}")
         if not fp8:
             ulp = 2.0 ** -8 if dtype == "f16" else 2.0 ** -5                 # one ulp at |logit| in [4, 8)
-            assert e_ht <= 3.0 * e_ot + ulp, f"{dtype}: HIP is {e_ht:.4g} from the exact evaluation, the torch-CPU oracle only {e_ot:.4g}"
+            assert e_ht <= 2.0 * e_ot + ulp, f"{dtype}: HIP is {e_ht:.4g} from the exact evaluation, the torch-CPU oracle only {e_ot:.4g}"
         eng.close()
 
 
