@@ -11,6 +11,13 @@ if REPO not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: minutes of CPU oracle time (full-depth Vicuna-7B legs); still part of -m gpu")
+    # The CPU oracle is most of the GPU suite's wall clock, and torch's default intra-op pool on a many-core host (128 threads on the
+    # 256-cpu GPU boxes) is its slowest setting: an 11008 x 4096 fp16 linear over 160 rows takes 97 ms with 128 threads, 12 ms with 32;
+    # over 5120 rows 2.5 s against 1.0-1.3 s; bf16 over 5120 rows 267 ms against 80 ms (tools/oracle_threads.py, measured on the box).
+    # Thread count does not enter the oracle's arithmetic contract (the golden vectors were produced on 8 cores).
+    import torch
+    if (os.cpu_count() or 1) >= 64:
+        torch.set_num_threads(32)
 
 
 @pytest.fixture(scope="session")
