@@ -141,11 +141,12 @@ def test_greedy_tokens_identical_to_oracle(engine, cfg, cpu_w):
     cover.check(MIN_COVER[engine.dtype], f"{engine.dtype} eager + graph")
 
 
-@pytest.mark.parametrize("T", [72, 200])
+@pytest.mark.parametrize("T", [72, 200, 520])
 def test_flash_prefill_attention_matches_oracle_and_the_16_query_kernel(cfg, cpu_w, monkeypatch, T):
     """csrc/flash.hip (64-query blocks, a wave owns 16 queries over their whole key range, V transposed through LDS once per
     workgroup) is what the batched prefill runs (>= 512 workgroups); RDX_FLASH_MIN=1 forces it onto these small prompts: left-padded
-    row, a row without <IMG>, T = 72 (two ragged query blocks) and T = 200 (four blocks, 7 key chunks, an odd last chunk), and a
+    row, a row without <IMG>, T = 72 (two ragged query blocks), T = 200 (four blocks, 7 key chunks, an odd last chunk), T = 520 (a multi-turn
+    sized prompt, test.py:440-674: nine blocks, the causal chunk skip over up to eight whole chunks), and a
     multi-turn continuation (Tk > Tq: the causal offset). Prefill logits and the K / V cache against the oracle
     (modeling_llama_imgemb.py:187-250), greedy tokens through 8 steps, and against attention_k (RDX_FLASH_MIN=0) within one ulp-ish."""
     from oracle import ref_cpu
@@ -160,7 +161,7 @@ def test_flash_prefill_attention_matches_oracle_and_the_16_query_kernel(cfg, cpu
         with torch.no_grad():
             logits, past, _ = orc.forward(orc.embed(ids, qf), km, ref_cpu.positions_from_mask(km))
             ref = orc.generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
-        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=256, lora=True, vision=False)
+        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=B, max_len=max(256, (T + 127) // 64 * 64), lora=True, vision=False)
         eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
         out = {}
         for flash in (1, 0):
