@@ -79,7 +79,7 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
     HIPCHK(c, hipEventCreate(&e1));
     int launches = 0;
     if (what == 7) {
-        // the chained down(l) -> QKV(l+1) launch (decode_layers_k, batch <= 2), IN SITU: `iters` eager decode steps with an event pair
+        // the chained down(l) -> QKV(l+1) launch (decode_chain_k, batch <= 2), IN SITU: `iters` eager decode steps with an event pair
         // around each of its launches (the hand-off counters are only valid inside a real step, so it cannot be looped alone)
         std::vector<int> slot(B);
         HIPCHK(c, hipMemcpyAsync(slot.data(), c->d_slot, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));

@@ -3,7 +3,7 @@
 //
 // Why another GEMM. gemm_dma_k stages BOTH operands of a 128 x 128 x 64 step through LDS by global_load_lds: 32 KiB of LDS-DMA
 // for 128 MFMAs. Measured per shape (tools/enc_kernels.py) every k-step costs ~1 us whatever the grid and however deep the DMA
-// ring (RDX_DMA_NS4): the CU's LDS-DMA landing rate (~25 GB/s per loader wave, MI355X_MICROARCH.md "ldsdma-fill") is the limit, and
+// ring (a four-stage build was measured in round 2 and removed): the CU's LDS-DMA landing rate (~25 GB/s per loader wave, MI355X_MICROARCH.md "ldsdma-fill") is the limit, and
 // the MFMA pipe idles at 20-25 %. Here only the WEIGHT slice goes through LDS (NT x 2 KiB per 64-deep stage, shared by all waves);
 // every wave fetches the MFMA B fragments of ITS OWN rows straight into registers (16 rows x 32 k per 16-byte lane load, through
 // the vector L1), one stage ahead, and for convolutions computes the im2col address per lane -- no activation bytes in LDS, no

@@ -62,7 +62,7 @@ CASES = [
     (4096, 4096, 1024, 1, False, 3),
     # ... its 320-row block variant (taken when it saves a round on 256 CUs: M = 5120, N = 4096 is 256 tiles instead of 320), ragged last block
     (5000, 4096, 576, 3, False, 3), (5120, 4096, 512, 0, False, 3),
-    # 16 < M <= 32 with LDS-staged activations (skinny32.hip): 4-tile and 2-tile workgroups, ragged tile groups, ragged K ranges
+    # 16 < M <= 32 on shapes outside the activation-stationary kernels' K (the generic two-row-tile GEMV; round 1's skinny32.hip is gone): ragged tile groups, ragged K ranges
     (32, 8208, 512, 3, False, 0), (19, 1040, 4096, 0, False, 0), (32, 2064, 1408, 4, False, 0), (27, 48, 11008, 3, False, 0),
     (32, 16400, 1024, 4, True, 0),
     # 16 < M <= 32, K = 4096, >= 512 tiles: activation-stationary persistent kernel (xstat32.hip): whole and ragged trips per
@@ -197,7 +197,7 @@ def test_fp8_x_fp8_gemm_matches_fake_quantised_fp32(eng, M, N, K, epi, norm, for
                                                (32, 8208, 4096, 8201, False), (21, 32016, 4096, 32001, False), (32, 8208, 4096, 8195, True),
                                                (3, 8208, 4096, 8200, True), (2, 4112, 4096, 4100, True)])
 def test_lm_head_epilogue_logits_and_greedy_choice(eng, M, N, K, n_valid, fp8):
-    """EPI_LOGITS of every weight-streaming kernel (skinny M <= 16, skinny32, xstat32; bf16/f16 and fp8 weights): logits rounded
+    """EPI_LOGITS of every weight-streaming kernel (skinny M <= 16, the two-row-tile GEMV for 16 < M <= 32, xstat32; bf16/f16 and fp8 weights): logits rounded
     to the model dtype and argmax over n < n_valid taken ON the rounded values with ties to the lowest index (torch.argmax of
     the fp16 logits row, GenerationMixin.greedy_search)."""
     dt = DT[eng.dtype]
