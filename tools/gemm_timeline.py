@@ -1,4 +1,4 @@
-"""In-kernel timeline of gemm_dma_k for one GEMM shape: python tools/gemm_timeline.py M N K [epi]  (run with RDX_WSGEMM=0)"""
+"""In-kernel timeline of gemm_dma_k for one GEMM shape: python tools/gemm_timeline.py M N K [epi]"""
 import sys, torch
 from radialog_amd.config import small_cfg
 from radialog_amd.engine import RdxEngine
