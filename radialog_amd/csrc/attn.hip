@@ -249,7 +249,9 @@ void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s)
 // LoRA + RoPE + KV-cache write of the prompt (head_dim 128)
 // ------------------------------------------------------------------------------------------------------------------
 // one thread = 8 contiguous dims of one (token, head): 16-byte loads/stores throughout; the rotate-half partner of q
-// (which needs the LoRA-updated value) is exchanged through LDS, the partner of k is read straight from the GEMM output.
+// (which needs the LoRA-updated value) sits 8 lanes away in the same 16-lane row (a head = 16 threads) and comes by DPP -- round 3: it used
+// to go through LDS behind two workgroup barriers per token, which serialised the eight waves of a workgroup on every token's load latency
+// (62 us per layer at 32 x 160 tokens for 250 MB); the partner of k is read straight from the GEMM output.
 // A workgroup handles `tpb` consecutive tokens of a prompt: a thread's LoRA-B rows (8 rows x 16 B for q and for v: 256 B per thread, 128 KiB per
 // workgroup) are read ONCE and stay in registers -- with one token per workgroup the batched prefill re-read them for each of its 5120 tokens
 // (655 MB through L2 per layer, 108 us against the 50 us its 250 MB of QKV / q / K / V traffic needs).
@@ -260,7 +262,6 @@ __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* 
                                                           T* __restrict__ qout, T* __restrict__ kcache,
                                                           T* __restrict__ vcache, int B, int Tn, int slot0, int tpb) {
     typedef typename Vec8<T>::type V8;
-    extern __shared__ float qs[];            // [hidden] q after the LoRA add
     constexpr int D = 128;
     const int b = blockIdx.y;
     const int H = d.hidden;
@@ -308,19 +309,21 @@ __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* 
             }
             V8 vo;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { qs[n0 + e] = q8[e]; vo[e] = fromf<T>(v8[e]); }
+            for (int e = 0; e < 8; ++e) vo[e] = fromf<T>(v8[e]);
             stg16(vcache + (((size_t)b * d.heads + hh) * d.max_len + slot0 + t) * D + dd, as_u4<T>(vo));
         }
-        __syncthreads();
+        // the DPP exchange runs for every lane of the wave (whole heads are active or inactive together: hidden % 128 == 0)
+        float qp8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qp8[e] = dpp_mov<DPP_ROR8>(act ? q8[e] : 0.f);          // lane ^ 8 inside the 16-lane row: dims +- 64 of the same head
         if (act) {
             const int pos = pos_ids[row];
             const V8 cv = as_vec8<T>(ldg16(cos_t + (size_t)pos * D + dd)), sv = as_vec8<T>(ldg16(sin_t + (size_t)pos * D + dd));
-            const int pn = lo ? n0 + D / 2 : n0 - D / 2;
             V8 qo, ko;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float c = tof<T>(cv[e]), sn = tof<T>(sv[e]);
-                const float qp = lo ? -qs[pn + e] : qs[pn + e];
+                const float qp = lo ? -qp8[e] : qp8[e];
                 const float kp = lo ? -kp8[e] : kp8[e];
                 qo[e] = fromf<T>(rope_one<T>(q8[e], qp, c, sn));
                 ko[e] = fromf<T>(rope_one<T>(k8[e], kp, c, sn));
@@ -328,7 +331,6 @@ __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* 
             stg16(qout + row * H + n0, as_u4<T>(qo));
             stg16(kcache + ((size_t)b * d.heads + hh) * d.max_len * D + kperm(slot0 + t, dd, d.k_perm), as_u4<T>(ko));     // fragment order per 16 positions
         }
-        __syncthreads();                     // qs is rewritten by the next token
     }
 }
 
@@ -341,8 +343,7 @@ void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, cons
     int tpb = 1;
     if ((long)T_ * B >= 2048) { tpb = (int)(((long)T_ * B + 511) / 512); tpb = tpb < 4 ? 4 : (tpb > 16 ? 16 : tpb); }
     dim3 grid((T_ + tpb - 1) / tpb, B), block(threads);
-    const size_t smem = (size_t)d.hidden * sizeof(float);
-    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rope_kv_prefill_k<T>), grid, block, smem, s, d, (const T*)qkv, (const T*)lora_bq, (const T*)lora_bv,
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rope_kv_prefill_k<T>), grid, block, 0, s, d, (const T*)qkv, (const T*)lora_bq, (const T*)lora_bv,
                                                 (const T*)cos_t, (const T*)sin_t, pos_ids, (T*)qout, (T*)kcache, (T*)vcache, B, T_, slot0, tpb));
 }
 
