@@ -270,7 +270,7 @@ __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* 
     const int hh = n0 / D, dd = n0 - hh * D;
     const bool lo = dd < D / 2;
     const bool lora = d.lora_r == 8;
-    u4 bqr[8], bvr[8];                       // the rows stay PACKED (64 VGPRs): they are v_dot2 operands as they are
+    u4 bqr[8], bvr[8];                       // the rows stay PACKED (64 VGPRs): see the empty asm in the loop
 #pragma unroll
     for (int e = 0; e < 8; ++e) { bqr[e] = (u4){0u, 0u, 0u, 0u}; bvr[e] = (u4){0u, 0u, 0u, 0u}; }
     if (act && lora) {
@@ -278,6 +278,15 @@ __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* 
         for (int e = 0; e < 8; ++e) { bqr[e] = ldg16(lbq + (size_t)(n0 + e) * 8); bvr[e] = ldg16(lbv + (size_t)(n0 + e) * 8); }
     }
     for (int t = blockIdx.x * tpb; t < min((int)(blockIdx.x + 1) * tpb, Tn); ++t) {
+        // opaque to the optimiser: without it the 128 conversions to fp32 are hoisted out of the token loop and the kernel needs 204 VGPRs
+        // (one workgroup per CU); packed, it fits 128 and two workgroups share a CU
+        V8 bq[8], bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            asm volatile("" : "+v"(bqr[e].x), "+v"(bqr[e].y), "+v"(bqr[e].z), "+v"(bqr[e].w));
+            asm volatile("" : "+v"(bvr[e].x), "+v"(bvr[e].y), "+v"(bvr[e].z), "+v"(bvr[e].w));
+            bq[e] = as_vec8<T>(bqr[e]); bv[e] = as_vec8<T>(bvr[e]);
+        }
         const size_t row = (size_t)b * Tn + t;
         const T* x = qkv + row * d.qkv_ld;
         float q8[8], k8[8], kp8[8];
@@ -288,16 +297,12 @@ __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* 
 #pragma unroll
             for (int e = 0; e < 8; ++e) { q8[e] = tof<T>(qv[e]); k8[e] = tof<T>(kv[e]); v8[e] = tof<T>(vv[e]); kp8[e] = tof<T>(kpv[e]); }
             if (lora) {
-                // lora_B(lora_A(x)): 8 products per output on the packed rows, two per v_dot2 (fp32 accumulation of exact products, as the matmul);
-                // the rows never leave their packed form (64 VGPRs) -- unpacked per token they were 128 conversions + 128 FMAs of the kernel's
-                // ~600 vector instructions per token, and the kernel was VALU-bound (59 us per layer at 32 x 160 against 42 us of traffic)
-                const u4 aq = ldg16(x + 3 * H), av = ldg16(x + 3 * H + 8);
+                const V8 aq = as_vec8<T>(ldg16(x + 3 * H)), av = as_vec8<T>(ldg16(x + 3 * H + 8));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float sq = dot2<T>(bqr[e].x, aq.x, 0.f), sv = dot2<T>(bvr[e].x, av.x, 0.f);
-                    sq = dot2<T>(bqr[e].y, aq.y, sq); sv = dot2<T>(bvr[e].y, av.y, sv);
-                    sq = dot2<T>(bqr[e].z, aq.z, sq); sv = dot2<T>(bvr[e].z, av.z, sv);
-                    sq = dot2<T>(bqr[e].w, aq.w, sq); sv = dot2<T>(bvr[e].w, av.w, sv);
+                    float sq = 0.f, sv = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { sq += tof<T>(bq[e][i]) * tof<T>(aq[i]); sv += tof<T>(bv[e][i]) * tof<T>(av[i]); }
                     q8[e] = rnd<T>(q8[e] + rnd<T>(rnd<T>(sq) * d.lora_scale));     // result += lora_B(lora_A(x)) * scaling
                     v8[e] = rnd<T>(v8[e] + rnd<T>(rnd<T>(sv) * d.lora_scale));
                 }
