@@ -43,11 +43,12 @@ sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 / fp16 MFMA peak (the 5 PFLOP/s headline includes 2:1 sparsity)
+MFMA_FP8_PEAK_TFLOPS = 5000.0    # dense fp8 MFMA peak (MX-scaled K = 128 instruction; MI355X_MICROARCH.md) -- what the fp8 prefill is priced against
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); default: the launcher's WORLD_SIZE, or 1 without a launcher")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1, help="reports per GPU per step (1 = configs[1], 32 = configs[2])")
@@ -60,7 +61,7 @@ def parse():
     ap.add_argument("--no-b32", action="store_true", help="skip the configs[2] (batch 32) sub-run of a batch-1 single-GPU bench")
     ap.add_argument("--no-fp8", action="store_true", help="skip the configs[4] (fp8 weights, batch 32) sub-run of a batch-1 bench")
     ap.add_argument("--no-graph", action="store_true")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -136,21 +137,41 @@ def _pick_threads():
     return best
 
 
-def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device, hip=None):
+def _oracle_decode(orc, ref_cpu, ids, q, n_tok):
+    """Prefill + n_tok greedy tokens on the CPU oracle -> (tokens, per-step fp32 logit rows, s_prefill, s_per_token)."""
+    km = ids.ne(0).long()
+    t0 = time.time()
+    logits, past, _ = orc.forward(orc.embed(ids, q), km, ref_cpu.positions_from_mask(km))
+    t_prefill = time.time() - t0
+    E = orc.W["model.embed_tokens.weight"]
+    toks, rows, t0 = [], [], time.time()
+    for s in range(n_tok):
+        rows.append(logits[0, -1].float().clone())
+        nxt = logits[:, -1].argmax(-1)
+        toks.append(int(nxt))
+        if s == n_tok - 1:
+            break
+        km = torch.cat([km, km.new_ones(1, 1)], -1)
+        logits, past, _ = orc.forward(torch.nn.functional.embedding(nxt[:, None], E), km, ref_cpu.positions_from_mask(km)[:, -1:], past)
+    return toks, rows, t_prefill, (time.time() - t0) / max(n_tok - 1, 1)
+
+
+def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device, hip_tf=None):
     """BASELINE configs[0], for real: the CPU oracle encodes ONE 448 px image, prefills the 160-token prompt and decodes 32 greedy
     tokens through all 32 production-width layers on the host cores (the weights are the engine's: generated on the GPU tensor by
     tensor, rounded to the model dtype, copied to the host -- not part of the timed work). The metric is quoted on 256-token
     reports: reports/s = 1 / (encode + prefill + 256 x the measured per-token time).
 
-    `hip` = (tokens int[32], per-step logits [32, V]) the engine produced for the SAME image and prompt (rank 0, row 0 of the
-    batch-1 run, outside the timed region): the oracle is then also the CHECKER of what was just timed -- full depth, the
-    benchmarked dtype, image -> tokens end to end (the oracle decodes from its own fp32 encoder output). Rule of tests/_parity.py:
-    tokens identical while the inputs are identical; a different token only where the oracle's top-2 margin is <= 2 x the measured
-    logit error of that step."""
+    `hip_tf(dtype, oracle_tokens) -> (argmax tokens int[32], logits [32, V])` runs the ENGINE on the same image and prompt (rank 0, row 0,
+    outside the timed region), teacher-forced with the oracle's tokens (rdx_decode_step_ids), so the oracle is also the CHECKER of what
+    was just timed: full depth, image -> tokens end to end (the oracle decodes from its own fp32 encoder output), all 32 steps compared.
+    Round 4: with an absolute logit bar per dtype (oracle_check) and in BOTH dtypes -- `parity` = the benchmarked dtype on the timed
+    engine, `parity_f16` = the reference's dtype (fp16, where north_star states its 1e-2 tolerance) on a second engine; the fp16 oracle
+    pass is not part of the timed CPU sample."""
     from oracle import ref_cpu
     from radialog_amd import synth
     threads = _pick_threads()
-    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[dtype_name]
+    DT = {"bf16": torch.bfloat16, "f16": torch.float16}
     n_tok = 32
     t_all = time.time()
     with torch.no_grad():
@@ -160,25 +181,15 @@ def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device, hip=None):
         t0 = time.time(); q, _ = ref_cpu.forward_image(img, Wv, cfg); t_enc = time.time() - t0
         del Wv
         specs = synth.llama_specs(cfg.llama, lora=True)
-        W = {name: gen(name, shape, device).to(dt).cpu() for name, (shape, gen) in specs.items()}
-        orc = ref_cpu.LlamaOracle(W, cfg.llama, dt, lora=True)
-        del W
         ids = synth.synth_prompt_ids(1, prompt_len, vocab=cfg.llama.vocab)
-        km = ids.ne(0).long()
-        t0 = time.time()
-        logits, past, _ = orc.forward(orc.embed(ids, q), km, ref_cpu.positions_from_mask(km))
-        t_prefill = time.time() - t0
-        E = orc.W["model.embed_tokens.weight"]
-        toks, rows, t0 = [], [], time.time()
-        for s in range(n_tok):
-            rows.append(logits[0, -1].float().clone())
-            nxt = logits[:, -1].argmax(-1)
-            toks.append(int(nxt))
-            if s == n_tok - 1:
-                break
-            km = torch.cat([km, km.new_ones(1, 1)], -1)
-            logits, past, _ = orc.forward(torch.nn.functional.embedding(nxt[:, None], E), km, ref_cpu.positions_from_mask(km)[:, -1:], past)
-        t_tok = (time.time() - t0) / (n_tok - 1)
+
+        def oracle_for(dn):
+            W = {name: gen(name, shape, device).to(DT[dn]).cpu() for name, (shape, gen) in specs.items()}
+            return ref_cpu.LlamaOracle(W, cfg.llama, DT[dn], lora=True)
+
+        orc = oracle_for(dtype_name)
+        toks, rows, t_prefill, t_tok = _oracle_decode(orc, ref_cpu, ids, q, n_tok)
+        del orc
     t_cfg0 = t_enc + t_prefill + (n_tok - 1) * t_tok
     t_report = t_enc + t_prefill + new_tokens * t_tok
     res = {
@@ -190,29 +201,58 @@ def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device, hip=None):
                    f"wall incl. weight generation {time.time()-t_all:.0f} s"),
         "s_per_token": t_tok, "s_encode": t_enc, "s_prefill": t_prefill, "config0_s": t_cfg0, "tokens": toks[:8],
     }
-    if hip is not None:
-        res["parity"] = oracle_check(hip[0], hip[1], toks, rows)
+    if hip_tf is not None:
+        ht, hl = hip_tf(dtype_name, toks)
+        res["parity"] = oracle_check(ht, hl, toks, rows, dtype_name, teacher_forced=True)
+        other = "f16" if dtype_name != "f16" else None
+        if other:
+            with torch.no_grad():
+                orc = oracle_for(other)
+                toks2, rows2, _, _ = _oracle_decode(orc, ref_cpu, ids, q, n_tok)
+                del orc
+            ht, hl = hip_tf(other, toks2)
+            res["parity_" + other] = oracle_check(ht, hl, toks2, rows2, other, teacher_forced=True)
     return res
 
 
-def oracle_check(hip_tokens, hip_logits, ref_tokens, ref_logits):
-    """The engine's greedy tokens / logits of the benchmarked configuration against the oracle's, step by step (tests/_parity.py's rule)."""
+# Absolute logit bars of the full-depth parity legs (tests/test_gpu_fullsize.py): the one-layer tolerance x sqrt(32 layers) -- 1e-2 -> 6e-2
+# in fp16 (north_star's dtype and tolerance), 8e-2 -> 0.45 in bf16 (8 x the ulp). 99 % of the steps must be inside, all inside 1.5 x.
+PARITY_ABS_BAR = {"f16": 6e-2, "bf16": 0.45}
+
+
+def oracle_check(hip_tokens, hip_logits, ref_tokens, ref_logits, dtype="bf16", teacher_forced=False):
+    """The engine's tokens / logits of the benchmarked configuration against the oracle's, step by step (tests/_parity.py's rules).
+    `ok` needs BOTH (round 4): every compared step's worst logit difference under 1.5 x the absolute bar of the dtype (the number of
+    steps over the bar itself is reported: the tests demand 99 % under it over 64 steps), and every differing argmax at an oracle top-2 margin <= 2 x the measured error of that step. Free-running
+    (teacher_forced=False) the comparison ends at the first differing token -- later inputs differ; teacher-forced (the engine was fed
+    the oracle's tokens through rdx_decode_step_ids) every step is compared."""
     n = min(len(ref_tokens), len(hip_tokens))
-    same, worst, note, ok = 0, 0.0, None, True
+    bar = PARITY_ABS_BAR[dtype]
+    same, worst, note, ok, over, compared = 0, 0.0, None, True, 0, 0
     for s in range(n):
         err = float((hip_logits[s].float().cpu() - ref_logits[s]).abs().max())
         worst = max(worst, err)
+        compared += 1
+        over += int(err >= bar)
+        if err >= 1.5 * bar:
+            ok = False
+            note = note or f"step {s}: logit error {err:.4g} exceeds 1.5 x the absolute bar {bar} of {dtype}"
         if int(hip_tokens[s]) != int(ref_tokens[s]):
             top2 = ref_logits[s].topk(2).values
             margin = float(top2[0] - top2[1])
-            ok = margin <= 2.0 * err + 1e-7
-            note = (f"step {s}: engine token {int(hip_tokens[s])} vs oracle {int(ref_tokens[s])}, oracle top-2 margin {margin:.4g}, logit error "
-                    f"{err:.4g} -> " + ("a near-tie the rounding-order noise can flip; later steps have different inputs and are not compared"
-                                         if ok else "NOT explained by the logit error: MISMATCH"))
-            break
+            flip_ok = margin <= 2.0 * err + 1e-7
+            ok = ok and flip_ok
+            msg = (f"step {s}: engine token {int(hip_tokens[s])} vs oracle {int(ref_tokens[s])}, oracle top-2 margin {margin:.4g}, logit error "
+                   f"{err:.4g} -> " + ("a near-tie the rounding-order noise can flip" + ("" if teacher_forced else "; later steps have different inputs and are not compared")
+                                        if flip_ok else "NOT explained by the logit error: MISMATCH"))
+            note = msg if note is None or not flip_ok else note
+            if not teacher_forced:
+                break
+            continue
         same += 1
-    return {"checked": "image -> tokens, full depth, the benchmarked dtype, rank 0 row 0 (outside the timed region)",
-            "tokens_identical": same, "tokens_compared": n, "worst_logit_err": worst, "divergence": note, "ok": ok}
+    return {"checked": "image -> tokens, full depth, rank 0 row 0 (outside the timed region)" + (", teacher-forced with the oracle's tokens" if teacher_forced else ""),
+            "dtype": dtype, "abs_bar": bar, "tokens_identical": same, "tokens_compared": compared, "steps_over_bar": over, "worst_logit_err": worst,
+            "divergence": note, "ok": ok}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -241,7 +281,7 @@ def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms
     kv_bytes = B * (T + N / 2.0) * 524288 + B * 524288          # 2 x 32 layers x 4096 x 2 B per cached token
     # dominant kernel of the decode loop, HIP events on the library's stream
     eng.generate(ids, out_q, max_new=8, eos_id=-1, pad_id=0, use_graph=use_graph)        # state: a prefill + a few steps
-    dom = None
+    dom, other = None, [None]
     if B <= 2:
         try:
             ms = eng.time_unit(7, 8)               # in situ: 8 eager decode steps, an event pair around each of the 32 chained launches
@@ -257,6 +297,22 @@ def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms
         nm = (f"xstat32_k<{args.dtype},EPI_SILU_MUL{',W8,A8 (fp8 x fp8 MFMA)' if wb == 1 else ''}> (gate/up SwiGLU, activation-stationary batch 3-32 GEMM)" if B > 2 else
               f"skinny_gemm_k<{args.dtype},MT,EPI_SILU_MUL,NORM{',W8' if wb == 1 else ''}> (gate/up SwiGLU GEMV)")
         dom = (nm, ms, nb, f"gate_up B={B} {args.dtype}{' fp8' if args.fp8 else ''}")
+        if B > 2:
+            # rocprofv3 ranks the decode attention first at batch 32 (profiles/r03_bench_default_kernel_stats.md): time it at the state the
+            # 8-token generate above left (context T + 8) and name whichever of the two takes longer per launch
+            try:
+                ms_a = eng.time_unit(6, 10)
+                L_ctx = T + 8
+                nb_a = B * (2 * L_ctx * H_ * 2 + 2 * H_ * 2 + 3 * H_ * 2 + H_ * 2)       # K and V rows of the context + the appended row, qkv in, out
+                other[0] = {"kernel": f"decode_attention_k<{args.dtype}> (batch-32 throughput variant; LoRA-B + RoPE + KV append + softmax.V)",
+                            "us_per_launch": ms_a * 1e3, "bytes_per_launch": nb_a, "context": L_ctx,
+                            "achieved": nb_a / (ms_a * 1e-3) / 1e9, "frac": nb_a / (ms_a * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                if ms_a > ms:
+                    other[0], dom = ({"kernel": nm, "us_per_launch": ms * 1e3, "bytes_per_launch": nb, "achieved": nb / (ms * 1e-3) / 1e9,
+                                      "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                                     (other[0]["kernel"], ms_a, nb_a, f"decode_attention B={B} {args.dtype}"))
+            except Exception:
+                pass
     name, k_ms, k_bytes, key = dom
     eng.generate(ids, out_q, max_new=8, eos_id=-1, pad_id=0, use_graph=use_graph)
     step_ms = eng.time_unit(0, 20)
@@ -266,15 +322,18 @@ def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms
         "bound": "hbm", "kernel": name,
         "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(key),
-        "bytes_per_launch": k_bytes, "us_per_launch": k_ms * 1e3,
+        "bytes_per_launch": k_bytes, "us_per_launch": k_ms * 1e3, "second_kernel": other[0],
         "decode_step_ms": step_ms, "decode_step_weight_GBs": step_bytes / (step_ms * 1e-3) / 1e9,
         "decode_step_frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
         # average over the timed reports: (weights + KV read/write per SURVEY 8(d)) / mean step time / 8 TB/s
         "prefill_ms": prefill_ms, "decode_avg_step_ms": avg_step_ms,
         "decode_avg_frac": (step_bytes + kv_bytes) / (avg_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        # the encoder always computes in the model dtype (bf16 peak); the prefill GEMMs of the fp8 configuration run on the fp8 MFMA and are
+        # priced against the fp8 dense peak (round 3 reported them against the bf16 peak: VERDICT r3 "weak" 9)
         "mfma": {"peak_tflops": MFMA_PEAK_TFLOPS, "encode_gflop_per_img": encode_flops(cfg) / 1e9, "encode_tflops": enc_tf,
                  "encode_frac": enc_tf / MFMA_PEAK_TFLOPS, "prefill_tflop": prefill_flops(lc, T, B) / 1e12, "prefill_tflops": pre_tf,
-                 "prefill_frac": pre_tf / MFMA_PEAK_TFLOPS,
+                 "prefill_peak_tflops": MFMA_FP8_PEAK_TFLOPS if args.fp8 else MFMA_PEAK_TFLOPS,
+                 "prefill_frac": pre_tf / (MFMA_FP8_PEAK_TFLOPS if args.fp8 else MFMA_PEAK_TFLOPS),
                  "prefill_weight_GBs": step_bytes / (prefill_ms * 1e-3) / 1e9},
     }
     return enc_ms, roof
@@ -327,6 +386,26 @@ def fixture_check(dtype, B, fp8, tokens_row0):
     return {"key": key, "tokens": tokens_row0, "expected": want, "ok": list(want) == list(tokens_row0)}
 
 
+def cpu_baseline_pointer():
+    """N > 1 lines: the CPU oracle is timed on rank 0 at N = 1 only (contract); multi-rank lines carry the committed N = 1 figure of this
+    build so that SCALE records are self-contained."""
+    for name in ("r04_bench.json", "r03_bench.json"):
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                cb = json.loads(f.read().strip().splitlines()[-1])["cpu_baseline"]
+            return {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                    "sample": f"not re-timed at N > 1: the N = 1 figure committed in profiles/{name} ({cb['sample'][:160]}...)", "source": f"profiles/{name}"}
+        except Exception:
+            continue
+    return {"value": None, "unit": "reports/s", "cores": None, "kind": "port", "sample": "timed at N = 1 only (run `python bench.py` without --gpus)"}
+
+
+def spawn_command(n, port, argv):
+    """The launcher line `python bench.py --gpus N` turns itself into (the driver's own form): one process per GPU, 127.0.0.1 rendezvous."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` with no launcher in the environment: become `torch.distributed.run` with N local ranks (one process per
     GPU). The reference has no inference launcher to mirror (its only one is the training DDP of model/lavis/common/dist_utils.py:57-91)."""
@@ -343,18 +422,39 @@ def spawn_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs between the ranks' processes on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    cmd = spawn_command(n, port, sys.argv[1:])
     print("bench.py: no launcher in the environment, starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr)
     sys.stdout.flush(); sys.stderr.flush()
     os.execvpe(sys.executable, cmd, env)
 
 
-def main():
-    args = parse()
+def resolve_gpus(args, env):
+    """--gpus: an explicit value must agree with the launcher's WORLD_SIZE (exit 2 otherwise: the line would carry the wrong n_gpus);
+    without the flag the launcher's WORLD_SIZE is taken (`torchrun --nproc-per-node N bench.py` must not fail), or 1."""
+    world = int(env.get("WORLD_SIZE", "1")) if ("WORLD_SIZE" in env or "RANK" in env) else None
+    if args.gpus is None:
+        args.gpus = world or 1
     if args.gpus < 1:
         print("bench.py: --gpus must be >= 1", file=sys.stderr)
         sys.exit(2)
+    if world is not None and world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}; start it with --nproc-per-node {args.gpus} "
+              f"(or run `python bench.py --gpus {args.gpus}` alone: it starts the ranks itself)", file=sys.stderr)
+        sys.exit(2)
+
+
+def gather_clock(dist, elapsed, world, device):
+    """MAX over ranks of the per-rank clock + every rank's own value (per_rank_ms_per_step has exactly `world` entries)."""
+    te = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    allt = [torch.zeros_like(te) for _ in range(world)]
+    dist.all_gather(allt, te)
+    dist.all_reduce(te, op=dist.ReduceOp.MAX)
+    return float(te.item()), [float(t.item()) for t in allt]
+
+
+def main():
+    args = parse()
+    resolve_gpus(args, os.environ)
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)                          # does not return
     # ONE JSON line on stdout, whatever native libraries print: RCCL writes its version banner to fd 1 at communicator bring-up. fd 1 is
@@ -366,11 +466,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = world > 1 or "RANK" in os.environ      # by torch.distributed.run (also at --nproc-per-node 1)
-    if world != args.gpus:
-        # a launcher started a different number of ranks than the benchmark was asked to measure: the line would carry the wrong n_gpus
-        print(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}; start it with --nproc-per-node {args.gpus} "
-              f"(or run `python bench.py --gpus {args.gpus}` alone: it starts the ranks itself)", file=sys.stderr)
-        sys.exit(2)
     if local_rank >= torch.cuda.device_count():
         print(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
         sys.exit(2)
@@ -418,12 +513,8 @@ def main():
         elapsed, out, img, ids, out_q = run_steps(eng, cfg, args, B, T, N, rank, world, dist, steps, warmup, use_graph)
         per_rank_ms = [elapsed / steps * 1e3]
         if dist is not None:
-            te = torch.tensor([elapsed], dtype=torch.float64, device=host_dev(eng))
-            allt = [torch.zeros_like(te) for _ in range(world)]
-            dist.all_gather(allt, te)
-            per_rank_ms = [float(t.item()) / steps * 1e3 for t in allt]
-            dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            elapsed = float(te.item())
+            elapsed, per_rank = gather_clock(dist, elapsed, world, host_dev(eng))
+            per_rank_ms = [t / steps * 1e3 for t in per_rank]
         assert out.shape[0] == B * world and out.shape[1] == N, f"gathered token matrix {tuple(out.shape)}, expected {(B * world, N)}"
         r = {"B": B, "fp8": fp8, "steps": steps, "warmup": warmup, "elapsed": elapsed, "per_rank_ms": per_rank_ms, "comm_world": eng.comm_world,
              "comm_note": comm_note, "tokens_row0": [int(t) for t in out[rank * B, :8].tolist()]}
@@ -432,12 +523,23 @@ def main():
             r["enc_ms"], r["roof"] = measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed / steps * 1e3, use_graph)
             args.fp8 = fp8_was
             r["token_check"] = fixture_check(args.dtype, B, fp8, r["tokens_row0"])
-            if keep_engine:       # rank 0, batch 1: 32 tokens + logits of the benchmarked configuration for the oracle's check (untimed)
-                q, _ = eng.encode_image(img, want_image_embeds=False)
-                tk, sc, _ = eng.generate(ids, q, max_new=32, eos_id=-1, pad_id=0, use_graph=use_graph, output_scores=True)
-                r["hip32"] = (tk[0, :32].cpu().tolist(), sc[:32, 0].float().cpu().clone())
+            if keep_engine:       # rank 0, batch 1: the timed engine stays up for the oracle's teacher-forced check (untimed, after the sub-runs)
+                r["engine"], r["img"], r["ids"] = eng, img, ids
+                return r
         eng.close()
         return r
+
+    def engine_tf(eng, img, ids, ref_tokens):
+        """The engine on row 0 of the benchmark's image and prompt, fed the oracle's tokens: (argmax per step, fp32 logits [n, V])."""
+        q, _ = eng.encode_image(img[:1], want_image_embeds=False)
+        n = len(ref_tokens)
+        _, lg = eng.prefill(ids[:1], q, max_new=n, eos_id=-1)
+        rows = [lg[0].float().cpu().clone()]
+        for s_ in range(1, n):
+            _, lg = eng.decode_step(input_ids=torch.tensor([ref_tokens[s_ - 1]]))
+            rows.append(lg[0].float().cpu().clone())
+        hl = torch.stack(rows)
+        return hl.argmax(-1).tolist(), hl
 
     def sub_line(r, workload):
         roof = r["roof"]
@@ -485,12 +587,33 @@ def main():
         for key, (sr, wl) in subs.items():
             res[key] = sub_line(sr, wl)
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg, args.dtype, T, N, torch.device("cuda", local_rank), hip=r.get("hip32"))
-        checks = [res["token_check"]] + [res[k]["token_check"] for k in subs] + [res.get("cpu_baseline", {}).get("parity", {"ok": True})]
-        res["results_verified"] = all(c.get("ok", True) for c in checks)
+            def hip_tf(dn, ref_tokens):
+                if dn == args.dtype and not args.fp8 and r.get("engine") is not None:
+                    return engine_tf(r["engine"], r["img"], r["ids"], ref_tokens)
+                e2 = RdxEngine(cfg, dtype=dn, device=local_rank, max_batch=1, max_len=max_len, lora=True)       # the other dtype: a second engine
+                e2.load_weights(synth_getter(cfg, e2.device, lora=True))
+                try:
+                    return engine_tf(e2, r["img"], r["ids"], ref_tokens)
+                finally:
+                    e2.close()
+            res["cpu_baseline"] = cpu_baseline(cfg, args.dtype, T, N, torch.device("cuda", local_rank), hip_tf=None if args.fp8 else hip_tf)
+        elif world > 1:
+            res["cpu_baseline"] = cpu_baseline_pointer()
+        if r.get("engine") is not None:
+            r["engine"].close()
+        res["max_batch_per_gpu"] = 32                                       # librdx's decoder holds at most 32 rows per context (api.hip)
+        cb = res.get("cpu_baseline", {})
+        fixtures = [res["token_check"]] + [res[k]["token_check"] for k in subs]
+        oracle_ok = all(cb.get(k, {"ok": True}).get("ok", True) for k in ("parity", "parity_f16"))
+        # fixture misses are FLAGGED, not fatal (the batch-32 / fp8 fixtures were written by this engine and a toolchain change that
+        # moves one ulp would fail them); a disagreement with the CPU oracle -- the independent checker -- is fatal (exit 3)
+        res["fixtures_match"] = all(c.get("ok", True) for c in fixtures)
+        res["results_verified"] = res["fixtures_match"] and oracle_ok
         sys.stdout.flush()
         os.write(out_fd, (json.dumps(res) + "\n").encode())
-        rc = 0 if res["results_verified"] else 3
+        rc = 0 if oracle_ok else 3
+        if not res["fixtures_match"]:
+            print("bench.py: WARNING: a timed configuration's first tokens differ from tests/golden/bench_tokens.json (token_check)", file=sys.stderr)
     else:
         rc = 0
     if dist is not None:

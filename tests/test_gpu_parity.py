@@ -12,7 +12,7 @@ import torch
 
 from radialog_amd import synth
 from radialog_amd.config import small_cfg
-from _parity import Cover, check_greedy
+from _parity import Cover, check_greedy, teacher_forced as _teacher_forced
 
 pytestmark = pytest.mark.gpu
 
@@ -417,39 +417,6 @@ def test_unplanted_lm_head_teacher_forced_margin_rule(cfg, cpu_w):
               f"logit error {worst:.4g} (median oracle margin {float(ref['margins'].median()):.4g})")
         assert same >= decided                       # every decided step was identical (the helper asserted it step by step)
         eng.close()
-
-
-def _teacher_forced(eng, ref, ids, qf, N, tol, label):
-    """Decode N steps feeding the ORACLE's tokens (rdx_decode_step_ids), so that every step's inputs are the oracle's and every
-    (row, step) pair is compared -- a free-running comparison ends a row at its first near-tie flip, long before position 416.
-    Per (row, step): the largest of the 32 001 logit differences must be below tol for >= 99 % of the pairs and below 1.5 x tol for all of
-    them (round 3, measured: over 256 x 32 001 fp16 logits the extreme of the accumulation-order noise reaches 1.12e-2 = 2.9 ulps at
-    |logit| in [4, 8), where five-step legs see 6-9e-3; the oracle itself sits 5e-3 from the exactly-accumulated value); the engine's own
-    argmax equals the oracle's token unless the oracle's margin is <= 2 x the measured logit error of that step.
-    Returns (identical, total, worst error)."""
-    rt = ref["tokens"]
-    B = rt.shape[0]
-    toks, lg = eng.prefill(ids, qf, max_new=N, eos_id=-1)
-    same, worst, over = 0, 0.0, 0
-    for s in range(N):
-        if s > 0:
-            _, lg = eng.decode_step(input_ids=rt[:, s - 1])
-        lgc = lg.float().cpu()
-        assert not torch.isnan(lgc).any(), f"{label} step {s}: NaN logits"
-        err = (lgc - ref["scores"][s].float()).abs().amax(dim=1)
-        worst = max(worst, float(err.max()))
-        over += int((err >= tol).sum())
-        assert float(err.max()) < 1.5 * tol, f"{label} step {s} (position {ids.shape[1] + s}): logits differ by {float(err.max()):.4g} (bar {1.5 * tol})"
-        am = lgc.argmax(dim=1)
-        for b in range(B):
-            if int(am[b]) == int(rt[b, s]):
-                same += 1
-            else:
-                margin = float(ref["margins"][s, b])
-                assert margin <= 2.0 * float(err[b]) + 1e-7, (f"{label} row {b} step {s}: token {int(am[b])} != oracle {int(rt[b, s])} at margin "
-                                                              f"{margin:.4g}, which a logit error of {float(err[b]):.4g} cannot flip")
-    assert over <= 0.01 * B * N, f"{label}: {over} of {B * N} (row, step) pairs exceed the logit tolerance {tol}"
-    return same, B * N, worst
 
 
 @pytest.mark.parametrize("B,N,dtypes,fp8", [(1, 256, ("f16", "bf16"), False), (32, 64, ("f16", "bf16"), False), (4, 64, ("bf16",), False),

@@ -46,11 +46,21 @@ def _worker(rank, world, port, devices, rows, n, q):
         dist.destroy_process_group()
 
 
-def test_rccl_allgather_two_ranks_through_the_c_abi_is_rank_major():
+@pytest.mark.parametrize("ranks", ["two", "all"])
+def test_rccl_allgather_through_the_c_abi_is_rank_major(ranks):
+    """ranks = "two": 2 ranks (devices 0 and 1; on a one-GPU box both on device 0 -> the recorded refusal and a skip);
+    ranks = "all": min(visible GPUs, 8) ranks, one per GPU -- BASELINE configs[3]/[4]'s world on the driver's 8-GPU node (skipped below 3 GPUs)."""
     import torch.multiprocessing as mp
-    world, rows, n = 2, 3, 5
     ndev = torch.cuda.device_count()
-    devices = [0, 1] if ndev >= 2 else [0, 0]
+    if ranks == "all":
+        if ndev < 3:
+            pytest.skip(f"{ndev} GPU(s) visible: the all-GPU leg needs >= 3 (the two-rank leg covers 2)")
+        world = min(ndev, 8)
+        devices = list(range(world))
+    else:
+        world = 2
+        devices = [0, 1] if ndev >= 2 else [0, 0]
+    rows, n = 3, 5
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -81,7 +91,7 @@ def test_rccl_allgather_two_ranks_through_the_c_abi_is_rank_major():
         assert all("rdx_comm_init" in e or "ncclCommInitRank" in e for e in errs.values()), errs
         pytest.skip(f"one GPU visible: RCCL refuses two ranks of one communicator on the same device -- {errs[0]}")
     base = torch.arange(rows * n, dtype=torch.int32).view(rows, n)
-    want = torch.cat([base + 100000, base + 200000], 0).tolist()        # rank 0's rows first, then rank 1's
+    want = torch.cat([base + 100000 * (r + 1) for r in range(world)], 0).tolist()        # rank 0's rows first, then rank 1's, ...
     for r in range(world):
         status, (mat, same) = got[r]
         assert status == "ok" and same

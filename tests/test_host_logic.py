@@ -158,18 +158,14 @@ def test_peft_wrapper_forwards_attribute_writes_to_the_wrapped_model():
 def test_test_py_sizes_the_engine_for_beams_and_downstream_passes():
     """test.py's max_batch arithmetic: rows = batch x beams for the report loop, 14 greedy rows for the binary QA, 5 x
     beams for the findings QA, never more than librdx's 32 rows -- the report loop is chunked instead."""
-    import re
-    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "test.py")).read()
-    body = src[src.index("    beams = max(args.num_beams, 1)"): src.index("    lang_model = LlamaForCausalLM.from_pretrained(")]
-    body = re.sub(r"^    ", "", body, flags=re.M)
-
-    def size(batch_size, num_beams, bin_qa=False, all_qa=False):
-        from types import SimpleNamespace
-        ns = {"args": SimpleNamespace(batch_size=batch_size, num_beams=num_beams, do_cp_bin_qa=bin_qa, do_cp_all_qa=all_qa),
-              "p": SimpleNamespace(error=lambda m: (_ for _ in ()).throw(SystemExit(m))), "print": lambda *a, **k: None}
-        exec(body, ns)
-        return ns["max_batch"], ns["args"].batch_size, ns["qa_batch"]
-
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "test.py")
+    spec = importlib.util.spec_from_file_location("rdx_test_entry", path)       # (`import test` would find the stdlib's package)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    size = mod.engine_rows
+    with pytest.raises(ValueError):
+        size(1, 9)
     assert size(12, 1) == (12, 12, 5)
     assert size(12, 3) == (30, 10, 5)                       # 36 rows would not fit: chunks of 10 prompts x 3 beams
     assert size(12, 3, bin_qa=True) == (30, 10, 5)          # the greedy binary QA needs 14 rows, not 14 x 3

@@ -92,3 +92,41 @@ def test_allgather_through_the_engine_branch_world2():
     expect = _fake_generate(0, 7, 5).tolist()
     res = _run(total=7, n_new=5, use_engine=True)
     assert res[0] == expect and res[1] == expect
+
+
+def _clock_worker(rank, world, port, q):
+    import importlib.util
+    import sys
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(repo, "bench.py"))
+        mod = importlib.util.module_from_spec(spec)
+        argv, sys.argv = sys.argv, ["bench.py"]
+        try:
+            spec.loader.exec_module(mod)
+        finally:
+            sys.argv = argv
+        q.put((rank, mod.gather_clock(dist, 1.0 + rank, world, "cpu")))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_clock_is_the_max_over_ranks_and_lists_every_rank():
+    """bench.py's timing contract at N > 1 (world 4 here): `elapsed` = MAX of the per-rank clocks, `per_rank_ms_per_step` has one entry
+    per rank in rank order -- on every rank."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_clock_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        mx, per = res[r]
+        assert mx == 4.0 and per == [1.0, 2.0, 3.0, 4.0]
