@@ -189,6 +189,13 @@ int rdx_gemm_test(rdx_ctx* ctx, const void* X, const float* W, const float* bias
 int rdx_kernel_bench(rdx_ctx* ctx, int rows, int N, int K, int H, int ksize, int stride, int epi, int iters, float* ms_host,
                      long long* trace_host /* nullable: [trace_wgs][8] per-workgroup timestamps of gemm_dma_k (plain GEMMs) */, int trace_wgs);
 
+/* one NHWC convolution (ksize 1 | 3, pad ksize / 2) on caller data: path 0 = the production dispatch of the row-major kernels, 1 = the fragment-packed
+ * family pconv_k (round 4; pack -> conv -> unpack), 2 = pconv_k writing row-major itself. X [B][H][H][Cin], resid / out [B][Ho][Ho][Cout] model dtype;
+ * W [Cout][ksize^2 Cin] fp32 with K ordered (kh, kw, c); ms_host (nullable): ms per launch of the convolution kernel alone. Test / benchmark hook
+ * (the reference's convolutions are torchvision's, behind biovil_t/resnet.py:25-47). */
+int rdx_conv_test(rdx_ctx* ctx, const void* X, const float* W, const float* bias, const void* resid, void* out, int B, int H, int Cin, int Cout,
+                  int ksize, int stride, int epi, int path, int iters, float* ms_host);
+
 /* microbenchmark: aggregate GB/s that `wgs` 256-thread workgroups pull from a cache-resident buffer (bytes_per_wg each, read `reps`
  * times; shared = 1: all read the same region); mode 0 = global_load_dwordx4 to registers, 1 = global_load_lds_dwordx4 (LDS-DMA) */
 int rdx_l2_bench(rdx_ctx* ctx, int mode, long long bytes_per_wg, int shared, int reps, int wgs, float* gbps_host);

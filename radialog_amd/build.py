@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librdx.so")
-SOURCES = ["gemm.hip", "xstat32.hip", "gemm_dma.hip", "gemm8.hip", "attn.hip", "flash.hip", "chain.hip", "elem.hip", "beam.hip", "conv1x1.hip", "wsgemm.hip", "stem.hip", "wstat.hip",
+SOURCES = ["gemm.hip", "xstat32.hip", "gemm_dma.hip", "gemm8.hip", "attn.hip", "flash.hip", "chain.hip", "elem.hip", "beam.hip", "conv1x1.hip", "wsgemm.hip", "stem.hip", "wstat.hip", "pconv.hip",
            "api.hip", "api_dispatch.hip", "api_encode.hip", "api_llama.hip", "api_comm.hip", "api_debug.hip"]
 HEADERS = ["rdx_common.h", "rdx_kernels.h", "rdx_ctx.h", "skinny_body.h", "attn_body.h", "handoff.h", os.path.join("..", "..", "include", "rdx.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

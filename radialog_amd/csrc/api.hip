@@ -66,6 +66,7 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
         delete c;
         return fail(nullptr, -2, "rdx_create: cannot create stream on device %d", device_id);
     }
+    { const char* e = getenv("RDX_PCONV"); c->trunk_packed = !(e && atoi(e) == 0); }      // read once (A/B legs of the tests set it before rdx_create)
     if (hipMalloc(&c->zero16, 64) == hipSuccess) { hipMemset(c->zero16, 0, 64); c->allocs.push_back(c->zero16); } else c->zero16 = nullptr;
     c->gemm_ws_floats = (size_t)16 << 20;          // 64 MiB of fp32 split-K slabs
     if (hipMalloc((void**)&c->gemm_ws, c->gemm_ws_floats * sizeof(float)) != hipSuccess) { c->gemm_ws = nullptr; c->gemm_ws_floats = 0; }

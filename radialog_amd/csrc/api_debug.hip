@@ -236,6 +236,63 @@ extern "C" int rdx_kernel_bench(rdx_ctx* c, int rows, int N, int K, int H, int k
     return 0;
 }
 
+// One NHWC convolution on caller data through (path 0) the production dispatch of the row-major encoder path (conv_gemm) or (path 1) the
+// fragment-packed kernel family pconv_k (pack_rows -> pconv -> unpack_rows; path 2: pconv writing row-major itself). X [B][H][H][Cin] and resid /
+// out [B][Ho][Ho][Cout] model dtype, W [Cout][ksize * ksize * Cin] fp32 in the (kh, kw, c) K order, bias fp32. ms_host (nullable) = ms per launch
+// of the convolution kernel alone over `iters` launches (layout conversions excluded).
+extern "C" int rdx_conv_test(rdx_ctx* c, const void* X, const float* W, const float* bias, const void* resid, void* out, int B, int H, int Cin,
+                             int Cout, int ksize, int stride, int epi, int path, int iters, float* ms_host) {
+    if (!c || !X || !W || !out || B <= 0) return fail(c, -1, "rdx_conv_test: bad arguments");
+    if (!(ksize == 1 || ksize == 3)) return fail(c, -1, "rdx_conv_test: ksize 1 or 3");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int K = ksize * ksize * Cin, Ho = (H + 2 * (ksize / 2) - ksize) / stride + 1;
+    const int M = B * Ho * Ho, Min = B * H * H, dt = c->cfg.dtype;
+    if (K % 32 || Cout % 16) return fail(c, -1, "rdx_conv_test: need K %% 32 == 0 and Cout %% 16 == 0");
+    const bool need_res = epi == EPI_RESID || epi == EPI_RESID_RELU;
+    if (need_res && !resid) return fail(c, -1, "rdx_conv_test: epilogue needs a residual");
+    const int mt_in = (Min + 15) / 16, mt_out = (M + 15) / 16;
+    const size_t wb = (size_t)Cout * K * 2, xpb = (size_t)mt_in * 16 * Cin * 2, opb = (size_t)mt_out * 16 * Cout * 2;
+    char* buf = nullptr;
+    HIPCHK(c, hipMalloc((void**)&buf, wb + xpb + 2 * opb + 256));
+    GemmW w; w.N = Cout; w.K = K; w.Npad = Cout; w.w = buf;
+    launch_pack_weight(dt, W, buf, Cout, K, Cout, nullptr, c->stream);
+    char *xp = buf + wb, *rp = xp + xpb, *op = rp + opb;
+    struct WsScope { rdx_ctx* c; ~WsScope() { c->ws_ok = false; } } ws_scope{c};
+    c->ws_ok = true;
+    PConvArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    if (path) {
+        launch_pack_rows(dt, X, Cin, xp, Min, Cin, c->stream);
+        if (need_res) launch_pack_rows(dt, resid, Cout, rp, M, Cout, c->stream);
+        pa.X = xp; pa.W = buf; pa.bias = bias; pa.resid = need_res ? rp : nullptr; pa.out = path == 2 ? out : (void*)op; pa.zero16 = c->zero16;
+        pa.Hin = H; pa.Win = H; pa.Cin = Cin; pa.Hout = Ho; pa.Wout = Ho; pa.N = Cout; pa.M = M; pa.mt_in = mt_in; pa.mt_out = mt_out; pa.ldo = Cout;
+        if (!c->zero16 || !pconv_supported(pa, ksize * ksize, stride, epi)) { hipFree(buf); return fail(c, -1, "rdx_conv_test: shape not supported by pconv"); }
+    }
+    auto once = [&]() {
+        if (path) launch_pconv(dt, pa, ksize * ksize, stride, epi, path == 2, c->stream);
+        else conv_gemm(c, X, w, bias, need_res ? resid : nullptr, out, B, H, H, Cin, ksize, ksize, stride, ksize / 2, Ho, Ho, epi);
+    };
+    once();
+    if (ms_host && iters > 0) {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        hipEventRecord(e0, c->stream);
+        for (int i = 0; i < iters; ++i) once();
+        hipEventRecord(e1, c->stream);
+        hipEventSynchronize(e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+        *ms_host = ms / (float)iters;
+    }
+    if (path == 1) launch_unpack_rows(dt, op, out, Cout, M, Cout, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(buf);
+    HIPCHK(c, e);
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 // Microbenchmark: GB/s that `wgs` workgroups (256 threads) pull from a cache-resident buffer, `bytes_per_wg` each (shared = 1: all
 // read the same region), read `reps` times; mode 0 = global_load_dwordx4, 1 = global_load_lds_dwordx4. Returns the aggregate GB/s.
 extern "C" int rdx_l2_bench(rdx_ctx* c, int mode, long long bytes_per_wg, int shared, int reps, int wgs, float* gbps_host) {

@@ -18,6 +18,7 @@ static int ensure_enc_ws(rdx_ctx* c, int B) {
     size_t mx = std::max(act, act2);
     const int P = v_grid(f) * v_grid(f);
     mx = std::max(mx, (size_t)B * P * f.v_proj * 2);
+    mx += (size_t)16 * std::max(std::max(f.v_stem, f.v_planes[3] * 4), f.v_proj) * 2;       // fragment-packed tensors round their rows up to whole 16-row tiles
     ALLOC(c, c->vin, (size_t)B * Hp * Hp * 4 * 2);
     for (int i = 0; i < 4; ++i) ALLOC(c, c->vbuf[i], mx);
     if (f.enable_cls) {
@@ -60,9 +61,26 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
     launch_img_prep(dt, image, c->vin, Bimg, S_, 3, Hp, Hp, s);
     if (previous) launch_img_prep(dt, previous, (char*)c->vin + (size_t)Bimg * Hp * Hp * 4 * 2, Bimg, S_, 3, Hp, Hp, s);
     int Hc = S_ / 2;
+    // Round 4: the trunk runs on FRAGMENT-PACKED activations (pconv.hip: both MFMA operands straight from L2 into registers, no LDS, no
+    // barriers; packed [C / 32][pixels / 16][64][8]) whenever every convolution of it has a packed kernel -- the stem writes the packed
+    // layout, the last Bottleneck writes row-major NHWC for the GEMMs behind it. RDX_PCONV=0 keeps the row-major kernels of rounds 1-3
+    // (the A/B leg of tests/test_gpu_fullsize.py).
+    bool packed = c->zero16 && c->trunk_packed && stem_pool_supported(f.v_stem) && f.v_stem % 32 == 0;
+    if (packed) {
+        int Ch = f.v_stem;
+        for (const VBlock& vb : c->vb) {
+            PConvArgs t; memset(&t, 0, sizeof(t));
+            t.Cin = Ch; t.N = vb.planes; packed = packed && pconv_supported(t, 1, 1, EPI_RELU);
+            t.Cin = vb.planes; t.N = vb.planes; packed = packed && pconv_supported(t, 9, vb.stride, EPI_RELU);
+            t.Cin = vb.planes; t.N = 4 * vb.planes; t.resid = &t; packed = packed && pconv_supported(t, 1, 1, EPI_RESID_RELU);
+            Ch = 4 * vb.planes;
+        }
+    }
+    auto mtiles = [](long rows) { return (int)((rows + 15) / 16); };
     if (stem_pool_supported(f.v_stem)) {
         // conv1 + bn1 + relu + maxpool in one launch: the 224^2 x 64 stem output never goes to HBM (stem.hip)
-        launch_stem_pool(dt, c->vin, c->v_conv1.w, c->v_conv1_b, c->vbuf[1], B, Hp, Hc, S_ / 4, f.v_stem, s);
+        launch_stem_pool(dt, c->vin, c->v_conv1.w, c->v_conv1_b, c->vbuf[1], B, Hp, Hc, S_ / 4, f.v_stem,
+                         packed ? mtiles((long)B * (S_ / 4) * (S_ / 4)) : 0, s);
     } else {
         conv_gemm(c, c->vin, c->v_conv1, c->v_conv1_b, nullptr, c->vbuf[0], B, Hp, Hp, 4, 7, 8, 2, 0, Hc, Hc, EPI_RELU);
         launch_maxpool(dt, c->vbuf[0], c->vbuf[1], B, Hc, Hc, f.v_stem, s);
@@ -70,8 +88,27 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
     Hc = S_ / 4;
     int C = f.v_stem;
     void *cur = c->vbuf[1], *t1 = c->vbuf[0], *t2 = c->vbuf[2], *t3 = c->vbuf[3];
+    auto pconv = [&](const void* X, const GemmW& W, const float* bias, const void* resid, void* out, int Hin, int Cin, int taps, int stride, int Hout,
+                     int epi, bool rowout) {
+        PConvArgs a; memset(&a, 0, sizeof(a));
+        a.X = X; a.W = W.w; a.bias = bias; a.resid = resid; a.out = out; a.zero16 = c->zero16;
+        a.Hin = Hin; a.Win = Hin; a.Cin = Cin; a.Hout = Hout; a.Wout = Hout; a.N = W.N;
+        a.M = B * Hout * Hout; a.mt_in = mtiles((long)B * Hin * Hin); a.mt_out = mtiles(a.M); a.ldo = W.N;
+        launch_pconv(dt, a, taps, stride, epi, rowout, s);
+    };
     for (const VBlock& vb : c->vb) {
         const int Ho = (Hc - 1) / vb.stride + 1;      // 3x3 pad 1 and the 1x1 downsample agree (odd sizes: 61 -> 31)
+        if (packed) {
+            const bool last = (&vb == &c->vb.back());
+            pconv(cur, vb.c1, vb.b1, nullptr, t1, Hc, C, 1, 1, Hc, EPI_RELU, false);
+            pconv(t1, vb.c2, vb.b2, nullptr, t2, Hc, vb.planes, 9, vb.stride, Ho, EPI_RELU, false);
+            const void* idt = cur;
+            if (vb.has_ds) { pconv(cur, vb.ds, vb.bds, nullptr, t3, Hc, C, 1, vb.stride, Ho, EPI_NONE, false); idt = t3; }
+            pconv(t2, vb.c3, vb.b3, idt, t1, Ho, vb.planes, 1, 1, Ho, EPI_RESID_RELU, last);        // the trunk's output: row-major NHWC
+            std::swap(cur, t1);
+            Hc = Ho; C = 4 * vb.planes;
+            continue;
+        }
         conv_gemm(c, cur, vb.c1, vb.b1, nullptr, t1, B, Hc, Hc, C, 1, 1, 1, 0, Hc, Hc, EPI_RELU);
         conv_gemm(c, t1, vb.c2, vb.b2, nullptr, t2, B, Hc, Hc, vb.planes, 3, 3, vb.stride, 1, Ho, Ho, EPI_RELU);
         const void* idt = cur;

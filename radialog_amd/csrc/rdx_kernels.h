@@ -44,6 +44,18 @@ struct ConvGeom {        // mode 0: plain row-major A.  mode 1: im2col gather fr
     int Hin, Win, Cin, Hout, Wout, KH, KW, stride, pad;
 };
 
+// fragment-packed convolution / GEMM (pconv.hip): X, resid and out are packed activation tensors [C / 32][mtiles][64 lanes][8]
+// (m = NHWC pixel index), W the usual fragment-packed weight with K ordered (kh, kw, c)
+struct PConvArgs {
+    const void* X; const void* W; const float* bias; const void* resid; void* out;
+    const void* zero16;              // >= 16 zero bytes: what taps in the padding read
+    int Hin, Win, Cin, Hout, Wout, N;
+    int M;                           // output pixels = B x Hout x Wout
+    int mt_in, mt_out;               // 16-row tiles of the packed input / output tensors
+    int ldo;                         // row stride (elements) when the output is written row-major
+    int clog;                        // log2(Cin / 32), filled by launch_pconv
+};
+
 struct AttnArgs {        // generic softmax(QK^T/sqrt(D)) V over strided tensors
     const void* Q; const void* K; const void* V; void* O;
     long q_bs, q_ts, q_hs;           // element strides: batch, token, head
@@ -108,10 +120,17 @@ void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, i
 bool wsgemm_supported(const GemmArgs& a, const ConvGeom& cg, int epi);
 void launch_wsgemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, const void* zero16, hipStream_t s);
 
+// fragment-packed convolution (pconv.hip): taps 1 | 9 (3 x 3 pad 1), stride 1 | 2, epilogues NONE / RELU / RESID_RELU; rowout = row-major output
+bool pconv_supported(const PConvArgs& a, int taps, int stride, int epi);
+void launch_pconv(int dtype, PConvArgs a, int taps, int stride, int epi, bool rowout, hipStream_t s);
+void launch_pack_rows(int dtype, const void* X, int ldx, void* P, int M, int C, hipStream_t s);      // row-major [M][C] -> packed
+void launch_unpack_rows(int dtype, const void* P, void* X, int ldx, int M, int C, hipStream_t s);
+
 // fused ResNet stem (stem.hip): 7x7/2 conv + bias + ReLU + 3x3/2 max pool from the padded NHWC4 image to [B][Ho][Ho][stem]
 bool stem_pool_supported(int stem_channels);
+// packed_mt != 0: the output is written fragment-packed [stem / 32][packed_mt][64][8] (the layout pconv_k reads) instead of NHWC
 void launch_stem_pool(int dtype, const void* in, const void* Wp, const float* bias, void* out, int B, int Hp, int Hc, int Ho, int stem,
-                      hipStream_t s);
+                      int packed_mt, hipStream_t s);
 
 void launch_l2_bench(int mode, const void* buf, size_t bytes_per_wg, int shared, int reps, int wgs, unsigned* sink, hipStream_t s);
 

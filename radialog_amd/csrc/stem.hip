@@ -23,7 +23,7 @@ constexpr int ST_PH = 4, ST_PW = 16, ST_CR = 2 * ST_PH + 1, ST_CW = 2 * ST_PW + 
 
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void stem_pool_k(const T* __restrict__ in, const u4* __restrict__ Wp, const float* __restrict__ bias,
-                                                   T* __restrict__ out, int Hp, int Hc, int Ho) {
+                                                   T* __restrict__ out, int Hp, int Hc, int Ho, int packed_mt) {
     typedef typename Vec8<T>::type V8;
     typedef T T4 __attribute__((ext_vector_type(4)));
     constexpr int C = NT * 16, KC = 7, CPITCH = C + 8;             // conv tile pixel pitch in LDS (elements): + 16 B against bank conflicts
@@ -100,7 +100,11 @@ __global__ __launch_bounds__(256) void stem_pool_k(const T* __restrict__ in, con
         V8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = fromf<T>(m[j]);
-        stg16(out + (((size_t)b * Ho + ph0 + ph) * Ho + pw0 + pw) * C + c8 * 8, as_u4<T>(o));
+        const size_t pix = ((size_t)b * Ho + ph0 + ph) * Ho + pw0 + pw;
+        if (packed_mt)      // fragment-packed output [C / 32][packed_mt][lane (g = c8 % 4, r = m % 16)][8] for pconv_k (round 4)
+            stg16(reinterpret_cast<u4*>(out) + ((size_t)(c8 >> 2) * packed_mt + (pix >> 4)) * 64 + (c8 & 3) * 16 + (pix & 15), as_u4<T>(o));
+        else
+            stg16(out + pix * C + c8 * 8, as_u4<T>(o));
     }
 }
 
@@ -110,17 +114,17 @@ bool stem_pool_supported(int stem_channels) {
 
 // in: padded NHWC4 image [B][Hp][Hp][4] (Hp = S + 6); Wp: the stem weights packed as a [stem][224] GEMM weight; out [B][Ho][Ho][stem]
 void launch_stem_pool(int dtype, const void* in, const void* Wp, const float* bias, void* out, int B, int Hp, int Hc, int Ho, int stem,
-                      hipStream_t s) {
+                      int packed_mt, hipStream_t s) {
     dim3 grid((Ho + ST_PW - 1) / ST_PW, (Ho + ST_PH - 1) / ST_PH, B), block(256);
     RDX_DISPATCH_T(dtype, T, {
         if (stem == 64) {
             const size_t smem = (size_t)ST_CR * ST_SEG * 16 * (64 + 8) * sizeof(T);
             static bool attr = false;
             if (!attr) { (void)hipFuncSetAttribute((const void*)stem_pool_k<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-            hipLaunchKernelGGL((stem_pool_k<T, 4>), grid, block, smem, s, (const T*)in, (const u4*)Wp, bias, (T*)out, Hp, Hc, Ho);
+            hipLaunchKernelGGL((stem_pool_k<T, 4>), grid, block, smem, s, (const T*)in, (const u4*)Wp, bias, (T*)out, Hp, Hc, Ho, packed_mt);
         } else {
             const size_t smem = (size_t)ST_CR * ST_SEG * 16 * (32 + 8) * sizeof(T);
-            hipLaunchKernelGGL((stem_pool_k<T, 2>), grid, block, smem, s, (const T*)in, (const u4*)Wp, bias, (T*)out, Hp, Hc, Ho);
+            hipLaunchKernelGGL((stem_pool_k<T, 2>), grid, block, smem, s, (const T*)in, (const u4*)Wp, bias, (T*)out, Hp, Hc, Ho, packed_mt);
         }
     });
 }

@@ -275,6 +275,24 @@ class RdxEngine:
                                                eps, force), "rdx_gemm_test")
         return out
 
+    def conv_test(self, x, w, bias=None, resid=None, ksize=1, stride=1, epi=0, path=0, iters=0):
+        """One NHWC convolution (rdx_conv_test): x [B,H,H,Cin] model dtype, w [Cout, ksize*ksize*Cin] fp32 in the (kh, kw, c) K order;
+        path 0 = row-major production dispatch, 1 = fragment-packed pconv_k, 2 = pconv_k with row-major output. Returns out
+        [B,Ho,Ho,Cout] (and ms per launch when iters > 0)."""
+        B, H, _, Cin = x.shape
+        Cout = w.shape[0]
+        Ho = (H + 2 * (ksize // 2) - ksize) // stride + 1
+        x = x.to(self.device, self.tdtype).contiguous()
+        w = w.to(self.device, torch.float32).contiguous()
+        b = None if bias is None else bias.to(self.device, torch.float32).contiguous()
+        r = None if resid is None else resid.to(self.device, self.tdtype).contiguous()
+        out = torch.empty(B, Ho, Ho, Cout, dtype=self.tdtype, device=self.device)
+        ms = C.c_float(0)
+        torch.cuda.synchronize(self.device)
+        check(self.ctx, self.lib.rdx_conv_test(self.ctx, _ptr(x), _ptr(w), _ptr(b), _ptr(r), _ptr(out), B, H, Cin, Cout, ksize, stride, epi,
+                                               path, iters, C.byref(ms) if iters else None), "rdx_conv_test")
+        return (out, ms.value) if iters else out
+
     def logits_test(self, x, w, n_valid=None, fp8=False):
         """(logits [M,N] model dtype, argmax int32[M]) of x @ w.T through the lm_head epilogue of the weight-streaming kernels."""
         import ctypes

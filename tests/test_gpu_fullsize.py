@@ -32,23 +32,35 @@ def full_vis_w():
     return cfg, synth.make_weights({**synth.vision_specs(cfg.vision), **synth.qformer_specs(cfg.qformer)})
 
 
-@pytest.mark.parametrize("dtype", ["f16", "bf16"])
-def test_full_size_encoder_matches_oracle(full_vis_w, dtype):
+@pytest.fixture(scope="module")
+def full_enc_ref(full_vis_w):
     from oracle import ref_cpu
-    from radialog_amd.engine import RdxEngine, synth_getter
     cfg, W = full_vis_w
     img = synth.synth_images(8, cfg.vision.img)
     with torch.no_grad():
         ref_q, ref_emb = ref_cpu.forward_image(img, W, cfg)
+    return img, ref_q, ref_emb
+
+
+@pytest.mark.parametrize("dtype,trunk", [("f16", "packed"), ("bf16", "packed"), ("f16", "rowmajor")])
+def test_full_size_encoder_matches_oracle(full_vis_w, full_enc_ref, dtype, trunk, monkeypatch):
+    """trunk = "packed": the round-4 default -- the ResNet trunk on fragment-packed activations (pconv_k); "rowmajor" (RDX_PCONV=0 at
+    rdx_create): the LDS-staged row-major kernels of rounds 1-3, kept as the A/B leg. Both against the fp32 oracle, and against each other
+    within the same tolerance."""
+    from radialog_amd.engine import RdxEngine, synth_getter
+    cfg, W = full_vis_w
+    img, ref_q, ref_emb = full_enc_ref
+    if trunk == "rowmajor":
+        monkeypatch.setenv("RDX_PCONV", "0")
     eng = RdxEngine(cfg, dtype=dtype, device=0, llama=False)
     eng.load_weights(synth_getter(cfg, eng.device), llama=False)
     tol = ENC_TOL[dtype]
-    for B in (1, 8, 3):                   # 1: split-K over the deep layers; 8: batched tiles; 3 after 8: a smaller batch in the grown workspace
+    for B in (1, 8, 3):                   # 1: few-tile grids; 8: batched tiles; 3 after 8: a smaller batch in the grown workspace
         q, emb = eng.encode_image(img[:B].to(eng.device))
         assert q.shape == (B, 32, 768) and emb.shape == (B, 196, 1408)
         assert torch.isfinite(q).all() and torch.isfinite(emb).all()
         e_emb, e_q = _rel_l2(emb.cpu(), ref_emb[:B]), _rel_l2(q.cpu(), ref_q[:B])
-        print(f"full-size encoder {dtype} B={B}: rel-L2 image_embeds {e_emb:.3e}, Q-Former out {e_q:.3e}")
+        print(f"full-size encoder {dtype} {trunk} B={B}: rel-L2 image_embeds {e_emb:.3e}, Q-Former out {e_q:.3e}")
         assert e_emb < tol, f"B={B}: image_embeds (ResNet-50 trunk + projector + scramble + ln_vision) rel-L2 {e_emb}"
         assert e_q < tol, f"B={B}: Q-Former last_hidden_state rel-L2 {e_q}"
         # per-image: no row may hide behind the batch norm
