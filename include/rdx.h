@@ -176,7 +176,7 @@ int rdx_gemv_trace(rdx_ctx* ctx, int what, int layer, long long* host, int max_t
  * force: 0 = production dispatch (M <= 32 -> skinny, else LDS-DMA GEMM when K % 64 == 0, else tiled), 1 = skinny,
  * 2 = tiled_gemm_k, 3 = gemm_dma_k, 4 = skinny with fp8 (e4m3 + per-row scale) weights, 5 = the batch 3-32 K-split path (epi 3 only:
  * pack X, xsplit32_k, slab combine + residual), 6 = 5 with fp8 weights, 7 = the encoder's many-row kernel wsgemm_k (K % 64 == 0, epi 0-3 / 6;
- * RDX_WS_CFG=A..H forces a tile shape), 8 = the single prompt's weight-stationary kernel wstat_k (K = 4096 / 11008, epi 0 / 3 / 4: the rows are
+ * RDX_WS_CFG=A..E forces a tile shape), 8 = the single prompt's weight-stationary kernel wstat_k (K = 4096 / 11008, epi 0 / 3 / 4: the rows are
  * RMS-normalised or just re-laid into the fragment-packed order by rmsnorm_k<T, 3>, then streamed past the register-resident weights),
  * 9 / 10 / 11 = the fp8 path's prefill GEMM gemm8 (e4m3 weights x e4m3 activations with 1 / 2 / 4 K groups; K % 64 == 0, epi 0 / 3 / 4).
  * force 4 / 6 hold the fp8 weights as the engine does (e4m3 bytes + scales only): batch >= 3 shapes multiply fp8 x fp8.
@@ -188,6 +188,11 @@ int rdx_gemm_test(rdx_ctx* ctx, const void* X, const float* W, const float* bias
  * H x H x K channels -> N channels, stride, pad ksize / 2) through the dispatch the encoder / prefill use; zero-filled operands. */
 int rdx_kernel_bench(rdx_ctx* ctx, int rows, int N, int K, int H, int ksize, int stride, int epi, int iters, float* ms_host,
                      long long* trace_host /* nullable: [trace_wgs][8] per-workgroup timestamps of gemm_dma_k (plain GEMMs) */, int trace_wgs);
+
+/* test / experiment switches of one context (defaults come from the environment at rdx_create): "flash_min" = 64-query workgroups from which the
+ * batched prefill attention takes the flash-style kernel (0 never, 1 always; RDX_FLASH_MIN, default 512), "pconv" = the image encoder on
+ * fragment-packed activations (1, default) or on the row-major kernels of rounds 1-3 (0; RDX_PCONV). No reference counterpart. */
+int rdx_set_option(rdx_ctx* ctx, const char* name, int value);
 
 /* one NHWC convolution (ksize 1 | 3, pad ksize / 2) on caller data: path 0 = the production dispatch of the row-major kernels, 1 = the fragment-packed
  * family pconv_k (round 4; pack -> conv -> unpack), 2 = pconv_k writing row-major itself. X [B][H][H][Cin], resid / out [B][Ho][Ho][Cout] model dtype;

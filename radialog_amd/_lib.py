@@ -82,6 +82,7 @@ SYMBOLS = {
     "rdx_gemv_trace": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int]),
     "rdx_gemm_test": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_int]),
     "rdx_kernel_bench": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P, C.c_int]),
+    "rdx_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "rdx_conv_test": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "rdx_l2_bench": (C.c_int, [_P, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "rdx_logits_test": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),

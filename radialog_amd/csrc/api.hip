@@ -66,6 +66,8 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
         delete c;
         return fail(nullptr, -2, "rdx_create: cannot create stream on device %d", device_id);
     }
+    { const char* e = getenv("RDX_FLASH_MIN"); if (e) c->flash_min = atoi(e); }
+    { const char* e = getenv("RDX_PCONV_KSPLIT"); c->pconv_noks = e && atoi(e) == 0; }
     { const char* e = getenv("RDX_PCONV"); c->trunk_packed = !(e && atoi(e) == 0); }      // read once (A/B legs of the tests set it before rdx_create)
     if (hipMalloc(&c->zero16, 64) == hipSuccess) { hipMemset(c->zero16, 0, 64); c->allocs.push_back(c->zero16); } else c->zero16 = nullptr;
     c->gemm_ws_floats = (size_t)16 << 20;          // 64 MiB of fp32 split-K slabs
@@ -345,4 +347,13 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
     if (R.rc) return R.rc;
     c->finalized = true;
     return 0;
+}
+
+// Test / experiment switches of one context (read from the environment once, at rdx_create): "flash_min" = workgroups from which the batched
+// prefill attention takes flash_prefill_k (0 = never, 1 = always; RDX_FLASH_MIN), "pconv" = the encoder on fragment-packed activations (RDX_PCONV).
+extern "C" int rdx_set_option(rdx_ctx* c, const char* name, int value) {
+    if (!c || !name) return -1;
+    if (!strcmp(name, "flash_min")) { c->flash_min = value; return 0; }
+    if (!strcmp(name, "pconv")) { c->trunk_packed = value != 0; return 0; }
+    return fail(c, -1, "rdx_set_option: unknown option '%s'", name);
 }

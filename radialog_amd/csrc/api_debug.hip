@@ -266,6 +266,13 @@ extern "C" int rdx_conv_test(rdx_ctx* c, const void* X, const float* W, const fl
         if (need_res) launch_pack_rows(dt, resid, Cout, rp, M, Cout, c->stream);
         pa.X = xp; pa.W = buf; pa.bias = bias; pa.resid = need_res ? rp : nullptr; pa.out = path == 2 ? out : (void*)op; pa.zero16 = c->zero16;
         pa.Hin = H; pa.Win = H; pa.Cin = Cin; pa.Hout = Ho; pa.Wout = Ho; pa.N = Cout; pa.M = M; pa.mt_in = mt_in; pa.mt_out = mt_out; pa.ldo = Cout;
+        pa.no_ksplit = c->pconv_noks;
+        if (const char* e = getenv("RDX_PCONV_TILE")) {            // "MxN" or "MxNkS": forced register tile (tools/pconv_check.py)
+            if (e[0] >= '1' && e[0] <= '8' && e[1] == 'x' && (e[2] == '2' || e[2] == '4')) {
+                pa.tile_m = e[0] - '0'; pa.tile_n = e[2] - '0';
+                if (e[3] == 'k' && (e[4] == '4' || e[4] == '8')) pa.tile_k = e[4] - '0';
+            }
+        }
         if (!c->zero16 || !pconv_supported(pa, ksize * ksize, stride, epi)) { hipFree(buf); return fail(c, -1, "rdx_conv_test: shape not supported by pconv"); }
     }
     auto once = [&]() {
@@ -351,7 +358,7 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
         w.w = nullptr; w.w8 = (char*)wp + (size_t)N * K * 2; w.scale = (float*)((char*)wp + (size_t)N * K * 3);
         launch_pack_weight_fp8(c->cfg.dtype, W, w.w8, w.scale, nullptr, N, K, N, c->stream);
         char* tmp = nullptr;
-        HIPCHK(c, hipMalloc((void**)&tmp, (size_t)M * K + (size_t)M * 4 * sizeof(float)));
+        if (hipMalloc((void**)&tmp, (size_t)M * K + (size_t)M * 4 * sizeof(float)) != hipSuccess) { hipFree(wp); return fail(c, -2, "rdx_gemm_test: out of device memory"); }
         float* xs = (float*)(tmp + (size_t)M * K);
         if (norm_w) launch_rmsnorm_fp8(c->cfg.dtype, X, norm_w, tmp, xs, M, K, eps, c->stream);
         else launch_quant_rows(c->cfg.dtype, X, K, tmp, xs, M, K, G, c->stream);
@@ -395,7 +402,7 @@ extern "C" int rdx_gemm_test(rdx_ctx* c, const void* X, const float* W, const fl
         if (epi != EPI_RESID || !resid || M <= 16 || M > 32) { hipFree(wp); return fail(c, -1, "rdx_gemm_test: force 5 needs epi 3 and 16 < M <= 32"); }
         char* tmp = nullptr;
         const size_t xb = (size_t)32 * K * 2, sb = (size_t)4 * 32 * N * 4;
-        HIPCHK(c, hipMalloc((void**)&tmp, 2 * xb + sb));
+        if (hipMalloc((void**)&tmp, 2 * xb + sb) != hipSuccess) { hipFree(wp); return fail(c, -2, "rdx_gemm_test: out of device memory"); }
         launch_rmsnorm_packed32(c->cfg.dtype, const_cast<void*>(X), nullptr, tmp, M, K, eps, split8 ? 2 : 1, nullptr, 0, c->stream);   // w = null: re-layout only
         a.X = tmp; a.xpacked = split8 ? 2 : 1; a.norm_w = nullptr;
         const int kg = xsplit32_groups(a);

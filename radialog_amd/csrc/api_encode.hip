@@ -77,6 +77,14 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
         }
     }
     auto mtiles = [](long rows) { return (int)((rows + 15) / 16); };
+    // backbone_to_vit and the projector on the packed trunk output as well (single-image mode; the ViT pooler keeps the row-major kernels)
+    const bool head_packed = packed && !previous && f.v_b2v % 32 == 0 && f.v_proj % 32 == 0 && (4 * f.v_planes[3]) % 32 == 0;
+    auto pgemm_rows = [&](const void* X, int K, const GemmW& W, const float* bias, const void* resid, void* out, int rows, int epi, bool rowout) {
+        PConvArgs a; memset(&a, 0, sizeof(a));
+        a.X = X; a.W = W.w; a.bias = bias; a.resid = resid; a.out = out; a.zero16 = c->zero16;
+        a.Hin = a.Win = a.Hout = a.Wout = 1; a.Cin = K; a.N = W.N; a.M = rows; a.mt_in = a.mt_out = mtiles(rows); a.ldo = W.N; a.no_ksplit = c->pconv_noks;
+        launch_pconv(dt, a, 1, 1, epi, rowout, s);
+    };
     if (stem_pool_supported(f.v_stem)) {
         // conv1 + bn1 + relu + maxpool in one launch: the 224^2 x 64 stem output never goes to HBM (stem.hip)
         launch_stem_pool(dt, c->vin, c->v_conv1.w, c->v_conv1_b, c->vbuf[1], B, Hp, Hc, S_ / 4, f.v_stem,
@@ -93,13 +101,13 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
         PConvArgs a; memset(&a, 0, sizeof(a));
         a.X = X; a.W = W.w; a.bias = bias; a.resid = resid; a.out = out; a.zero16 = c->zero16;
         a.Hin = Hin; a.Win = Hin; a.Cin = Cin; a.Hout = Hout; a.Wout = Hout; a.N = W.N;
-        a.M = B * Hout * Hout; a.mt_in = mtiles((long)B * Hin * Hin); a.mt_out = mtiles(a.M); a.ldo = W.N;
+        a.M = B * Hout * Hout; a.mt_in = mtiles((long)B * Hin * Hin); a.mt_out = mtiles(a.M); a.ldo = W.N; a.no_ksplit = c->pconv_noks;
         launch_pconv(dt, a, taps, stride, epi, rowout, s);
     };
     for (const VBlock& vb : c->vb) {
         const int Ho = (Hc - 1) / vb.stride + 1;      // 3x3 pad 1 and the 1x1 downsample agree (odd sizes: 61 -> 31)
         if (packed) {
-            const bool last = (&vb == &c->vb.back());
+            const bool last = (&vb == &c->vb.back()) && !head_packed;     // row-major NHWC only when the GEMMs behind the trunk are the row-major ones
             pconv(cur, vb.c1, vb.b1, nullptr, t1, Hc, C, 1, 1, Hc, EPI_RELU, false);
             pconv(t1, vb.c2, vb.b2, nullptr, t2, Hc, vb.planes, 9, vb.stride, Ho, EPI_RELU, false);
             const void* idt = cur;
@@ -122,9 +130,14 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
     }
     // a3/a4: backbone_to_vit, projector (missing_previous_emb + BN folded into proj1's bias), NHWC output
     const int P = Hc * Hc;
-    { GemmArgs a = gargs(cur, C, c->v_b2v, nullptr, t1, f.v_b2v, B * P); run_gemm(c, a, EPI_NONE); }      // [B*P][b2v], NHWC = token order
     const int MP = Bimg * P;
-    if (!previous) {
+    if (head_packed) {
+        pgemm_rows(cur, C, c->v_b2v, nullptr, nullptr, t1, MP, EPI_NONE, false);
+        pgemm_rows(t1, f.v_b2v, c->v_p1, c->v_p1_b, nullptr, t2, MP, EPI_RELU, false);
+    } else
+    { GemmArgs a = gargs(cur, C, c->v_b2v, nullptr, t1, f.v_b2v, B * P); run_gemm(c, a, EPI_NONE); }      // [B*P][b2v], NHWC = token order
+    if (head_packed) {
+    } else if (!previous) {
         { GemmArgs a = gargs(t1, f.v_b2v, c->v_p1, c->v_p1_b, t2, f.v_proj, MP); run_gemm(c, a, EPI_RELU); }
     } else {
         // a3': VisionTransformerPooler over [current ; previous] tokens (biovil_t/transformer.py:73-224), then the projector's
@@ -151,6 +164,8 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
         launch_pool_concat(dt, t1, xe, qkv, Bimg, P, Cv, s);                      // [Bimg*P][2*b2v]
         { GemmArgs a = gargs(qkv, 2 * Cv, c->v_p1f, c->v_p1f_b, t2, f.v_proj, MP); run_gemm(c, a, EPI_RELU); }
     }
+    if (head_packed) pgemm_rows(t2, f.v_proj, c->v_p2, c->v_p2_b, nullptr, t3, MP, EPI_NONE, true);            // row-major [MP][proj] for the scramble / the pooling
+    else
     { GemmArgs a = gargs(t2, f.v_proj, c->v_p2, c->v_p2_b, t3, f.v_proj, MP); run_gemm(c, a, EPI_NONE); }
     if (cls_logits) {
         // findings classifier head (chexpert_model.py:16-21): avg_pool2d + flatten, fc1 + ReLU, fc2
@@ -169,8 +184,51 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
 
     // a6: Q-Former, query-only path
     const int H = f.q_hidden, NQ = f.q_nquery, M = B * NQ, KVW = c->n_cross * 2 * H;
-    launch_broadcast_rows(dt, c->q_query_ln, c->qx, NQ, H, B, s);
     { GemmArgs a = gargs(c->v_imgemb, f.v_proj, c->q_wkv, c->q_bkv, c->qkvx, KVW, MP); run_gemm(c, a, EPI_NONE); }
+    // Round 4: the hidden state and every GEMM input of the Q-Former fragment-packed (pconv_k as a plain GEMM: both operands straight into
+    // registers, the workgroup's waves splitting K; the 1024-row GEMMs of a batch of 32 had 48-192 LDS-staged tiles with 12-48 serial 0.7-us
+    // k-steps each, one image's 32 rows ran on the GEMV family): the LayerNorms and the attention output write the packed layout, only
+    // Q / K / V stay row-major for the attention kernel.
+    bool qpacked = c->trunk_packed && c->zero16 && NQ % 16 == 0 && layernorm_packed_supported(H) && H % 32 == 0 && f.q_inter % 32 == 0;
+    if (qpacked) {
+        const int mt = M / 16;
+        auto pgemm = [&](const void* X, int K, const GemmW& W, const float* bias, const void* resid, void* out, int epi, bool rowout) {
+            PConvArgs a; memset(&a, 0, sizeof(a));
+            a.X = X; a.W = W.w; a.bias = bias; a.resid = resid; a.out = out; a.zero16 = c->zero16;
+            a.Hin = a.Win = a.Hout = a.Wout = 1; a.Cin = K; a.N = W.N; a.M = M; a.mt_in = mt; a.mt_out = mt; a.ldo = W.N; a.no_ksplit = c->pconv_noks;
+            launch_pconv(dt, a, 1, 1, epi, rowout, s);
+        };
+        auto attn = [&](const void* Q, long q_ts, const void* K_, const void* V_, long kv_bs, long kv_ts, int Tk) {
+            AttnArgs at;
+            memset(&at, 0, sizeof(at));
+            at.Q = Q; at.q_bs = (long)NQ * q_ts; at.q_ts = q_ts; at.q_hs = 64;
+            at.K = K_; at.V = V_; at.k_bs = at.v_bs = kv_bs; at.k_ts = at.v_ts = kv_ts; at.k_hs = at.v_hs = 64;
+            at.O = c->qctx; at.o_packed_mt = mt;
+            at.B = B; at.H = f.q_heads; at.Tq = NQ; at.Tk = Tk;
+            launch_attention(dt, 64, at, s);
+        };
+        launch_broadcast_packed(dt, c->q_query_ln, c->qx, NQ, H, B, s);
+        for (const QLayer& L : c->ql) {
+            pgemm(c->qx, H, L.s_wqkv, L.s_bqkv, nullptr, c->qqkv, EPI_NONE, true);
+            attn(c->qqkv, 3 * H, (const char*)c->qqkv + (size_t)H * 2, (const char*)c->qqkv + (size_t)2 * H * 2, (long)NQ * 3 * H, 3 * H, NQ);
+            pgemm(c->qctx, H, L.s_wo, L.s_bo, c->qx, c->qt, EPI_RESID, false);
+            launch_layernorm_packed(dt, c->qt, L.s_g, L.s_b, c->qx, nullptr, M, H, f.q_ln_eps, s);
+            if (L.cross_idx >= 0) {
+                pgemm(c->qx, H, L.c_wq, L.c_bq, nullptr, c->qqkv, EPI_NONE, true);
+                const char* Kx = (const char*)c->qkvx + (size_t)L.cross_idx * 2 * H * 2;
+                attn(c->qqkv, H, Kx, Kx + (size_t)H * 2, (long)P * KVW, KVW, P);
+                pgemm(c->qctx, H, L.c_wo, L.c_bo, c->qx, c->qt, EPI_RESID, false);
+                launch_layernorm_packed(dt, c->qt, L.c_g, L.c_b, c->qx, nullptr, M, H, f.q_ln_eps, s);
+            }
+            pgemm(c->qx, H, L.w1, L.b1, nullptr, c->qh, EPI_GELU, false);
+            pgemm(c->qh, f.q_inter, L.w2, L.b2, c->qx, c->qt, EPI_RESID, false);
+            const bool last = (&L == &c->ql.back());
+            launch_layernorm_packed(dt, c->qt, L.f_g, L.f_b, last ? nullptr : c->qx, last ? qformer_out : nullptr, M, H, f.q_ln_eps, s);
+        }
+        HIPCHK(c, hipGetLastError());
+        return 0;
+    }
+    launch_broadcast_rows(dt, c->q_query_ln, c->qx, NQ, H, B, s);
     for (const QLayer& L : c->ql) {
         { GemmArgs a = gargs(c->qx, H, L.s_wqkv, L.s_bqkv, c->qqkv, 3 * H, M); run_gemm(c, a, EPI_NONE); }
         AttnArgs at;

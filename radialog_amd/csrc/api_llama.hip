@@ -107,7 +107,8 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
             at.K = kc; at.V = vc; at.k_bs = at.v_bs = (long)f.heads * f.max_len * 128; at.k_ts = at.v_ts = 128; at.k_hs = at.v_hs = (long)f.max_len * 128;
             at.O = c->patt; at.o_bs = (long)T * H; at.o_ts = H; at.o_hs = 128;
             at.B = B; at.H = f.heads; at.Tq = T; at.Tk = keep + T; at.causal = 1; at.k_perm = c->ld.k_perm; at.key_mask = c->key_mask; at.km_bs = f.max_len;
-            launch_attention(dt, 128, at, s);
+            at.flash_min = c->flash_min;
+        launch_attention(dt, 128, at, s);
             launch_quant_rows(dt, c->patt, H, c->pxq, c->pxs, (int)M, H, 2, s);
             g8(L.wo, H, 2, c->px, H, c->px, EPI_RESID);
             launch_rmsnorm_fp8(dt, c->px, L.mlp_norm, c->pxq, c->pxs, (int)M, H, f.rms_eps, s);
@@ -152,6 +153,7 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
         at.O = c->patt; at.o_bs = (long)T * H; at.o_ts = H; at.o_hs = 128;
         at.B = B; at.H = f.heads; at.Tq = T; at.Tk = keep + T; at.causal = 1; at.k_perm = c->ld.k_perm; at.key_mask = c->key_mask; at.km_bs = f.max_len;
         at.o_packed_mt = ws ? mtl : 0;
+        at.flash_min = c->flash_min;
         launch_attention(dt, 128, at, s);
         { GemmArgs a = gargs(c->patt, H, L.wo, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H; prompt_gemm(a, EPI_RESID, false); }
         if (ws) launch_rmsnorm_packed(dt, c->px, L.mlp_norm, c->pxn, (int)M, mtl, H, f.rms_eps, s);

@@ -31,9 +31,14 @@ namespace rdx {
 constexpr int FL_D = 128, FL_DC = FL_D / 32, FL_WAVES = 4, FL_QB = FL_WAVES * 16;
 constexpr int FL_VTP = 36;                       // keys per transposed V row in LDS (72 B: the two 4-key halves of a lane land 16 banks apart)
 
-// exp of a non-positive fp32 argument as v_exp_f32(x log2 e): within 2 ulp of expf. The fp32 softmax is rounded to the model dtype right
-// after (2^-8 / 2^-11 relative), so a probability changes -- by one model-dtype ulp -- only when it sits within 2^-22 of a rounding boundary;
-// expf's range handling and the IEEE division of the normalisation were ~40 % of this kernel's vector instructions.
+// exp of a non-positive fp32 argument as v_exp_f32(x log2 e). Error bound: the product x log2(e) is rounded once (relative 2^-24, i.e. an
+// ABSOLUTE error of |x| log2(e) 2^-24 in the exponent) and v_exp_f32 adds ~1 ulp, so the result is within (1 + |x| 2^-24 ln 2 / 2^-24 ...) =
+// about (1 + 0.69 |x|) ulp of expf: 2 ulp near 0, ~8 ulp at x = -10, ~60 ulp at x = -87 (where the probability itself is 1e-38). The fp32
+// softmax is rounded to the model dtype right after (2^-8 / 2^-11 relative), so a probability changes -- by one model-dtype ulp -- only when it
+// sits within |x| 2^-23 (relative) of a rounding boundary: for the |x| < 16 that carry any weight that is < 2^-19, and attention_k (expf +
+// IEEE division) can round such a probability the other way: the two kernels are equal within one model-dtype ulp per probability, NOT bit
+// for bit, which is why 1-2 prompts (attention_k) and batched prompts (this kernel) are compared with a tolerance in the tests. expf's range
+// handling and the IEEE division of the normalisation were ~40 % of this kernel's vector instructions.
 __device__ __forceinline__ float fexp(float x) { return __expf(x); }
 
 template <typename T> __device__ __forceinline__ float scale_score(float s);
@@ -229,8 +234,7 @@ __global__ __launch_bounds__(FL_WAVES * 64, 4) void flash_prefill_k(AttnArgs a) 
 }
 
 bool flash_prefill_supported(int head_dim, const AttnArgs& a) {
-    const char* e = getenv("RDX_FLASH_MIN");                   // read per launch: tests toggle it (0 = never, 1 = always: A / B against attention_k)
-    const int min_wgs = e ? atoi(e) : 512;
+    const int min_wgs = a.flash_min;                           // rdx_ctx::flash_min: RDX_FLASH_MIN at rdx_create (default 512), rdx_set_option("flash_min") in tests
     const long wgs = (long)((a.Tq + FL_QB - 1) / FL_QB) * a.H * a.B;
     return min_wgs > 0 && head_dim == FL_D && a.causal && wgs >= min_wgs && (a.v_ts & 7) == 0 && (a.q_ts & 7) == 0 && (a.k_perm || (a.k_ts & 7) == 0) &&
            a.key_mask && (a.km_bs & 3) == 0;

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_k(GemmArgs a) {
         // stage s + 3 goes into the slot stage s-1 was read from (past the end: the last stage again, harmless, keeps the wait counted). SP: its LDS-DMA
         // pieces are issued one by one behind the MFMAs of row tiles 1, 3, 5, ... instead of all in front of the first MFMA: an LDS-DMA instruction
         // costs 60-185 cycles of issue, and four or five of them up front left the matrix pipe idle that long every stage (batched prefill
-        // 68.8 -> 66.5 ms; behind the even row tiles 66.2-67.4; RDX_DMA256_SPREAD=0 restores the old order)
+        // 68.8 -> 66.5 ms; behind the even row tiles 66.2-67.4)
         const int sn = min(s + G2_NS - 1, nsteps - 1), slotn = (s + G2_NS - 1) % G2_NS;
         if (!spread) stage(sn, slotn);
         const u4* base = lds + (size_t)(s % G2_NS) * SUB * 64;

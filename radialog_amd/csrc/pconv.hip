@@ -66,22 +66,128 @@ void launch_unpack_rows(int dtype, const void* P, void* X, int ldx, int M, int C
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((unpack_rows_k<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const u4*)P, (T*)X, ldx, M, C, mtiles));
 }
 
+// ---- LayerNorm over the channels of a packed tensor (Q-Former post-LN; fp32 statistics, two-pass variance like layernorm_k) ------------
+// one wave per 16-row tile: lane (g, r) holds row r's channels 32 kc + 8 g .. + 8 of every chunk; a row's statistics are the sums over the four
+// lane rows g (v_permlane16/32_swap). out_f32 (nullable) = the rows in fp32 row-major [M][H] (the Q-Former's last_hidden_state).
+template <typename T, int KCW>
+__global__ __launch_bounds__(256) void layernorm_packed_k(const u4* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          u4* __restrict__ out, float* __restrict__ out_f32, int H, int mtiles, int M, float eps) {
+    // one workgroup (4 waves) per 16-row tile; wave w holds chunks w, w + 4, ... (<= KCW of them): lane (g, r) = row r's channels 32 kc + 8 g .. + 8.
+    // Row statistics: sum over a lane's values, over the four lane rows g (v_permlane16/32_swap), over the waves (LDS, fixed order).
+    typedef typename Vec8<T>::type V8;
+    __shared__ float red[2][4][16];
+    const int mt = blockIdx.x, lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, g = lane >> 4;
+    const int KC = H >> 5;
+    u4 v[KCW];
+    float gm[KCW][8], bt[KCW][8];
+#pragma unroll
+    for (int q = 0; q < KCW; ++q) {
+        const int kc = w + 4 * q;
+        if (kc < KC) {
+            v[q] = ldg16(x + ((size_t)kc * mtiles + mt) * 64 + lane);
+            const int c0 = kc * 32 + g * 8;
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c0 + 4);
+            gm[q][0] = g0.x; gm[q][1] = g0.y; gm[q][2] = g0.z; gm[q][3] = g0.w; gm[q][4] = g1.x; gm[q][5] = g1.y; gm[q][6] = g1.z; gm[q][7] = g1.w;
+            bt[q][0] = b0.x; bt[q][1] = b0.y; bt[q][2] = b0.z; bt[q][3] = b0.w; bt[q][4] = b1.x; bt[q][5] = b1.y; bt[q][6] = b1.z; bt[q][7] = b1.w;
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < KCW; ++q)
+        if (w + 4 * q < KC) {
+            const V8 e = as_vec8<T>(v[q]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += tof<T>(e[j]);
+        }
+    s = xor32_sum(xor16_sum(s));
+    if (g == 0) red[0][w][r] = s;
+    __syncthreads();
+    const float mean = ((red[0][0][r] + red[0][1][r]) + (red[0][2][r] + red[0][3][r])) / (float)H;
+    float qv = 0.f;
+#pragma unroll
+    for (int q = 0; q < KCW; ++q)
+        if (w + 4 * q < KC) {
+            const V8 e = as_vec8<T>(v[q]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = tof<T>(e[j]) - mean; qv += d * d; }
+        }
+    qv = xor32_sum(xor16_sum(qv));
+    if (g == 0) red[1][w][r] = qv;
+    __syncthreads();
+    const float rstd = rsqrtf(((red[1][0][r] + red[1][1][r]) + (red[1][2][r] + red[1][3][r])) / (float)H + eps);
+    const int m = mt * 16 + r;
+#pragma unroll
+    for (int q = 0; q < KCW; ++q) {
+        const int kc = w + 4 * q;
+        if (kc < KC) {
+            const V8 e = as_vec8<T>(v[q]);
+            V8 o;
+            float y[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { y[j] = (tof<T>(e[j]) - mean) * rstd * gm[q][j] + bt[q][j]; o[j] = fromf<T>(y[j]); }
+            if (out) out[((size_t)kc * mtiles + mt) * 64 + lane] = as_u4<T>(o);
+            if (out_f32 && m < M) {
+                float4* d = reinterpret_cast<float4*>(out_f32 + (size_t)m * H + kc * 32 + g * 8);
+                d[0] = make_float4(y[0], y[1], y[2], y[3]);
+                d[1] = make_float4(y[4], y[5], y[6], y[7]);
+            }
+        }
+    }
+}
+
+bool layernorm_packed_supported(int H) { return H % 32 == 0 && H <= 1024; }
+void launch_layernorm_packed(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* out_f32, int M, int H, float eps,
+                             hipStream_t s) {
+    const int mtiles = (M + 15) / 16;
+    RDX_DISPATCH_T(dtype, T, {
+        if (H <= 256) hipLaunchKernelGGL((layernorm_packed_k<T, 2>), dim3(mtiles), dim3(256), 0, s, (const u4*)x, gamma, beta, (u4*)out, out_f32, H, mtiles, M, eps);
+        else if (H <= 768) hipLaunchKernelGGL((layernorm_packed_k<T, 6>), dim3(mtiles), dim3(256), 0, s, (const u4*)x, gamma, beta, (u4*)out, out_f32, H, mtiles, M, eps);
+        else hipLaunchKernelGGL((layernorm_packed_k<T, 8>), dim3(mtiles), dim3(256), 0, s, (const u4*)x, gamma, beta, (u4*)out, out_f32, H, mtiles, M, eps);
+    });
+}
+
+// the `rows` x H row-major block `src` (LayerNorm(query_tokens), rows % 16 == 0) repeated for B images, packed: tile mt holds rows (mt % (rows / 16)) * 16 ..
+template <typename T>
+__global__ __launch_bounds__(256) void broadcast_packed_k(const T* __restrict__ src, u4* __restrict__ dst, int rows, int H, int mtiles) {
+    const size_t slot = (size_t)blockIdx.x * 256 + threadIdx.x, total = (size_t)(H / 32) * mtiles * 64;
+    if (slot >= total) return;
+    const int lane = slot & 63, r = lane & 15, g = lane >> 4;
+    const size_t t = slot >> 6;
+    const int mt = t % mtiles, kc = t / mtiles, row = (mt % (rows / 16)) * 16 + r;
+    dst[slot] = ldg16(src + (size_t)row * H + kc * 32 + g * 8);
+}
+void launch_broadcast_packed(int dtype, const void* src, void* dst, int rows, int H, int B, hipStream_t s) {
+    const int mtiles = B * rows / 16;
+    const size_t total = (size_t)(H / 32) * mtiles * 64;
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((broadcast_packed_k<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const T*)src, (u4*)dst, rows, H, mtiles));
+}
+
 // ---- the kernel ---------------------------------------------------------------------------------------------------------------------
 // TAPS 1 | 9 (3 x 3, pad 1); STRIDE 1 | 2; ROWOUT: the output is written row-major [M][ldo] instead of packed (the trunk's last block)
-template <typename T, int EPI, int MTW, int NTW, int TAPS, int STRIDE, bool ROWOUT>
-__global__ __launch_bounds__(256) void pconv_k(PConvArgs a) {
+// KSPLIT: the workgroup's waves (4 or 8 = blockDim / 64) share ONE output tile and split its K chunks between them; partials meet in LDS in a
+// fixed order (deterministic). For grids that cannot give every SIMD a wave (the Q-Former's 1024-row GEMMs: 192-576 tiles; the deep convolutions of a
+// single image) this shortens a wave's serial walk over K -- 24-144 dependent L2 round trips -- by the split factor at the same total traffic.
+template <typename T, int EPI, int MTW, int NTW, int TAPS, int STRIDE, bool ROWOUT, bool KSPLIT>
+__global__ __launch_bounds__(KSPLIT ? 512 : 256) void pconv_k(PConvArgs a) {
     constexpr int NS = MTW * NTW >= 16 ? 2 : (MTW * NTW >= 8 ? 3 : 4);       // register-ring depth
     typedef typename Vec8<T>::type V8;
     static_assert(NTW % 2 == 0, "column tiles are paired in the epilogue");
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int n_groups = (a.N >> 4) / NTW;
-    const int gw = blockIdx.x * 4 + w;
+    const int gw = KSPLIT ? (int)blockIdx.x : (int)blockIdx.x * 4 + w;
     const int mg = gw / n_groups, ng = gw - mg * n_groups;
     const int m_groups = (a.mt_out + MTW - 1) / MTW;
-    if (mg >= m_groups) return;
+    if (mg >= m_groups) return;                                    // (never with KSPLIT: the grid is exact, every wave reaches the barrier)
     const int clog = a.clog, cmask = TAPS > 1 ? (1 << clog) - 1 : 0x7fffffff;       // 3 x 3: Cin / 32 = 1 << clog chunks per tap (a power of two)
     const int KC = TAPS > 1 ? TAPS << clog : a.Cin >> 5;           // 32-deep chunks of K
+    // this wave's chunk range
+    int k_lo = 0, k_hi = KC;
+    if (KSPLIT) {
+        const int nw = blockDim.x >> 6, per = (KC + nw - 1) / nw;
+        k_lo = min(w * per, KC); k_hi = min(k_lo + per, KC);
+    }
     const u4* Xp = reinterpret_cast<const u4*>(a.X);
     const u4* Wp = reinterpret_cast<const u4*>(a.W) + (size_t)(ng * NTW) * KC * 64 + lane;
     const u4* zero = reinterpret_cast<const u4*>(a.zero16);
@@ -143,25 +249,51 @@ __global__ __launch_bounds__(256) void pconv_k(PConvArgs a) {
     // stage, so NS - 1 chunks are always in flight (small tiles are latency-bound per chunk: a deeper ring, not a wider tile, is what
     // shortens a wave's serial K walk)
     u4 wr[NS][NTW], xr[NS][MTW];
-    int tap_set = 0;
-    set_tap(0);
+    int tap_set = TAPS > 1 ? k_lo >> clog : 0;
+    set_tap(tap_set);
 #pragma unroll
     for (int s_ = 0; s_ < NS; ++s_) {
-        if (s_ < KC) {
-            if (TAPS > 1 && (s_ >> clog) != tap_set) { tap_set = s_ >> clog; set_tap(tap_set); }
-            load(s_, wr[s_], xr[s_]);
+        const int kn = k_lo + s_;
+        if (kn < k_hi) {
+            if (TAPS > 1 && (kn >> clog) != tap_set) { tap_set = kn >> clog; set_tap(tap_set); }
+            load(kn, wr[s_], xr[s_]);
         }
     }
-    for (int kk = 0; kk < KC; kk += NS) {
+    for (int kk = k_lo; kk < k_hi; kk += NS) {
 #pragma unroll
         for (int s_ = 0; s_ < NS; ++s_) {
-            if (kk + s_ < KC) {
+            if (kk + s_ < k_hi) {
                 mma(wr[s_], xr[s_]);
                 const int kn = kk + s_ + NS;
-                if (kn < KC) {
+                if (kn < k_hi) {
                     if (TAPS > 1 && (kn >> clog) != tap_set) { tap_set = kn >> clog; set_tap(tap_set); }
                     load(kn, wr[s_], xr[s_]);
                 }
+            }
+        }
+    }
+    if (KSPLIT) {
+        // partial tiles -> LDS [wave][j][i][lane] (16 bytes per lane); the wave that owns m-tile i (i % waves) adds the partials of its tiles in
+        // wave order and runs their epilogue
+        extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+        v4f* part = reinterpret_cast<v4f*>(psm);
+        const int nw = blockDim.x >> 6;
+#pragma unroll
+        for (int j = 0; j < NTW; ++j)
+#pragma unroll
+            for (int i = 0; i < MTW; ++i) part[((w * NTW + j) * MTW + i) * 64 + lane] = acc[j][i];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+            if ((i % nw) != w) continue;
+#pragma unroll
+            for (int j = 0; j < NTW; ++j) {
+                v4f t = part[((0 * NTW + j) * MTW + i) * 64 + lane];
+                for (int ww = 1; ww < nw; ++ww) {
+                    const v4f p = part[((ww * NTW + j) * MTW + i) * 64 + lane];
+                    t[0] += p[0]; t[1] += p[1]; t[2] += p[2]; t[3] += p[3];
+                }
+                acc[j][i] = t;
             }
         }
     }
@@ -180,6 +312,7 @@ __global__ __launch_bounds__(256) void pconv_k(PConvArgs a) {
         for (int i = 0; i < MTW; ++i) {
             const int mt = mg * MTW + i;
             if (mt >= a.mt_out) continue;
+            if (KSPLIT && (i % (int)(blockDim.x >> 6)) != w) continue;      // the owner of m-tile i holds the reduced tile
             float ve[4], vo[4];
             ve[0] = acc[jp][i][0] + be.x; ve[1] = acc[jp][i][1] + be.y; ve[2] = acc[jp][i][2] + be.z; ve[3] = acc[jp][i][3] + be.w;
             vo[0] = acc[jp + 1][i][0] + bo.x; vo[1] = acc[jp + 1][i][1] + bo.y; vo[2] = acc[jp + 1][i][2] + bo.z; vo[3] = acc[jp + 1][i][3] + bo.w;
@@ -240,62 +373,87 @@ bool pconv_supported(const PConvArgs& a, int taps, int stride, int epi) {
     return true;
 }
 
-// tile shape: the largest register tile that still gives every SIMD a wave (256 CUs x 4 SIMDs); below that the smallest tile (most waves).
-// Measured at batch 32 / batch 1 over the 23 trunk shapes (tools/pconv_check.py, profiles/r04_pconv_shapes.md): within 10 % of the best
-// tile per shape; 8 x 4 (one wave per SIMD by registers) wins only the stride-2 3 x 3 of layer3 by 5 %.
-void pconv_pick(const PConvArgs& a, int* mtw, int* ntw) {
-    const int nt = a.N / 16;
-    const char* e = getenv("RDX_PCONV_TILE");                     // "MxN" override for experiments (tools/pconv_check.py)
-    if (e && e[0] >= '1' && e[0] <= '8' && e[1] == 'x' && (e[2] == '2' || e[2] == '4') && nt % (e[2] - '0') == 0) { *mtw = e[0] - '0'; *ntw = e[2] - '0'; return; }
+// tile shape: the largest register tile that still gives every SIMD a wave (256 CUs x 4 SIMDs = 1024). When no tile does and K is long enough, the
+// waves of a workgroup split K (KSPLIT, 4 or 8 waves per tile) -- the grid grows by that factor at the same total traffic.
+// Measured at batch 32 / batch 1 over the 23 trunk shapes (tools/pconv_check.py, profiles/r04_pconv_shapes.md): within 10 % of the best tile per shape.
+void pconv_pick(const PConvArgs& a, int taps, int* mtw, int* ntw, int* ks) {
+    const int nt = a.N / 16, KC = taps * (a.Cin / 32);
+    *ks = 1;
+    if (a.tile_m > 0 && (a.tile_n == 2 || a.tile_n == 4) && nt % a.tile_n == 0) {      // forced tile (the debug hook's RDX_PCONV_TILE)
+        *mtw = a.tile_m; *ntw = a.tile_n;
+        if (a.tile_k == 4 || a.tile_k == 8) *ks = (a.tile_k == 8 && *mtw * *ntw > 8) ? 4 : a.tile_k;
+        return;
+    }
+    auto tiles = [&](int mm, int nn) { return (long)((a.mt_out + mm - 1) / mm) * (nt / nn); };
+    const long t44 = nt % 4 == 0 ? tiles(4, 4) : 0;
+    // (1) big grids (the trunk at batch): 64 x 64 tiles, one wave each, no split -- a K-split workgroup's LDS partials limit residency and a
+    //     784-tile layer4 convolution then runs in 1.5 rounds (139 vs 69 us)
+    if (t44 >= 1024 || (t44 >= 700 && a.M >= 4096)) { *mtw = 4; *ntw = 4; return; }
+    const bool allow_ks = !a.no_ksplit;
+    // (2) grids that cannot give every SIMD a wave and a K of >= 16 chunks: the workgroup's waves split K (Q-Former GEMMs at 1024 rows: 76 -> 45 us
+    //     per layer; layer3 / layer4 of a single image: 11-19 -> 6-7 us)
+    if (allow_ks && KC >= 16) {
+        if (t44 * 4 >= 1024 && t44 <= 640) { *mtw = 4; *ntw = 4; *ks = 4; return; }
+        if (tiles(4, 2) * 4 >= 1024) { *mtw = 4; *ntw = 2; *ks = 4; return; }
+        const int k = KC >= 64 ? 8 : 4;
+        if (tiles(2, 2) * k >= 1024) { *mtw = 2; *ntw = 2; *ks = k; return; }
+        *mtw = 1; *ntw = 2; *ks = k;
+        return;
+    }
+    // (3) short K: the largest tile that still gives every SIMD a wave, else the smallest tile
     static const int cand[5][2] = {{4, 4}, {4, 2}, {2, 4}, {2, 2}, {1, 2}};
-    auto waves = [&](int mm, int nn) { return (long)((a.mt_out + mm - 1) / mm) * (nt / nn); };
     for (int i = 0; i < 5; ++i) {
         if (nt % cand[i][1]) continue;
         *mtw = cand[i][0]; *ntw = cand[i][1];
-        if (waves(*mtw, *ntw) >= 1024) return;
+        if (tiles(*mtw, *ntw) >= 1024) return;
     }
 }
 
 template <typename T, int EPI, int MTW, int NTW, int TAPS, int STRIDE>
-static void launch_pc5(const PConvArgs& a, bool rowout, hipStream_t s) {
+static void launch_pc5(const PConvArgs& a, bool rowout, int ks, hipStream_t s) {
     const int n_groups = (a.N / 16) / NTW, m_groups = (a.mt_out + MTW - 1) / MTW;
     const long waves = (long)n_groups * m_groups;
+    if (ks > 1) {
+        const dim3 grid((unsigned)waves), block(64 * ks);
+        const size_t smem = (size_t)ks * MTW * NTW * 1024;
+        if (rowout) hipLaunchKernelGGL((pconv_k<T, EPI, MTW, NTW, TAPS, STRIDE, true, true>), grid, block, smem, s, a);
+        else hipLaunchKernelGGL((pconv_k<T, EPI, MTW, NTW, TAPS, STRIDE, false, true>), grid, block, smem, s, a);
+        return;
+    }
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-    if (rowout) hipLaunchKernelGGL((pconv_k<T, EPI, MTW, NTW, TAPS, STRIDE, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((pconv_k<T, EPI, MTW, NTW, TAPS, STRIDE, false>), grid, block, 0, s, a);
+    if (rowout) hipLaunchKernelGGL((pconv_k<T, EPI, MTW, NTW, TAPS, STRIDE, true, false>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((pconv_k<T, EPI, MTW, NTW, TAPS, STRIDE, false, false>), grid, block, 0, s, a);
 }
 template <typename T, int EPI, int MTW, int NTW>
-static void launch_pc3(const PConvArgs& a, int taps, int stride, bool rowout, hipStream_t s) {
-    if (taps == 1 && stride == 1) launch_pc5<T, EPI, MTW, NTW, 1, 1>(a, rowout, s);
+static void launch_pc3(const PConvArgs& a, int taps, int stride, bool rowout, int ks, hipStream_t s) {
+    if (taps == 1 && stride == 1) launch_pc5<T, EPI, MTW, NTW, 1, 1>(a, rowout, ks, s);
     else if (EPI == EPI_GELU || EPI == EPI_RESID) return;          // plain-GEMM epilogues (pconv_supported)
-    else if (taps == 1) launch_pc5<T, (EPI == EPI_GELU || EPI == EPI_RESID) ? EPI_NONE : EPI, MTW, NTW, 1, 2>(a, rowout, s);
-    else if (stride == 1) launch_pc5<T, (EPI == EPI_GELU || EPI == EPI_RESID) ? EPI_NONE : EPI, MTW, NTW, 9, 1>(a, rowout, s);
-    else launch_pc5<T, (EPI == EPI_GELU || EPI == EPI_RESID) ? EPI_NONE : EPI, MTW, NTW, 9, 2>(a, rowout, s);
+    else if (taps == 1) launch_pc5<T, (EPI == EPI_GELU || EPI == EPI_RESID) ? EPI_NONE : EPI, MTW, NTW, 1, 2>(a, rowout, ks, s);
+    else if (stride == 1) launch_pc5<T, (EPI == EPI_GELU || EPI == EPI_RESID) ? EPI_NONE : EPI, MTW, NTW, 9, 1>(a, rowout, ks, s);
+    else launch_pc5<T, (EPI == EPI_GELU || EPI == EPI_RESID) ? EPI_NONE : EPI, MTW, NTW, 9, 2>(a, rowout, ks, s);
 }
 template <typename T, int EPI>
-static void launch_pc1(const PConvArgs& a, int taps, int stride, bool rowout, int mtw, int ntw, hipStream_t s) {
+static void launch_pc1(const PConvArgs& a, int taps, int stride, bool rowout, int mtw, int ntw, int ks, hipStream_t s) {
     if (ntw == 4) {
-        if (mtw == 8) launch_pc3<T, EPI, 8, 4>(a, taps, stride, rowout, s);
-        else if (mtw == 4) launch_pc3<T, EPI, 4, 4>(a, taps, stride, rowout, s);
-        else if (mtw == 2) launch_pc3<T, EPI, 2, 4>(a, taps, stride, rowout, s);
-        else launch_pc3<T, EPI, 1, 4>(a, taps, stride, rowout, s);
+        if (mtw >= 4) launch_pc3<T, EPI, 4, 4>(a, taps, stride, rowout, ks, s);
+        else launch_pc3<T, EPI, 2, 4>(a, taps, stride, rowout, ks, s);
     } else {
-        if (mtw >= 4) launch_pc3<T, EPI, 4, 2>(a, taps, stride, rowout, s);
-        else if (mtw == 2) launch_pc3<T, EPI, 2, 2>(a, taps, stride, rowout, s);
-        else launch_pc3<T, EPI, 1, 2>(a, taps, stride, rowout, s);
+        if (mtw >= 4) launch_pc3<T, EPI, 4, 2>(a, taps, stride, rowout, ks, s);
+        else if (mtw == 2) launch_pc3<T, EPI, 2, 2>(a, taps, stride, rowout, ks, s);
+        else launch_pc3<T, EPI, 1, 2>(a, taps, stride, rowout, ks, s);
     }
 }
 
 void launch_pconv(int dtype, PConvArgs a, int taps, int stride, int epi, bool rowout, hipStream_t s) {
     a.clog = ilog2(a.Cin / 32);
-    int mtw = 1, ntw = 2;
-    pconv_pick(a, &mtw, &ntw);
+    int mtw = 1, ntw = 2, ks = 1;
+    pconv_pick(a, taps, &mtw, &ntw, &ks);
     RDX_DISPATCH_T(dtype, T, {
-        if (epi == EPI_RELU) launch_pc1<T, EPI_RELU>(a, taps, stride, rowout, mtw, ntw, s);
-        else if (epi == EPI_RESID_RELU) launch_pc1<T, EPI_RESID_RELU>(a, taps, stride, rowout, mtw, ntw, s);
-        else if (epi == EPI_GELU) launch_pc1<T, EPI_GELU>(a, taps, stride, rowout, mtw, ntw, s);
-        else if (epi == EPI_RESID) launch_pc1<T, EPI_RESID>(a, taps, stride, rowout, mtw, ntw, s);
-        else launch_pc1<T, EPI_NONE>(a, taps, stride, rowout, mtw, ntw, s);
+        if (epi == EPI_RELU) launch_pc1<T, EPI_RELU>(a, taps, stride, rowout, mtw, ntw, ks, s);
+        else if (epi == EPI_RESID_RELU) launch_pc1<T, EPI_RESID_RELU>(a, taps, stride, rowout, mtw, ntw, ks, s);
+        else if (epi == EPI_GELU) launch_pc1<T, EPI_GELU>(a, taps, stride, rowout, mtw, ntw, ks, s);
+        else if (epi == EPI_RESID) launch_pc1<T, EPI_RESID>(a, taps, stride, rowout, mtw, ntw, ks, s);
+        else launch_pc1<T, EPI_NONE>(a, taps, stride, rowout, mtw, ntw, ks, s);
     });
 }
 

@@ -98,6 +98,8 @@ struct rdx_ctx {
     void* d_cur_rope = nullptr;      // [B][2][128] cos | sin row of each row's current position (written by greedy_step_k)
     ChainLayer* d_clayers = nullptr; int* d_cctr = nullptr;
     int *d_ctr = nullptr, *d_err = nullptr;   // per-layer hand-off counters of the fused launch, sticky error flag
+    int flash_min = 512;             // batched causal prefill attention: flash_prefill_k from this many workgroups (RDX_FLASH_MIN at create / rdx_set_option)
+    bool pconv_noks = false;         // RDX_PCONV_KSPLIT=0 at create: pconv_k never splits K inside a workgroup (A/B)
     bool trunk_packed = true;        // the ResNet trunk (and the Q-Former GEMMs) on fragment-packed activations (pconv.hip); RDX_PCONV=0 at create: the row-major kernels
     bool ws_ok = false;              // set while the image encoder runs: its many-row GEMMs / convolutions may take wsgemm_k
     float* gemm_ws = nullptr; size_t gemm_ws_floats = 0;      // split-K slabs of gemm_dma_k

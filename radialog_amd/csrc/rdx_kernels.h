@@ -54,6 +54,8 @@ struct PConvArgs {
     int mt_in, mt_out;               // 16-row tiles of the packed input / output tensors
     int ldo;                         // row stride (elements) when the output is written row-major
     int clog;                        // log2(Cin / 32), filled by launch_pconv
+    int no_ksplit;                   // experiments: never let a workgroup's waves split K (rdx_ctx::pconv_noks, RDX_PCONV_KSPLIT=0 at create)
+    int tile_m, tile_n, tile_k;      // experiments: forced register tile (MTW x NTW, K split over tile_k waves; 0 = pick; tools/pconv_check.py)
 };
 
 struct AttnArgs {        // generic softmax(QK^T/sqrt(D)) V over strided tensors
@@ -66,6 +68,7 @@ struct AttnArgs {        // generic softmax(QK^T/sqrt(D)) V over strided tensors
     int causal;                      // query i attends keys j <= i + (Tk - Tq)
     int k_perm;                      // K is a decode KV-cache slab in the 16-position fragment order (rdx_common.h kperm), D = 128
     const uint8_t* key_mask; long km_bs;   // nullable [B][>=Tk], 1 = attend
+    int flash_min;                   // causal head_dim-128 prefill: take flash_prefill_k from this many 64-query workgroups (0 = never); rdx_ctx::flash_min
     int o_packed_mt;                 // != 0: O is written fragment-packed for wstat_k, [(h D + d) / 32][o_packed_mt][lane][8], row = b Tq + q
 };
 
@@ -95,7 +98,7 @@ void launch_xstat32(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 // (+ residual, rounding) by the following RMSNorm (launch_rmsnorm_packed32 with `slab`). groups = 0: shape not supported
 int xsplit32_groups(const GemmArgs& a);
 void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s);
-int xs_min_rows();        // smallest batch on the xstat32 / xsplit32 path (RDX_XS_MINM, default 3)
+int xs_min_rows();        // smallest batch on the xstat32 / xsplit32 path (3)
 void launch_tiled_gemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s);
 // LDS-DMA GEMM for plain row-major activations (M > 32, K % 64 == 0); `ws` = fp32 split-K workspace (nullable)
 bool gemm_dma_supported(const GemmArgs& a);
@@ -123,6 +126,10 @@ void launch_wsgemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, co
 // fragment-packed convolution (pconv.hip): taps 1 | 9 (3 x 3 pad 1), stride 1 | 2, epilogues NONE / RELU / RESID_RELU; rowout = row-major output
 bool pconv_supported(const PConvArgs& a, int taps, int stride, int epi);
 void launch_pconv(int dtype, PConvArgs a, int taps, int stride, int epi, bool rowout, hipStream_t s);
+// LayerNorm / broadcast on packed tensors (the Q-Former on packed activations)
+bool layernorm_packed_supported(int H);
+void launch_layernorm_packed(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* out_f32, int M, int H, float eps, hipStream_t s);
+void launch_broadcast_packed(int dtype, const void* src, void* dst, int rows, int H, int B, hipStream_t s);
 void launch_pack_rows(int dtype, const void* X, int ldx, void* P, int M, int C, hipStream_t s);      // row-major [M][C] -> packed
 void launch_unpack_rows(int dtype, const void* P, void* X, int ldx, int M, int C, hipStream_t s);
 

@@ -275,6 +275,10 @@ class RdxEngine:
                                                eps, force), "rdx_gemm_test")
         return out
 
+    def set_option(self, name: str, value: int):
+        """rdx_set_option: "flash_min" (batched prefill attention kernel choice), "pconv" (packed / row-major encoder kernels)."""
+        check(self.ctx, self.lib.rdx_set_option(self.ctx, name.encode(), int(value)), "rdx_set_option")
+
     def conv_test(self, x, w, bias=None, resid=None, ksize=1, stride=1, epi=0, path=0, iters=0):
         """One NHWC convolution (rdx_conv_test): x [B,H,H,Cin] model dtype, w [Cout, ksize*ksize*Cin] fp32 in the (kh, kw, c) K order;
         path 0 = row-major production dispatch, 1 = fragment-packed pconv_k, 2 = pconv_k with row-major output. Returns out

@@ -165,10 +165,10 @@ def test_flash_prefill_attention_matches_oracle_and_the_16_query_kernel(cfg, cpu
         eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
         out = {}
         for flash in (1, 0):
-            monkeypatch.setenv("RDX_FLASH_MIN", str(flash))
+            eng.set_option("flash_min", flash)
             toks, lg = eng.prefill(ids, qf, max_new=4)
             out[flash] = (lg.float().cpu().clone(), eng.kv_read(cfg.llama.layers - 1, 1, B)[:, :, :T].float().cpu().clone())
-        monkeypatch.setenv("RDX_FLASH_MIN", "1")
+        eng.set_option("flash_min", 1)
         tol = LOGIT_TOL[dtype]
         valid = km.bool()[:, None, :, None]
         err = float((out[1][0] - logits[:, -1].float()).abs().max())
