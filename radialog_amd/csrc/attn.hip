@@ -383,8 +383,7 @@ void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t
         const size_t smem = decode_attention_smem_floats(DA_WAVES, a.d.max_len) * sizeof(float);
         RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T, DA_WAVES>), grid, dim3(DA_WAVES * 64), smem, s, a));
     } else {
-        size_t smem = decode_attention_smem_floats(DA_WAVES_TP, a.d.max_len) * sizeof(float);
-        if (const char* pe = getenv("RDX_ATT_PAD")) smem += (size_t)atoi(pe);          // experiment: LDS padding caps the workgroups per CU
+        const size_t smem = decode_attention_smem_floats(DA_WAVES_TP, a.d.max_len) * sizeof(float);
         RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T, DA_WAVES_TP>), grid, dim3(DA_WAVES_TP * 64), smem, s, a));
     }
 }
