@@ -29,7 +29,8 @@ enum { RDX_W_GEMM = 0,   /* [rows=N][cols=K] fp32 -> model dtype, re-laid-out in
                             * form (64-deep MFMA fragment order): prefill and batch >= 3 decode multiply fp8 x fp8
                             * (activations e4m3 with a scale per row and K group), batch <= 2 expands the bytes in
                             * registers; a shape without an fp8 kernel makes the call return -8, there is no
-                            * dequantised copy to fall back to (BASELINE configs[4])                                */
+                            * dequantised copy to fall back to (BASELINE configs[4]). The 2r LoRA-A rows ride the QKV weight
+                            * and are therefore e4m3 too (own row scales, e4m3 input); only LoRA-B is a model-dtype epilogue */
 
 typedef struct rdx_config {
     int dtype;                                     /* RDX_DTYPE_* : arithmetic type of weights/activations         */

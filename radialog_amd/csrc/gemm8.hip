@@ -6,7 +6,8 @@
 // (`xgroups` ranges of K: group q = 128-deep blocks [NB q / G, NB (q + 1) / G), NB = K / 128; 1 for the projections behind an RMSNorm, 2 for o_proj, 4 for down_proj -- the
 // ranges one workgroup of the batch 3-32 K-split decode kernels holds, xstat32.hip, so that one rule describes prefill and decode),
 // scale = absmax / 448 in fp32 [M][xgroups] (elem.hip: quant_rows_k, rmsnorm -> fp8). The LoRA-B product and every other epilogue
-// stay in the model dtype (finetune.py:167-173 keeps the adapter un-merged, demo.py:232-234).
+// stay in the model dtype (finetune.py:167-173 keeps the adapter un-merged, demo.py:232-234); the 2r LoRA-A rows are 16 extra rows of the QKV
+// weight and are quantised with it (own row scales).
 //   acc (fp32) = sum over the group's k of q_w q_x;  at a group boundary acc *= sx[m][g] / sx[m][g + 1] (rows of this lane; at most three
 //   times per GEMM);  out = T(acc * sx[m][last] * sw[n]) -> epilogue. The oracle evaluates sum_g sx[m][g] sum_k q_w q_x sw[n] (fake-quantised
 //   operands, fp32): same value up to fp32 rounding order.

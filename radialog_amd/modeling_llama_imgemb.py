@@ -65,8 +65,10 @@ class LlamaForCausalLM:
         self.base_model = self.model
         self.dtype, self.lora = dtype, lora
         self.max_batch, self.max_len = max_batch, max_len
-        # BASELINE configs[4]: the decoder's GEMM weights (and, in the prefill / from batch 3, the activations) in OCP e4m3 on the fp8 MFMA; LoRA
-        # stays an un-merged model-dtype epilogue. No reference counterpart: `from_pretrained(..., weights_fp8=True)` is this build's extra kwarg
+        # BASELINE configs[4]: the decoder's GEMM weights (and, in the prefill / from batch 3, the activations) in OCP e4m3 on the fp8 MFMA. LoRA stays
+        # un-merged: the LoRA-B product is a model-dtype epilogue, the 16 LoRA-A rows are part of the QKV weight and quantised with it (their own
+        # row scales; weights.py -- the oracle mirrors it, so what this costs on a trained adapter, whose A rows are small against a row's absmax, is
+        # NOT measured here: no adapter file is reachable offline). No reference counterpart: `from_pretrained(..., weights_fp8=True)` is this build's extra kwarg
         self.weights_fp8 = bool(weights_fp8)
         self.device = torch.device("cuda", device)
         self._engine = None
