@@ -22,8 +22,11 @@
 //     32-channel chunk) are exchanged between lane rows with v_permlane16_swap so that every lane ends with 8 consecutive channels = one
 //     16-byte slot of the PACKED output -- a wave stores a complete, contiguous KiB fragment block per (chunk, m-tile); the residual is the
 //     same slot of the residual tensor. Rounding points as the tiled kernels: T(acc + bias) [relu], then T(relu(resid + that)).
-// What bounds it: the CU's vector-memory path (64 B/clk): (MTW + NTW) KiB per MTW x NTW MFMAs -- 4 x 4 tiles cap at 50 % of the MFMA peak, 8 x 4
-// at 67 %; the memory-bound stages (layer1 / layer2) stream at the HBM rate.
+//   * small grids (one image's deep stages, the Q-Former's 32 .. 1024-row GEMMs): the 4 or 8 waves of a workgroup share ONE output tile and split K (KSPLIT);
+//     partials meet in LDS in wave order (deterministic) -- a wave's serial walk over K, not the byte count, is what such a launch waits for.
+// What bounds it: the CU's vector-memory path (64 B/clk): (MTW + NTW) KiB per MTW x NTW MFMAs -- 4 x 4 tiles cap at 50 % of the MFMA peak (23-25 % reached
+// at batch 32, PMC MfmaUtil 16-21 % over the 3 x 3 shapes: profiles/r04_pconv_shapes.md, r04_pmc_encoder_b32.md); the memory-bound stages (layer1 / layer2)
+// stream at 4.1-4.5 TB/s. Also in this file: the row-major <-> packed converters of the test hook, the packed LayerNorm and query broadcast of the Q-Former.
 #include <algorithm>
 #include <stdlib.h>
 
@@ -67,8 +70,8 @@ void launch_unpack_rows(int dtype, const void* P, void* X, int ldx, int M, int C
 }
 
 // ---- LayerNorm over the channels of a packed tensor (Q-Former post-LN; fp32 statistics, two-pass variance like layernorm_k) ------------
-// one wave per 16-row tile: lane (g, r) holds row r's channels 32 kc + 8 g .. + 8 of every chunk; a row's statistics are the sums over the four
-// lane rows g (v_permlane16/32_swap). out_f32 (nullable) = the rows in fp32 row-major [M][H] (the Q-Former's last_hidden_state).
+// one 4-wave workgroup per 16-row tile (a first version with ONE wave per tile took 13.6 us at 32 rows: 24 dependent fragment loads and 190 values per
+// lane in a single wave). out_f32 (nullable) = the rows in fp32 row-major [M][H] (the Q-Former's last_hidden_state).
 template <typename T, int KCW>
 __global__ __launch_bounds__(256) void layernorm_packed_k(const u4* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           u4* __restrict__ out, float* __restrict__ out_f32, int H, int mtiles, int M, float eps) {
