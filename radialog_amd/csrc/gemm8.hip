@@ -50,6 +50,19 @@ __device__ __forceinline__ v4f mfma8x2(const v8i& a, const v8i& b, v4f c) {
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
 }
 
+// The same instruction family in its 32 x 32 x 64 shape: ONE 64-deep chunk of a 32-row tile pair per operand (lane (h, r32) = row r32 of the pair, its two
+// 16-byte pieces g = 2 h and 2 h + 1, i.e. k = 32 h .. + 32 of the chunk), 16 fp32 results per lane -- the K = 128 rate on single-chunk stages.
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef long v4l __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v8i pair8l(const u4& p0, const u4& p1) {
+    const long a0 = (long)(((unsigned long long)p0.y << 32) | p0.x), a1 = (long)(((unsigned long long)p0.w << 32) | p0.z);
+    const long b0 = (long)(((unsigned long long)p1.y << 32) | p1.x), b1 = (long)(((unsigned long long)p1.w << 32) | p1.z);
+    return __builtin_bit_cast(v8i, (v4l){a0, a1, b0, b1});
+}
+__device__ __forceinline__ v16f mfma8_32(const v8i& a, const v8i& b, v16f c) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+}
+
 // 4 consecutive columns n .. n + 3 of row m: v already carries both scales
 template <typename T, int EPI>
 __device__ __forceinline__ void store4_8(const GemmArgs& a, int m, int n, float v[4]) {
@@ -283,6 +296,143 @@ __global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
     epilogue8<T, EPI, 4, MTW>(a, acc, M0, N0, wm, wn, r, g);
 }
 
+// ---- the same block on the block-scaled instruction in its 32 x 32 x 64 shape (round 4) ---------------------------------------------------
+// Ring, staging and LDS layout are gemm8_256_k's ([stage][W 16 | X XS sub-tiles][lane (g, r)][16 bytes]); a wave's 128 (160) x 64 tile is 4 (5) x 2
+// tiles of 32 x 32: lane (h, r32) reads row r32 of a sub-tile PAIR -- pieces g = 2 h, 2 h + 1 of sub-tile 2 t + (r32 >> 4) -- so one 64-deep stage
+// is one MFMA per tile at twice the 16x16x32 rate and no stage ever waits for its neighbour (the K = 128 shape needs two resident stages per
+// MFMA: half the DMA lead, measured slower in round 3). D[n = 8 j + 4 h + e][m = r32] (j = reg >> 2, e = reg & 3): four runs of four consecutive
+// columns per lane; the SwiGLU partner of a gate row (j even) is reg + 4 of the same lane.
+template <typename T, int EPI, int MTW, int NS>
+__global__ __launch_bounds__(512) void gemm8_256x_k(GemmArgs a) {
+    constexpr int XS = 2 * MTW, XPW = (XS + 7) / 8;
+    constexpr int LPS = 2 + XPW;
+    constexpr int SUB = 16 + XS, BM = XS * 16, MT32 = MTW / 2;
+    static_assert(MT32 >= LPS, "one LDS-DMA piece behind every row-tile pair");
+    extern __shared__ __attribute__((aligned(16))) u4 lds[];
+    const int MB = (a.M + BM - 1) / BM, NB = (a.N + 255) / 256;
+    const int nwg = MB * NB;
+    int tile;
+    {
+        const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, rr = nwg & 7;
+        tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
+    }
+    const int bn = tile / MB, bm = tile - bn * MB;
+    const int M0 = bm * BM, N0 = bn * 256;
+    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int h = lane >> 5, r32 = lane & 31, t2 = (lane >> 4) & 1;
+    const int wm = w >> 2, wn = w & 3;
+    const int KC = a.K >> 6, NT16 = (a.N + 15) >> 4;
+    const int nsteps = KC;
+    const unsigned char* X8 = reinterpret_cast<const unsigned char*>(a.X);
+    const u4* Wp = reinterpret_cast<const u4*>(a.W8) + lane;
+
+    const u4* wsrc[2];
+    const unsigned char* xsrc[XPW];
+    int xst[XPW];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wsrc[j] = Wp + (size_t)min((N0 >> 4) + w * 2 + j, NT16 - 1) * KC * 64;
+#pragma unroll
+    for (int j = 0; j < XPW; ++j) {
+        xst[j] = min(w * XPW + j, XS - 1);
+        xsrc[j] = X8 + (size_t)min(M0 + xst[j] * 16 + r, a.M - 1) * a.ldx + g * 16;
+    }
+    auto stage1 = [&](int s, int slot, int j) {
+        u4* base = lds + (size_t)slot * SUB * 64;
+        if (j < 2) __builtin_amdgcn_global_load_lds((gptr8_t)(wsrc[j] + (size_t)s * 64), (lptr8_t)(base + (w * 2 + j) * 64), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gptr8_t)(xsrc[j - 2] + (size_t)s * 64), (lptr8_t)(base + (16 + xst[j - 2]) * 64), 16, 0, 0);
+    };
+    auto stage = [&](int s, int slot) {
+#pragma unroll
+        for (int j = 0; j < LPS; ++j) stage1(s, slot, j);
+    };
+
+    v16f acc[2][MT32];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < MT32; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int G = a.xgroups > 0 ? a.xgroups : 1, NBK = KC >> 1;
+    int grp = 0, next_b = 2 * (NBK / G);
+    // this lane's two pieces of sub-tile pair p of a stage: u4 index (2 p + t2) * 64 + 32 h + (r32 & 15), and 16 further
+    const int lpos = t2 * 64 + 32 * h + r;
+
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) stage(min(p, nsteps - 1), p);
+    for (int s = 0; s < nsteps; ++s) {
+        // this wave's LPS loads of stage s have landed; the NS - 2 younger stages may still fly
+        if ((NS - 2) * LPS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if ((NS - 2) * LPS == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if ((NS - 2) * LPS == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int sn = min(s + NS - 1, nsteps - 1), slotn = (s + NS - 1) % NS;
+        if (s == next_b && grp + 1 < G) {
+#pragma unroll
+            for (int mt = 0; mt < MT32; ++mt) {
+                const int m = min(M0 + (wm * MT32 + mt) * 32 + r32, a.M - 1);
+                const float ratio = a.xscale[(size_t)m * G + grp] / a.xscale[(size_t)m * G + grp + 1];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[nt][mt][e] *= ratio;
+            }
+            ++grp; next_b = 2 * ((NBK * (grp + 1)) / G);
+        }
+        const u4* base = lds + (size_t)(s % NS) * SUB * 64;
+        v8i wf[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) { const u4 p0 = base[(wn * 4 + 2 * nt) * 64 + lpos], p1 = base[(wn * 4 + 2 * nt) * 64 + lpos + 16]; wf[nt] = pair8(p0, p1); }
+#pragma unroll
+        for (int mt = 0; mt < MT32; ++mt) {
+            const u4 x0 = base[(16 + wm * MTW + 2 * mt) * 64 + lpos], x1 = base[(16 + wm * MTW + 2 * mt) * 64 + lpos + 16];
+            const v8i xf = pair8(x0, x1);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[nt][mt] = mfma8_32(wf[nt], xf, acc[nt][mt]);
+            if (mt < LPS) { stage1(sn, slotn, mt); __builtin_amdgcn_sched_barrier(0); }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // epilogue: lane (h, r32) holds row m = .. + r32 and, per 32-column tile, the column runs 8 j + 4 h .. + 4 (j = 0 .. 3)
+#pragma unroll
+    for (int mt = 0; mt < MT32; ++mt) {
+        const int m = M0 + (wm * MT32 + mt) * 32 + r32;
+        const float sx = a.xscale[(size_t)min(m, a.M - 1) * G + (G - 1)];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int nb = N0 + (wn * 2 + nt) * 32;
+            if (EPI == EPI_SILU_MUL) {
+#pragma unroll
+                for (int tau = 0; tau < 2; ++tau) {               // 16-column tile: 8 gate rows (j = 2 tau), 8 up rows (j = 2 tau + 1)
+                    const int n = nb + 16 * tau + 4 * h;
+                    if (nb + 16 * tau >= a.N || m >= a.M) continue;
+                    const float4 sg = *reinterpret_cast<const float4*>(a.wscale + n), su = *reinterpret_cast<const float4*>(a.wscale + n + 8);
+                    const float sgv[4] = {sg.x, sg.y, sg.z, sg.w}, suv[4] = {su.x, su.y, su.z, su.w};
+                    typedef T T4 __attribute__((ext_vector_type(4)));
+                    T4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fromf<T>(swiglu<T>(acc[nt][mt][8 * tau + e] * sx * sgv[e], acc[nt][mt][8 * tau + 4 + e] * sx * suv[e]));
+                    const int oc = (nb >> 1) + 8 * tau + 4 * h;
+                    *reinterpret_cast<T4*>(reinterpret_cast<T*>(a.out) + (size_t)m * a.ldo + oc) = o;
+                }
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = nb + 8 * j + 4 * h;
+                if (nb + 16 * (j >> 1) >= a.N || m >= a.M) continue;
+                const float4 sw = *reinterpret_cast<const float4*>(a.wscale + n);
+                float v[4] = {acc[nt][mt][4 * j] * sx * sw.x, acc[nt][mt][4 * j + 1] * sx * sw.y, acc[nt][mt][4 * j + 2] * sx * sw.z, acc[nt][mt][4 * j + 3] * sx * sw.w};
+                store4_8<T, EPI>(a, m, n, v);
+            }
+        }
+    }
+}
+
 bool gemm8_supported(const GemmArgs& a, int epi) {
     const int G = a.xgroups > 0 ? a.xgroups : 1;
     return a.W8 && a.wscale && a.xscale && a.K % 128 == 0 && a.K / 128 >= G && G <= 4 && a.N % 16 == 0 && a.ldx % 16 == 0 && a.M >= 1 && !a.bias &&
@@ -301,6 +451,21 @@ static void launch_gemm8_epi(const GemmArgs& a, hipStream_t s) {
             hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G8B_NS * 32 * 64 * 16);
             hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, G8B_NS * 36 * 64 * 16);
             attr = true;
+        }
+        static int mx = -1;
+        if (mx < 0) { const char* e = getenv("RDX_GEMM8_MX"); mx = e ? atoi(e) : 4; }
+        if (mx) {
+            static bool attrx = false;
+            if (!attrx) {
+                hipFuncSetAttribute((const void*)gemm8_256x_k<T, EPI, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 64 * 16);
+                hipFuncSetAttribute((const void*)gemm8_256x_k<T, EPI, 8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32 * 64 * 16);
+                hipFuncSetAttribute((const void*)gemm8_256x_k<T, EPI, 10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 36 * 64 * 16);
+                attrx = true;
+            }
+            if (c320 * 115 < c256 * 100 && mx != 6) hipLaunchKernelGGL((gemm8_256x_k<T, EPI, 10, 4>), dim3(MB3 * NB2), dim3(512), (size_t)4 * 36 * 64 * 16, s, a);
+            else if (mx >= 5) hipLaunchKernelGGL((gemm8_256x_k<T, EPI, 8, 5>), dim3(MB2 * NB2), dim3(512), (size_t)5 * 32 * 64 * 16, s, a);   // 160 KiB
+            else hipLaunchKernelGGL((gemm8_256x_k<T, EPI, 8, 4>), dim3(MB2 * NB2), dim3(512), (size_t)4 * 32 * 64 * 16, s, a);
+            return;
         }
         if (c320 * 115 < c256 * 100) hipLaunchKernelGGL((gemm8_256_k<T, EPI, 10>), dim3(MB3 * NB2), dim3(512), (size_t)G8B_NS * 36 * 64 * 16, s, a);   // 144 KiB
         else hipLaunchKernelGGL((gemm8_256_k<T, EPI, 8>), dim3(MB2 * NB2), dim3(512), (size_t)G8B_NS * 32 * 64 * 16, s, a);                              // 128 KiB
