@@ -382,16 +382,19 @@ __global__ __launch_bounds__(512) void gemm8_256x_k(GemmArgs a) {
             ++grp; next_b = 2 * ((NBK * (grp + 1)) / G);
         }
         const u4* base = lds + (size_t)(s % NS) * SUB * 64;
-        v8i wf[2];
+        v8i wf[2], xf[MT32];
+        auto readx = [&](int mt) { const u4 x0 = base[(16 + wm * MTW + 2 * mt) * 64 + lpos], x1 = base[(16 + wm * MTW + 2 * mt) * 64 + lpos + 16]; xf[mt] = pair8(x0, x1); };
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) { const u4 p0 = base[(wn * 4 + 2 * nt) * 64 + lpos], p1 = base[(wn * 4 + 2 * nt) * 64 + lpos + 16]; wf[nt] = pair8(p0, p1); }
+        readx(0);
 #pragma unroll
         for (int mt = 0; mt < MT32; ++mt) {
-            const u4 x0 = base[(16 + wm * MTW + 2 * mt) * 64 + lpos], x1 = base[(16 + wm * MTW + 2 * mt) * 64 + lpos + 16];
-            const v8i xf = pair8(x0, x1);
+            if (mt + 1 < MT32) readx(mt + 1);                            // the next row-tile pair's fragment is on its way while this one multiplies
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[nt][mt] = mfma8_32(wf[nt], xf, acc[nt][mt]);
-            if (mt < LPS) { stage1(sn, slotn, mt); __builtin_amdgcn_sched_barrier(0); }
+            for (int nt = 0; nt < 2; ++nt) acc[nt][mt] = mfma8_32(wf[nt], xf[mt], acc[nt][mt]);
+            if (mt < LPS) stage1(sn, slotn, mt);
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
