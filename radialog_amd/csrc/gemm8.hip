@@ -2,7 +2,7 @@
 //
 // Weights: OCP e4m3, one absmax / 448 scale per output row, stored in the 64-deep fragment order [n_tile16][k_chunk64][lane (g, r)][16]
 // (gemm.hip: pack_weight_fp8_k) -- lane (g, r) holds W[16 nt + r][64 kc + 16 g .. + 16]: one 16-byte piece feeds TWO
-// v_mfma_f32_16x16x32_fp8_fp8 (bytes 0..7 and 8..15). Activations: e4m3 row-major [M][K], quantised per row and per K GROUP
+// 32-deep MFMA steps (bytes 0..7 and 8..15), or half of a K = 128 / one quarter-K operand of the 32 x 32 x 64 shape. Activations: e4m3 row-major [M][K], quantised per row and per K GROUP
 // (`xgroups` ranges of K: group q = 128-deep blocks [NB q / G, NB (q + 1) / G), NB = K / 128; 1 for the projections behind an RMSNorm, 2 for o_proj, 4 for down_proj -- the
 // ranges one workgroup of the batch 3-32 K-split decode kernels holds, xstat32.hip, so that one rule describes prefill and decode),
 // scale = absmax / 448 in fp32 [M][xgroups] (elem.hip: quant_rows_k, rmsnorm -> fp8). The LoRA-B product and every other epilogue
@@ -15,8 +15,10 @@
 //   gemm8_k      128 x 128 block, 4 waves (2 x 2), BK = 128 per step (32 KiB staged: 16 + 16 pieces of 1 KiB), two LDS buffers, counted
 //                vmcnt + raw s_barrier; any M, N % 16 == 0, K % 128 == 0;
 //   gemm8_256_k  256 (or 320) x 256 block, 8 waves (2 x 4), one 64-deep chunk per stage, four-stage ring (M >= 1024 and >= 256 blocks).
-// gemm8_k issues v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (K = 128 per instruction, twice the bf16 MFMA rate; the K groups are
-// whole 128-deep blocks, so a step never straddles a boundary), gemm8_256_k v_mfma_f32_16x16x32_fp8_fp8 (see there).
+// Both issue the K = 128-rate f8f6f4 instructions (twice the bf16 MFMA rate; v_mfma_f32_16x16x32_fp8_fp8 runs at the bf16 rate) with block scales 2^0:
+// gemm8_k v_mfma_f32_16x16x128_f8f6f4 (a step is two chunks; the K groups are whole 128-deep blocks, so a step never straddles a boundary),
+// gemm8_256_k v_mfma_f32_32x32x64_f8f6f4 (one chunk per MFMA; see there). Constant-zero scale operands of the builtin select the encoding WITHOUT
+// v_mfma_ld_scale_b32 -- hardware scale 1.0 (checked against the fake-quantised fp32 reference, tests/test_gpu_gemm.py) and 5 % faster than loading 0x7F.
 // Epilogues: NONE, RESID (out = resid + T(v)), SILU_MUL (gate / up rows interleaved 8 + 8 per tile).
 #include <algorithm>
 #include <stdlib.h>
@@ -30,14 +32,6 @@ namespace rdx {
 typedef __attribute__((address_space(1))) const void* gptr8_t;
 typedef __attribute__((address_space(3))) void* lptr8_t;
 
-// one 16-byte piece of each operand = two v_mfma_f32_16x16x32_fp8_fp8 (bytes 0..7 and 8..15 of every lane)
-__device__ __forceinline__ v4f mfma8(const u4& a, const u4& b, v4f c) {
-    const long a0 = (long)(((unsigned long long)a.y << 32) | a.x), a1 = (long)(((unsigned long long)a.w << 32) | a.z);
-    const long b0 = (long)(((unsigned long long)b.y << 32) | b.x), b1 = (long)(((unsigned long long)b.w << 32) | b.z);
-    c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, c, 0, 0, 0);
-    return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, c, 0, 0, 0);
-}
-
 // Two consecutive 64-deep pieces of each operand at once on the block-scaled instruction v_mfma_scale_f32_16x16x128_f8f6f4 (formats e4m3 x e4m3,
 // every E8M0 block scale = 2^0): one MFMA of K = 128 at TWICE the bf16 rate (MI355X_MICROARCH.md: the non-scaled fp8 16x16x32 runs at the
 // bf16 rate). It is a dot product over its 128 k slots, so ANY slot <-> k assignment is valid as long as both operands use the same one:
@@ -47,20 +41,14 @@ __device__ __forceinline__ v8i pair8(const u4& p0, const u4& p1) {
     return (v8i){(int)p0.x, (int)p0.y, (int)p0.z, (int)p0.w, (int)p1.x, (int)p1.y, (int)p1.z, (int)p1.w};
 }
 __device__ __forceinline__ v4f mfma8x2(const v8i& a, const v8i& b, v4f c) {
-    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
 }
 
 // The same instruction family in its 32 x 32 x 64 shape: ONE 64-deep chunk of a 32-row tile pair per operand (lane (h, r32) = row r32 of the pair, its two
 // 16-byte pieces g = 2 h and 2 h + 1, i.e. k = 32 h .. + 32 of the chunk), 16 fp32 results per lane -- the K = 128 rate on single-chunk stages.
 typedef float v16f __attribute__((ext_vector_type(16)));
-typedef long v4l __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v8i pair8l(const u4& p0, const u4& p1) {
-    const long a0 = (long)(((unsigned long long)p0.y << 32) | p0.x), a1 = (long)(((unsigned long long)p0.w << 32) | p0.z);
-    const long b0 = (long)(((unsigned long long)p1.y << 32) | p1.x), b1 = (long)(((unsigned long long)p1.w << 32) | p1.z);
-    return __builtin_bit_cast(v8i, (v4l){a0, a1, b0, b1});
-}
 __device__ __forceinline__ v16f mfma8_32(const v8i& a, const v8i& b, v16f c) {
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
 }
 
 // 4 consecutive columns n .. n + 3 of row m: v already carries both scales
@@ -128,6 +116,7 @@ __device__ __forceinline__ void regroup8(const GemmArgs& a, v4f (&acc)[NTW][MTW]
 }
 
 constexpr int G8_BM = 128, G8_BN = 128;
+constexpr int G8B_NS = 4;                         // LDS ring of the 256-row kernel (a fifth stage, 160 KiB, measured no faster)
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void gemm8_k(GemmArgs a) {
@@ -207,107 +196,28 @@ __global__ __launch_bounds__(256) void gemm8_k(GemmArgs a) {
     epilogue8<T, EPI, 4, 4>(a, acc, M0, N0, wm, wn, r, g);
 }
 
-// ---- 256 x 256 block (the batched prefill: M = 5120) ---------------------------------------------------------------------------------
-// 8 waves as 2 x 4 with 128 x 64 wave tiles; a STEP is a pair of 64-deep chunks (K = 128: 64 KiB staged, 16 + 16 pieces per chunk), two LDS
-// buffers; per step a wave reads 8 weight and 16 activation pieces and issues 32 K = 128 MFMAs. The next step's 8 LDS-DMA pieces per wave are
-// issued one by one behind the MFMAs of this step (they cost 60-185 cycles of issue each, gemm_dma256_k).
-// 256 x 256 block (the batched prefill), 8 waves as 2 x 4 with 128 x 64 wave tiles: gemm_dma256_k's four-stage ring of 32-KiB stages, a stage
-// being ONE 64-deep e4m3 chunk (16 + XS pieces) -- twice the K of a bf16 stage for the same bytes -- multiplied with v_mfma_f32_16x16x32_fp8_fp8.
-// (Round 3 also built it as K = 128 steps on the block-scaled instruction: two 64-KiB buffers are all the LDS holds then, one step of DMA lead
-// instead of three stages, and it measured SLOWER -- gate/up at M = 5120 766 us against 652 us, bf16 865 us)
-// MTW row tiles per wave: 8 (256-row blocks) or 10 (320-row blocks: taken when they save a round of workgroups on the 256 CUs -- the N = 4096
-// projections at M = 5120 are 320 blocks of 256 rows but 256 of 320, like gemm_dma256_k's 320-row variant).
-constexpr int G8B_NS = 4;
-
-template <typename T, int EPI, int MTW>
-__global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
-    constexpr int XS = 2 * MTW, XPW = (XS + 7) / 8;                     // activation sub-tiles per stage; staged per wave (the last waves re-stage sub-tile XS - 1)
-    constexpr int LPS = 2 + XPW;                                        // LDS-DMA pieces per wave per stage
-    constexpr int SUB = 16 + XS, BM = XS * 16;
-    extern __shared__ __attribute__((aligned(16))) u4 lds[];          // [stage 4][W 16 | X XS][lane 64]
-    const int MB = (a.M + BM - 1) / BM, NB = (a.N + 255) / 256;
-    const int nwg = MB * NB;
-    int tile;
-    {
-        const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, rr = nwg & 7;
-        tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
-    }
-    const int bn = tile / MB, bm = tile - bn * MB;
-    const int M0 = bm * BM, N0 = bn * 256;
-    const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int r = lane & 15, g = lane >> 4;
-    const int wm = w >> 2, wn = w & 3;
-    const int KC = a.K >> 6, NT16 = (a.N + 15) >> 4;
-    const int nsteps = KC;                                              // one 64-deep chunk per stage
-    const unsigned char* X8 = reinterpret_cast<const unsigned char*>(a.X);
-    const u4* Wp = reinterpret_cast<const u4*>(a.W8) + lane;
-
-    const u4* wsrc[2];
-    const unsigned char* xsrc[XPW];
-    int xst[XPW];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) wsrc[j] = Wp + (size_t)min((N0 >> 4) + w * 2 + j, NT16 - 1) * KC * 64;
-#pragma unroll
-    for (int j = 0; j < XPW; ++j) {
-        xst[j] = min(w * XPW + j, XS - 1);
-        xsrc[j] = X8 + (size_t)min(M0 + xst[j] * 16 + r, a.M - 1) * a.ldx + g * 16;
-    }
-    auto stage1 = [&](int s, int slot, int j) {                         // piece j of this wave's LPS pieces of stage s (j compile-time at every call)
-        u4* base = lds + (size_t)slot * SUB * 64;
-        if (j < 2) __builtin_amdgcn_global_load_lds((gptr8_t)(wsrc[j] + (size_t)s * 64), (lptr8_t)(base + (w * 2 + j) * 64), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds((gptr8_t)(xsrc[j - 2] + (size_t)s * 64), (lptr8_t)(base + (16 + xst[j - 2]) * 64), 16, 0, 0);
-    };
-    auto stage = [&](int s, int slot) {
-#pragma unroll
-        for (int j = 0; j < LPS; ++j) stage1(s, slot, j);
-    };
-
-    v4f acc[4][MTW];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < MTW; ++j) acc[i][j] = (v4f){0.f, 0.f, 0.f, 0.f};
-    const int G = a.xgroups > 0 ? a.xgroups : 1, NBK = KC >> 1;        // K groups are whole 128-deep blocks = pairs of stages
-    int grp = 0, next_b = 2 * (NBK / G);
-
-#pragma unroll
-    for (int p = 0; p < G8B_NS - 1; ++p) stage(min(p, nsteps - 1), p);   // stages 0..2 in flight
-    for (int s = 0; s < nsteps; ++s) {
-        if (LPS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); // this wave's loads of stage s have landed (two younger stages may fly)
-        else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                   // ... everyone's have, and everyone finished stage s - 1
-        const int sn = min(s + G8B_NS - 1, nsteps - 1), slotn = (s + G8B_NS - 1) % G8B_NS;
-        if (s == next_b && grp + 1 < G) { regroup8<4, MTW>(a, acc, M0, wm, r, grp); ++grp; next_b = 2 * ((NBK * (grp + 1)) / G); }
-        const u4* base = lds + (size_t)(s % G8B_NS) * SUB * 64;
-        u4 wf[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wf[nt] = base[(wn * 4 + nt) * 64 + lane];
-#pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
-            const u4 xf = base[(16 + wm * MTW + mt) * 64 + lane];
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma8(wf[nt], xf, acc[nt][mt]);
-            // stage s + 3 goes into the slot stage s - 1 was read from; its LDS-DMA pieces one by one behind the MFMAs of row tiles 1, 3, 5, ...
-            if ((mt & 1) == 1 && (mt >> 1) < LPS) { stage1(sn, slotn, mt >> 1); __builtin_amdgcn_sched_barrier(0); }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // LDS reads of this stage are done before the next barrier
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    epilogue8<T, EPI, 4, MTW>(a, acc, M0, N0, wm, wn, r, g);
-}
-
-// ---- the same block on the block-scaled instruction in its 32 x 32 x 64 shape (round 4) ---------------------------------------------------
-// Ring, staging and LDS layout are gemm8_256_k's ([stage][W 16 | X XS sub-tiles][lane (g, r)][16 bytes]); a wave's 128 (160) x 64 tile is 4 (5) x 2
-// tiles of 32 x 32: lane (h, r32) reads row r32 of a sub-tile PAIR -- pieces g = 2 h, 2 h + 1 of sub-tile 2 t + (r32 >> 4) -- so one 64-deep stage
-// is one MFMA per tile at twice the 16x16x32 rate and no stage ever waits for its neighbour (the K = 128 shape needs two resident stages per
-// MFMA: half the DMA lead, measured slower in round 3). D[n = 8 j + 4 h + e][m = r32] (j = reg >> 2, e = reg & 3): four runs of four consecutive
+// ---- 256 (or 320) x 256 block: the batched prefill (M = 5120) ---------------------------------------------------------------------------------
+// 8 waves as 2 x 4 with 128 (160) x 64 wave tiles = 4 (5) x 2 tiles of 32 x 32 on v_mfma_f32_32x32x64_f8f6f4; gemm_dma256_k's four-stage LDS ring, a stage
+// being ONE 64-deep e4m3 chunk of both operands (32 / 36 KiB, [W 16 | X XS sub-tiles][lane (g, r)][16 bytes]). Lane (h, r32) reads row r32 of a sub-tile
+// PAIR -- pieces g = 2 h, 2 h + 1 of sub-tile 2 t + (r32 >> 4) -- so one stage is one MFMA per tile and no MFMA needs two resident stages (the K = 128
+// shape does: half the DMA lead, measured slower in round 3). D[n = 8 j + 4 h + e][m = r32] (j = reg >> 2, e = reg & 3): four runs of four consecutive
 // columns per lane; the SwiGLU partner of a gate row (j even) is reg + 4 of the same lane.
+// Round 4 (tools/exp_fp8mx.sh, 32 x 160 tokens): the 16x16x32 fp8 kernel of round 3 took 662 us for gate/up (bf16: 865); this instruction 459; x fragments one
+// row-tile pair ahead 437; block scales as constant zeros (no ld_scale) 417 = 2.2 PFLOP/s = 44 % of the fp8 peak; prefill 50.7 -> 37.0 ms. Measured without gain:
+// a fifth ring stage (160 KiB), the barrier moved one stage ahead with the next stage's fragments read before it (the code below keeps that form: it needs
+// no register copies), all fragments of the next stage in registers before the barrier (128-row tiles), the XCD-compact tile order (halves the fabric
+// traffic, 1.75 -> 0.89 GB per gate/up launch, 3 % of time). Ablations: without the MFMAs the launch still takes 80 % of its time, without the LDS-DMA 87 %
+// (PMC: matrix pipe 47 % busy, no LDS bank conflicts, LDS array 18 % busy, waves parked 35 % / issue-stalled 38 %): neither pipe is the limit alone.
+// hipcc detail: an LDS read whose IR load carries no TBAA tag (fragments passed by reference into a helper) gets a conservative s_waitcnt vmcnt(0) in front
+// of it while LDS-DMA is in flight -- the ring collapses; loading the pieces BY VALUE (tagged loads) keeps the counted waits below the only ones.
+template <int MT32> struct Frag8 { v8i w[2]; v8i x[MT32]; };          // a wave's fragments of one stage: 2 + MT32 operands of 32 bytes per lane
+
 template <typename T, int EPI, int MTW, int NS>
-__global__ __launch_bounds__(512) void gemm8_256x_k(GemmArgs a) {
+__global__ __launch_bounds__(512) void gemm8_256_k(GemmArgs a) {
     constexpr int XS = 2 * MTW, XPW = (XS + 7) / 8;
     constexpr int LPS = 2 + XPW;
     constexpr int SUB = 16 + XS, BM = XS * 16, MT32 = MTW / 2;
-    static_assert(MT32 >= LPS, "one LDS-DMA piece behind every row-tile pair");
+    static_assert(MT32 >= LPS && NS >= 3, "one LDS-DMA piece behind every row-tile pair");
     extern __shared__ __attribute__((aligned(16))) u4 lds[];
     const int MB = (a.M + BM - 1) / BM, NB = (a.N + 255) / 256;
     const int nwg = MB * NB;
@@ -316,7 +226,11 @@ __global__ __launch_bounds__(512) void gemm8_256x_k(GemmArgs a) {
         const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, rr = nwg & 7;
         tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
     }
-    const int bn = tile / MB, bm = tile - bn * MB;
+    // The 32 workgroups an XCD runs at a time (consecutive `tile`s) form 4 row blocks x 8 column blocks: 12 operand panels per stage for 32 workgroups in
+    // its L2 instead of the 22 of a 20 x 1.6 strip. Bands of 8 column blocks, inside a band groups of 4 row blocks, column-major inside a group.
+    const int band = tile / (MB * 8), idx = tile - band * MB * 8, wdt = min(8, NB - band * 8);
+    const int gq = idx / (4 * wdt), gh = min(4, MB - gq * 4), rem = idx - gq * 4 * wdt;
+    const int bn = band * 8 + rem / gh, bm = gq * 4 + rem % gh;
     const int M0 = bm * BM, N0 = bn * 256;
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -359,45 +273,75 @@ __global__ __launch_bounds__(512) void gemm8_256x_k(GemmArgs a) {
     // this lane's two pieces of sub-tile pair p of a stage: u4 index (2 p + t2) * 64 + 32 h + (r32 & 15), and 16 further
     const int lpos = t2 * 64 + 32 * h + r;
 
-#pragma unroll
-    for (int p = 0; p < NS - 1; ++p) stage(min(p, nsteps - 1), p);
-    for (int s = 0; s < nsteps; ++s) {
-        // this wave's LPS loads of stage s have landed; the NS - 2 younger stages may still fly
-        if ((NS - 2) * LPS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if ((NS - 2) * LPS == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if ((NS - 2) * LPS == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int sn = min(s + NS - 1, nsteps - 1), slotn = (s + NS - 1) % NS;
-        if (s == next_b && grp + 1 < G) {
-#pragma unroll
-            for (int mt = 0; mt < MT32; ++mt) {
-                const int m = min(M0 + (wm * MT32 + mt) * 32 + r32, a.M - 1);
-                const float ratio = a.xscale[(size_t)m * G + grp] / a.xscale[(size_t)m * G + grp + 1];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) acc[nt][mt][e] *= ratio;
-            }
-            ++grp; next_b = 2 * ((NBK * (grp + 1)) / G);
-        }
-        const u4* base = lds + (size_t)(s % NS) * SUB * 64;
-        v8i wf[2], xf[MT32];
-        auto readx = [&](int mt) { const u4 x0 = base[(16 + wm * MTW + 2 * mt) * 64 + lpos], x1 = base[(16 + wm * MTW + 2 * mt) * 64 + lpos + 16]; xf[mt] = pair8(x0, x1); };
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) { const u4 p0 = base[(wn * 4 + 2 * nt) * 64 + lpos], p1 = base[(wn * 4 + 2 * nt) * 64 + lpos + 16]; wf[nt] = pair8(p0, p1); }
-        readx(0);
+    // Pipeline: the barrier of iteration s publishes stage s + 1 (and retires stage s - 1, whose slot takes stage s + NS - 1), so the first fragments of
+    // stage s + 1 are read behind the last MFMAs of stage s -- no wave ever sits behind a barrier with empty fragment registers.
+    auto wait_stage = [&](int younger) {                                 // this wave's loads of all but the `younger` youngest stages have landed
+        if (younger * LPS == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger * LPS == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (younger * LPS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (younger * LPS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (younger * LPS == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    };
+    auto regroup = [&]() {                                                // acc *= sx[m][grp] / sx[m][grp + 1] at a K-group boundary
 #pragma unroll
         for (int mt = 0; mt < MT32; ++mt) {
-            if (mt + 1 < MT32) readx(mt + 1);                            // the next row-tile pair's fragment is on its way while this one multiplies
-            __builtin_amdgcn_sched_barrier(0);
+            const int m = min(M0 + (wm * MT32 + mt) * 32 + r32, a.M - 1);
+            const float ratio = a.xscale[(size_t)m * G + grp] / a.xscale[(size_t)m * G + grp + 1];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[nt][mt] = mfma8_32(wf[nt], xf[mt], acc[nt][mt]);
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[nt][mt][e] *= ratio;
+        }
+        ++grp; next_b = 2 * ((NBK * (grp + 1)) / G);
+    };
+    typedef Frag8<MT32> Frag;
+    auto read_w = [&](Frag& f, const u4* base) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) { const u4 p0 = base[(wn * 4 + 2 * nt) * 64 + lpos], p1 = base[(wn * 4 + 2 * nt) * 64 + lpos + 16]; f.w[nt] = pair8(p0, p1); }
+    };
+    auto read_x = [&](Frag& f, const u4* base, int mt) {
+        const u4 q0 = base[(16 + wm * MTW + 2 * mt) * 64 + lpos], q1 = base[(16 + wm * MTW + 2 * mt) * 64 + lpos + 16];
+        f.x[mt] = pair8(q0, q1);
+    };
+    // PF = row-tile pairs whose fragments cross the barrier in registers (the rest is read inside the stage, one pair ahead of its MFMAs): all of them
+    // when the registers allow (128-row wave tiles: 2 x 48 fragment + 128 accumulator registers), one for the 160-row tiles.
+    constexpr int PF = MTW == 8 ? MT32 : 1;
+    auto step = [&](int s, Frag& cur, Frag& nxt) {
+        wait_stage(NS - 3);                                              // stage s + 1 (this wave's pieces)
+        __builtin_amdgcn_s_barrier();
+        const int sn = min(s + NS - 1, nsteps - 1), slotn = (s + NS - 1) % NS;
+        if (s == next_b && grp + 1 < G) regroup();
+        const u4* base = lds + (size_t)(s % NS) * SUB * 64;
+        const u4* basen = lds + (size_t)((s + 1) % NS) * SUB * 64;
+#pragma unroll
+        for (int mt = 0; mt < MT32; ++mt) {
+            if (PF < MT32 && mt >= PF - 1 && mt + 1 < MT32) read_x(cur, base, mt + 1);
+            if (PF < MT32 && mt == MT32 - 1) { read_w(nxt, basen);
+#pragma unroll
+                for (int q = 0; q < PF; ++q) read_x(nxt, basen, q); }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][mt] = mfma8_32(cur.w[0], cur.x[mt], acc[0][mt]);
+            acc[1][mt] = mfma8_32(cur.w[1], cur.x[mt], acc[1][mt]);
+            if (PF == MT32 && mt == 0) {                                 // the whole next stage goes in flight under this stage's remaining MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                read_w(nxt, basen);
+#pragma unroll
+                for (int q = 0; q < MT32; ++q) read_x(nxt, basen, q);
+            }
             if (mt < LPS) stage1(sn, slotn, mt);
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
+    };
+    Frag fa, fb;
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) stage(min(p, nsteps - 1), p);
+    wait_stage(NS - 2);
+    __builtin_amdgcn_s_barrier();
+    read_w(fa, lds);
+#pragma unroll
+    for (int q = 0; q < PF; ++q) read_x(fa, lds, q);
+    for (int s = 0; s < nsteps; s += 2) { step(s, fa, fb); step(s + 1, fb, fa); }   // K % 128 == 0: an even number of stages
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // epilogue: lane (h, r32) holds row m = .. + r32 and, per 32-column tile, the column runs 8 j + 4 h .. + 4 (j = 0 .. 3)
@@ -449,29 +393,15 @@ static void launch_gemm8_epi(const GemmArgs& a, hipStream_t s) {
         // 320-row blocks when they save rounds on the 256 CUs (cost = rounds x rows per block, 15 % handicap for the bigger tile, as gemm_dma256_k)
         const int MB3 = (a.M + 319) / 320;
         const long c256 = (long)((MB2 * NB2 + 255) / 256) * 256, c320 = (long)((MB3 * NB2 + 255) / 256) * 320;
+        constexpr size_t sm8 = (size_t)G8B_NS * 32 * 64 * 16, sm10 = (size_t)G8B_NS * 36 * 64 * 16;   // 128 / 144 KiB
         static bool attr = false;
         if (!attr) {
-            hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, G8B_NS * 32 * 64 * 16);
-            hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, G8B_NS * 36 * 64 * 16);
+            (void)hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 8, G8B_NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm8);
+            (void)hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 10, G8B_NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm10);
             attr = true;
         }
-        static int mx = -1;
-        if (mx < 0) { const char* e = getenv("RDX_GEMM8_MX"); mx = e ? atoi(e) : 4; }
-        if (mx) {
-            static bool attrx = false;
-            if (!attrx) {
-                hipFuncSetAttribute((const void*)gemm8_256x_k<T, EPI, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 64 * 16);
-                hipFuncSetAttribute((const void*)gemm8_256x_k<T, EPI, 8, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 32 * 64 * 16);
-                hipFuncSetAttribute((const void*)gemm8_256x_k<T, EPI, 10, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 36 * 64 * 16);
-                attrx = true;
-            }
-            if (c320 * 115 < c256 * 100 && mx != 6) hipLaunchKernelGGL((gemm8_256x_k<T, EPI, 10, 4>), dim3(MB3 * NB2), dim3(512), (size_t)4 * 36 * 64 * 16, s, a);
-            else if (mx >= 5) hipLaunchKernelGGL((gemm8_256x_k<T, EPI, 8, 5>), dim3(MB2 * NB2), dim3(512), (size_t)5 * 32 * 64 * 16, s, a);   // 160 KiB
-            else hipLaunchKernelGGL((gemm8_256x_k<T, EPI, 8, 4>), dim3(MB2 * NB2), dim3(512), (size_t)4 * 32 * 64 * 16, s, a);
-            return;
-        }
-        if (c320 * 115 < c256 * 100) hipLaunchKernelGGL((gemm8_256_k<T, EPI, 10>), dim3(MB3 * NB2), dim3(512), (size_t)G8B_NS * 36 * 64 * 16, s, a);   // 144 KiB
-        else hipLaunchKernelGGL((gemm8_256_k<T, EPI, 8>), dim3(MB2 * NB2), dim3(512), (size_t)G8B_NS * 32 * 64 * 16, s, a);                              // 128 KiB
+        if (c320 * 115 < c256 * 100) hipLaunchKernelGGL((gemm8_256_k<T, EPI, 10, G8B_NS>), dim3(MB3 * NB2), dim3(512), sm10, s, a);
+        else hipLaunchKernelGGL((gemm8_256_k<T, EPI, 8, G8B_NS>), dim3(MB2 * NB2), dim3(512), sm8, s, a);
         return;
     }
     const int MB = (a.M + G8_BM - 1) / G8_BM, NB = (a.N + G8_BN - 1) / G8_BN;

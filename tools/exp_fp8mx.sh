@@ -10,5 +10,5 @@ export TMPDIR=/tmp
 for mx in $MODES; do
   (cd /tmp && RDX_GEMM8_MX=$mx rocprofv3 --kernel-trace --stats -d /tmp/prof$mx -o p --output-format rocpd -- python $ROOT/tools/prefill_only.py 32 160 3 fp8 > /tmp/prof$mx.log 2>&1)
   db=$(find /tmp/prof$mx -name "*.db" | head -1)
-  python tools/prof_summary.py $db - 2>/dev/null | grep -i "gemm8\|kernel time" | head -10 > $OUT/kern_mx$mx.log
+  python tools/prof_summary.py $db - 2>/dev/null | head -24 > $OUT/kern_mx$mx.log
 done
