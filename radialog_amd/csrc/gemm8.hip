@@ -183,9 +183,15 @@ __global__ __launch_bounds__(256) void gemm8_k(GemmArgs a) {
         if (s == next_b && grp + 1 < G) { regroup8<4, 4>(a, acc, M0, wm, r, grp); ++grp; next_b = (nsteps * (grp + 1)) / G; }
         v8i wf[4], xf[4];                                             // a lane's pieces of both chunks of the step: one K = 128 operand
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) wf[nt] = pair8(base[((wn * 4 + nt) * 2 + 0) * 64 + lane], base[((wn * 4 + nt) * 2 + 1) * 64 + lane]);
+        for (int nt = 0; nt < 4; ++nt) {                              // pieces loaded BY VALUE (see gemm8_256_k: the hipcc vmcnt(0) trap)
+            const u4 p0 = base[((wn * 4 + nt) * 2 + 0) * 64 + lane], p1 = base[((wn * 4 + nt) * 2 + 1) * 64 + lane];
+            wf[nt] = pair8(p0, p1);
+        }
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) xf[mt] = pair8(base[(16 + (wm * 4 + mt) * 2 + 0) * 64 + lane], base[(16 + (wm * 4 + mt) * 2 + 1) * 64 + lane]);
+        for (int mt = 0; mt < 4; ++mt) {
+            const u4 p0 = base[(16 + (wm * 4 + mt) * 2 + 0) * 64 + lane], p1 = base[(16 + (wm * 4 + mt) * 2 + 1) * 64 + lane];
+            xf[mt] = pair8(p0, p1);
+        }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
