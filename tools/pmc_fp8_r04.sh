@@ -9,7 +9,7 @@ i=0
 for grp in $GROUPS_; do
   i=$((i+1)); tag=$(echo $grp | cut -d, -f1)${TAG:-}
   rm -rf /tmp/pmc8_$i
-  (cd /tmp && rocprofv3 --pmc $(echo $grp | tr ',' ' ') --kernel-trace -d /tmp/pmc8_$i -o pmc --output-format rocpd -- python $ROOT/tools/prefill_only.py 32 160 2 fp8 > /tmp/pmc8_$i.log 2>&1)
+  (cd /tmp && timeout 240 rocprofv3 --pmc $(echo $grp | tr ',' ' ') --kernel-trace -d /tmp/pmc8_$i -o pmc --output-format rocpd -- python $ROOT/tools/prefill_only.py 32 160 2 fp8 > /tmp/pmc8_$i.log 2>&1)
   db=$(find /tmp/pmc8_$i -name "*.db" 2>/dev/null | head -1)
   if [ -n "$db" ]; then python $ROOT/tools/pmc_summary.py $db gemm8_256 > $OUT/pmc8_$tag.txt 2>&1; else tail -8 /tmp/pmc8_$i.log > $OUT/pmc8_$tag.txt; fi
 done
