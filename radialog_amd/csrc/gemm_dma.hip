@@ -232,7 +232,12 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_k(GemmArgs a) {
         const int id = blockIdx.x, xcd = id & 7, q = nwg >> 3, rr = nwg & 7;
         tile = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (id >> 3);
     }
-    const int bn = tile / MB, bm = tile - bn * MB;
+    // the 32 workgroups an XCD runs at a time (consecutive `tile`s) form 4 row blocks x 8 column blocks: 12 operand panels per stage in its L2 instead of the
+    // 22 of a column strip (fabric traffic of a 5120 x 22016 x 4096 launch 1.75 -> 0.89 GB in the fp8 twin, gemm8.hip). Bands of 8 column blocks, groups of 4
+    // row blocks inside a band, column-major inside a group.
+    const int band = tile / (MB * 8), idx = tile - band * MB * 8, wdt = min(8, NB - band * 8);
+    const int gq = idx / (4 * wdt), gh = min(4, MB - gq * 4), rem = idx - gq * 4 * wdt;
+    const int bn = band * 8 + rem / gh, bm = gq * 4 + rem % gh;
     const int M0 = bm * G2_BM, N0 = bn * G2_BN;
     const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -287,12 +292,16 @@ __global__ __launch_bounds__(512, 2) void gemm_dma256_k(GemmArgs a) {
         V8 wf[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) wf[nt] = as_vec8<T>(base[(wn * 4 + nt) * 64 + lane]);
+        V8 xf[MTW];
+        xf[0] = as_vec8<T>(base[(16 + wm * MTW) * 64 + lane]);
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
-            const V8 xf = as_vec8<T>(base[(16 + wm * MTW + mt) * 64 + lane]);
+            if (mt + 1 < MTW) xf[mt + 1] = as_vec8<T>(base[(16 + wm * MTW + mt + 1) * 64 + lane]);   // the next row tile's fragment is on its way under these MFMAs
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma16(wf[nt], xf, acc[nt][mt]);
-            if (spread && (mt & 1) == 1 && (mt >> 1) < LPS) { stage1(sn, slotn, mt >> 1); __builtin_amdgcn_sched_barrier(0); }
+            for (int nt = 0; nt < 4; ++nt) acc[nt][mt] = mfma16(wf[nt], xf[mt], acc[nt][mt]);
+            if (spread && (mt & 1) == 1 && (mt >> 1) < LPS) stage1(sn, slotn, mt >> 1);
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // LDS reads of this stage are done before the next barrier
     }
