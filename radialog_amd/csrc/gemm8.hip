@@ -212,8 +212,9 @@ __global__ __launch_bounds__(256) void gemm8_k(GemmArgs a) {
 // row-tile pair ahead 437; block scales as constant zeros (no ld_scale) 417 = 2.2 PFLOP/s = 44 % of the fp8 peak; prefill 50.7 -> 37.0 ms. Measured without gain:
 // a fifth ring stage (160 KiB), the barrier moved one stage ahead with the next stage's fragments read before it (the code below keeps that form: it needs
 // no register copies), all fragments of the next stage in registers before the barrier (128-row tiles), the XCD-compact tile order (halves the fabric
-// traffic, 1.75 -> 0.89 GB per gate/up launch, 3 % of time). Ablations: without the MFMAs the launch still takes 80 % of its time, without the LDS-DMA 87 %
-// (PMC: matrix pipe 47 % busy, no LDS bank conflicts, LDS array 18 % busy, waves parked 35 % / issue-stalled 38 %): neither pipe is the limit alone.
+// traffic, 1.75 -> 0.89 GB per gate/up launch, 3 % of time), a K-loop skew between workgroups, four waves of 128 x 128 (761 us). What bounds it: the LDS-DMA ring
+// with NOTHING else in the loop takes 366 of the 437 us (3.6 GB of operand requests per launch = 9.85 TB/s out of the L2s, 85 % hits); the matrix pipe is 47 % busy,
+// the LDS array 18 %, no bank conflicts (profiles/r04_fp8_prefill_mx.md).
 // hipcc detail: an LDS read whose IR load carries no TBAA tag (fragments passed by reference into a helper) gets a conservative s_waitcnt vmcnt(0) in front
 // of it while LDS-DMA is in flight -- the ring collapses; loading the pieces BY VALUE (tagged loads) keeps the counted waits below the only ones.
 template <int MT32> struct Frag8 { v8i w[2]; v8i x[MT32]; };          // a wave's fragments of one stage: 2 + MT32 operands of 32 bytes per lane
