@@ -574,7 +574,8 @@ def main():
     if B == 1 and not args.fp8 and not args.no_fp8:
         # BASELINE configs[4] per-GPU load: fp8 e4m3 decoder weights + per-row scale, LoRA epilogue, batch 32 per GPU
         subs["fp8_b32"] = (timed_run(32, True, k2, 1), f"configs[4]: fp8 e4m3 decoder GEMM weights + per-row scale + un-merged LoRA epilogue, per-GPU "
-                                                       f"batch 32 (global {32 * world})")
+                                                       f"batch 32 (global {32 * world}); no reference fp8 path exists -- its oracle is the reference math on the "
+                                                       "same fake-quantised operands (tests/test_gpu_parity.py), i.e. unpinnable against the reference itself")
 
     if rank == 0:
         r, roof = main_r, main_r["roof"]
