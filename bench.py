@@ -21,7 +21,7 @@ Rank 0 prints ONE JSON line. `value` = reports/s of the whole job with inputs re
                launch `decode_chain_k` (profiles/r03_bench_b1_kernel_stats.md), at batch 3-32 the gate/up SwiGLU `xstat32_k`:
                algorithmic bytes per launch / its average launch duration measured live with HIP events on the library's stream
                (rdx_time; the chained launch is bracketed in situ inside real decode steps); `traffic` = HBM bytes per launch
-               from the rocprofv3 PMC passes of this same command (profiles/r03_pmc.json; counters cannot be read in-process).
+               from the rocprofv3 PMC passes of this same command (profiles/r04_pmc.json; counters cannot be read in-process).
                Also the whole-step fractions and the MFMA-side fractions north_star targets (`mfma`: encode and prefill
                TFLOP/s over the 2.5 PFLOP/s dense bf16 peak).
   b32          (batch-1 runs) BASELINE configs[2] / [3] timed in the same process at every world size: per-GPU batch 32, hipGraph step.
@@ -107,13 +107,17 @@ def prefill_flops(lc, T, B):
 
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs of
-    this command, FETCH doubled per the gfx950 correction; profiles/r03_pmc_hbm_traffic.md, machine-readable twin r03_pmc.json).
-    Only for configurations that were profiled -> null otherwise."""
-    try:
-        with open(os.path.join(REPO, "profiles", "r03_pmc.json")) as f:
-            return json.load(f).get(kernel_key, {}).get("traffic_bytes")
-    except Exception:
-        return None
+    this command, FETCH doubled per the gfx950 correction; profiles/r04_pmc_hbm_traffic.md, machine-readable twin r04_pmc.json written by
+    tools/pmc_to_json.py; the round-3 file as a fallback). Only for configurations that were profiled -> null otherwise."""
+    for name in ("r04_pmc.json", "r03_pmc.json"):
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                v = json.load(f).get(kernel_key, {}).get("traffic_bytes")
+            if v is not None:
+                return v
+        except Exception:
+            continue
+    return None
 
 
 def _pick_threads():
