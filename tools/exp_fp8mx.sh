@@ -1,8 +1,9 @@
 #!/bin/bash
-# fp8 batched prefill: A/B of gemm8.hip variants selected by an environment variable (VAR, default RDX_GEMM8_W4) over MODES; TESTS=1 runs the fp8 GEMM unit
-# tests per mode. Output -> gpurun_out/fp8mx/ (fresh per call).
+# fp8 batched prefill A/B harness (round 4, profiles/r04_fp8_prefill_mx.md): for every value in MODES of the environment variable VAR -- a switch compiled into
+# gemm8.hip for the duration of an experiment; none is left in the tree -- the fp8 GEMM unit tests (TESTS=1), the 32 x 160 prefill wall time and the
+# rocprofv3 kernel table. Without VAR it measures the build as it is. Output -> gpurun_out/fp8mx/ (fresh per call).
 ROOT=$(pwd); export PYTHONPATH=$ROOT; OUT=$ROOT/gpurun_out/fp8mx; mkdir -p $OUT
-MODES=${MODES:-"0 1"}; VAR=${VAR:-RDX_GEMM8_W4}
+MODES=${MODES:-"0"}; VAR=${VAR:-RDX_EXPERIMENT}
 export TMPDIR=/tmp
 : > $OUT/test.log; : > $OUT/prefill.log
 for mx in $MODES; do
