@@ -176,7 +176,7 @@ def test_fp8_weights_have_no_kernel_for_odd_batch3_shapes(eng):
     (216, 512, 1408, 3, False, 11, 4), (50, 2832, 512, 4, True, 9, 1), (3, 528, 512, 0, True, 9, 1), (257, 144, 768, 0, False, 10, 2)])
 def test_fp8_x_fp8_gemm_matches_fake_quantised_fp32(eng, M, N, K, epi, norm, force, groups):
     """BASELINE configs[4]: e4m3 weights (one scale per output row) x e4m3 activations (one scale per row and K group) on
-    v_mfma_f32_16x16x32_fp8_fp8 -- prefill (gemm8.hip) and batch 3-32 decode (xstat32.hip). Reference = fp32 math on the fake-quantised
+    the fp8 MFMAs -- prefill (gemm8.hip: v_mfma_f32_32x32x64_f8f6f4 / 16x16x128) and batch 3-32 decode (xstat32.hip: v_mfma_f32_16x16x32_fp8_fp8). Reference = fp32 math on the fake-quantised
     operands. The quantisation grid makes the comparison discontinuous (an activation one model-dtype ulp away can land on the next
     e4m3 code, 6 % apart), so the bar is 2 x the model-dtype tolerance on the largest output, and at least 1.25e-2 x that behind an
     RMSNorm (whose output is where the two sides differ by an ulp)."""

@@ -349,7 +349,7 @@ def test_production_width_layers_match_oracle(B, fp8, layers, dtypes):
     HIP logits must be no further from the exactly-accumulated (fp64) evaluation of the same rounding points than the torch-CPU
     oracle is, up to a factor 2 (round 3: tightened from 3; measured ratios 0.7 ... 1.45. Cause: the MFMA pipeline's fp32 accumulation leaves ~1 % of the bf16-rounded K / V elements one ulp
 off the exact value where torch's CPU FMA chain leaves 0.03 %, tests/diag/mfma_round.py; the worst of 5 million logits then sits
-2-3 ulps out instead of 1). fp8 = BASELINE configs[4]: e4m3 weights everywhere, e4m3 activations on v_mfma_f32_16x16x32_fp8_fp8 in the
+2-3 ulps out instead of 1). fp8 = BASELINE configs[4]: e4m3 weights everywhere, e4m3 activations on the fp8 MFMAs (f8f6f4 shapes in the prefill, 16x16x32_fp8 in the decode) in the
 prefill (gemm8.hip) and from batch 3 in decode (xstat32.hip); the oracle runs the reference math on the same fake-quantised operands
 (LlamaOracle(fp8=True))."""
     from oracle import ref_cpu
