@@ -377,12 +377,33 @@ __global__ __launch_bounds__(256) void scramble_layernorm_k(const T* __restrict_
     const int rrow = blockIdx.x, b = blockIdx.y;
     const T* src = pp + (size_t)b * P * C;
     float s = 0.f;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const size_t f = (size_t)rrow * C + c;
-        const int ch = (int)(f / P), pos = (int)(f % P);
-        const float v = tof<T>(src[(size_t)pos * C + ch]);
-        rowbuf[c] = v;
-        s += v;
+    if ((C & 7) == 0) {
+        // the row's C elements are the flat range [rrow C, rrow C + C) of the [C][P] matrix: <= C / P + 2 channels x all P positions. Gathered as 16-byte
+        // pieces (8 channels of one position) instead of one 2-byte element per 64-byte sector (round 3 PMC: 227 MB fetched for an 18 MB input at batch 32);
+        // the sums below run over rowbuf in the order they always did, so the result is bit-identical.
+        typedef typename Vec8<T>::type V8;
+        const int f0 = rrow * C, ch_lo = (f0 / P) & ~7, ch_hi = (f0 + C - 1) / P;
+        const int nch8 = ((ch_hi - ch_lo) >> 3) + 1;
+        for (int it = threadIdx.x; it < P * nch8; it += blockDim.x) {
+            const int pos = it / nch8, ch8 = ch_lo + (it - pos * nch8) * 8;
+            if (ch8 >= C) continue;
+            const V8 v = as_vec8<T>(ldg16(src + (size_t)pos * C + ch8));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = (ch8 + j) * P + pos - f0;
+                if (c >= 0 && c < C) rowbuf[c] = tof<T>(v[j]);
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += blockDim.x) s += rowbuf[c];
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            const size_t f = (size_t)rrow * C + c;
+            const int ch = (int)(f / P), pos = (int)(f % P);
+            const float v = tof<T>(src[(size_t)pos * C + ch]);
+            rowbuf[c] = v;
+            s += v;
+        }
     }
     const float mean = block_sum(s, red) / (float)C;
     float v2 = 0.f;
