@@ -1,3 +1,5 @@
+#!/bin/bash
+# PMC pass over the batched prefill GEMMs (bf16 gemm_dma256_k, fp8 gemm8_256_k): matrix-pipe busy cycles -> profiles/r04_pmc_prefill_mfma.md. --kernel-trace only.
 export PYTHONPATH=$PWD TMPDIR=/tmp; mkdir -p gpurun_out/mf
 for mode in bf16 fp8; do
   extra=""; [ $mode = fp8 ] && extra="fp8"
