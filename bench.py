@@ -61,6 +61,8 @@ def parse(argv=None):
     ap.add_argument("--no-b32", action="store_true", help="skip the configs[2] (batch 32) sub-run of a batch-1 single-GPU bench")
     ap.add_argument("--no-fp8", action="store_true", help="skip the configs[4] (fp8 weights, batch 32) sub-run of a batch-1 bench")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-f16", action="store_true", help="skip the fp16 (the reference's dtype) timed run of a batch-1 bf16 bench (value_f16)")
+    ap.add_argument("--no-enc256", action="store_true", help="skip the batch-256 image-encode timing (enc_b256)")
     return ap.parse_args(argv)
 
 
@@ -105,16 +107,41 @@ def prefill_flops(lc, T, B):
     return B * (per_tok * T + attn + 2.0 * lc.vocab * H + 2.0 * 32 * lc.qformer_dim * H)
 
 
+PMC_FILES = ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json")
+
+
 def pmc_traffic(kernel_key):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in separate runs of
-    this command, FETCH doubled per the gfx950 correction; profiles/r04_pmc_hbm_traffic.md, machine-readable twin r04_pmc.json written by
-    tools/pmc_to_json.py; the round-3 file as a fallback). Only for configurations that were profiled -> null otherwise."""
-    for name in ("r04_pmc.json", "r03_pmc.json"):
+    this command, FETCH doubled per the gfx950 correction; profiles/rNN_pmc_hbm_traffic.md, machine-readable twin rNN_pmc.json written by
+    tools/pmc_to_json.py; newest round first). Only for configurations that were profiled -> null otherwise. The figure is a REPLAY of a
+    committed profile, not a measurement of this run (counters cannot be read in-process): pmc_source() says which file and whether the
+    kernel sources it was taken on are the ones running now."""
+    for name in PMC_FILES:
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 v = json.load(f).get(kernel_key, {}).get("traffic_bytes")
             if v is not None:
                 return v
+        except Exception:
+            continue
+    return None
+
+
+def pmc_source(kernel_key):
+    """{"file", "tree", "tree_now", "stale"} of the PMC file pmc_traffic(kernel_key) read: `tree` = radialog_amd.build.source_hash() of the
+    kernel sources the profile was taken on (stamped by tools/pmc_to_json.py from round 5; absent in older files -> stale = null)."""
+    from radialog_amd import build as _b
+    now = _b.source_hash()
+    for name in PMC_FILES:
+        try:
+            with open(os.path.join(REPO, "profiles", name)) as f:
+                d = json.load(f)
+            if d.get(kernel_key, {}).get("traffic_bytes") is not None:
+                tree = d.get("_tree")
+                # `algorithmic_bytes`: the algorithmic bytes per launch AT THE STATE THE PROFILE WAS TAKEN IN (e.g. the decode attention's
+                # context), so that traffic / algorithmic is meaningful even when this run prices the kernel at another context
+                return {"file": f"profiles/{name}", "tree": tree, "tree_now": now, "stale": None if tree is None else tree != now,
+                        "algorithmic_bytes": d[kernel_key].get("algorithmic_bytes"), "note": d[kernel_key].get("note")}
         except Exception:
             continue
     return None
@@ -160,7 +187,7 @@ def _oracle_decode(orc, ref_cpu, ids, q, n_tok):
     return toks, rows, t_prefill, (time.time() - t0) / max(n_tok - 1, 1)
 
 
-def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device, hip_tf=None):
+def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device, hip_tf=None, b32_tf=None, fp8_tf=None, e2e_tf=None):
     """BASELINE configs[0], for real: the CPU oracle encodes ONE 448 px image, prefills the 160-token prompt and decodes 32 greedy
     tokens through all 32 production-width layers on the host cores (the weights are the engine's: generated on the GPU tensor by
     tensor, rounded to the model dtype, copied to the host -- not part of the timed work). The metric is quoted on 256-token
@@ -190,13 +217,23 @@ def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device, hip_tf=None):
         specs = synth.llama_specs(cfg.llama, lora=True)
         ids = synth.synth_prompt_ids(1, prompt_len, vocab=cfg.llama.vocab)
 
-        def oracle_for(dn):
+        def oracle_for(dn, fp8=False):
             W = {name: gen(name, shape, device).to(DT[dn]).cpu() for name, (shape, gen) in specs.items()}
-            return ref_cpu.LlamaOracle(W, cfg.llama, DT[dn], lora=True)
+            o = ref_cpu.LlamaOracle(W, cfg.llama, DT[dn], lora=True)
+            if fp8:
+                # LlamaOracle(fp8=True) with the e4m3 values taken from the fp32 SOURCE tensors like the engine's pack_weight_fp8_k does (not from
+                # their model-dtype rounding), one tensor at a time; force_a8: one row of a batch >= 3 run restated at batch 1
+                for name, (shape, gen) in specs.items():
+                    if name == "lm_head.weight" or (name.startswith("model.layers.") and len(shape) == 2 and
+                                                    (name.endswith("_proj.weight") or name.endswith("lora_A.weight"))):
+                        o.W8[name] = ref_cpu.fake_quant_e4m3(gen(name, shape, device).float().cpu())
+                o.fp8, o.force_a8 = True, True
+            return o
 
         orc = oracle_for(dtype_name)
         toks, rows, t_prefill, t_tok = _oracle_decode(orc, ref_cpu, ids, q, n_tok)
         del orc
+        t_sample = time.time() - t_all
     t_cfg0 = t_enc + t_prefill + (n_tok - 1) * t_tok
     t_report = t_enc + t_prefill + new_tokens * t_tok
     res = {
@@ -205,7 +242,7 @@ def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device, hip_tf=None):
                    f"has {os.cpu_count()} cpus): 1 image 448 px full-size encode {t_enc:.2f} s + prefill T={prompt_len} through all "
                    f"{cfg.llama.layers} layers ({dtype_name}) {t_prefill:.2f} s + {n_tok} greedy tokens at {t_tok*1e3:.0f} ms/token = "
                    f"{t_cfg0:.1f} s of CPU work; value = 1 / (encode + prefill + {new_tokens} x per-token) = 1 / {t_report:.1f} s; "
-                   f"wall incl. weight generation {time.time()-t_all:.0f} s"),
+                   f"wall incl. weight generation {t_sample:.0f} s"),
         "s_per_token": t_tok, "s_encode": t_enc, "s_prefill": t_prefill, "config0_s": t_cfg0, "tokens": toks[:8],
     }
     if hip_tf is not None:
@@ -224,6 +261,43 @@ def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device, hip_tf=None):
             res["parity_" + other] = oracle_check(ht, hl, toks2, rows2, other, teacher_forced=True)
             res["parity_" + other].update(encoder_rel_l2=erel, encoder_bar=enc_bar[other])
             res["parity_" + other]["ok"] = res["parity_" + other]["ok"] and erel < enc_bar[other]
+            if e2e_tf is not None:
+                # ONE end-to-end leg: the engine's OWN Q-Former output into its decoder (nothing handed over by the oracle), in the
+                # dtype whose noise floor leaves room for a bar -- fp16: the encoder's rounding noise moves full-depth logits by ~0.1,
+                # a splice / plumbing error between the halves moves them by O(1). Bar 0.25 on every step + 90 % argmax identity.
+                ht, hl = e2e_tf(other, toks2)
+                e = oracle_check(ht, hl, toks2, rows2, other, teacher_forced=True, bar=0.25)
+                e["checked"] = "END TO END: engine encoder -> engine decoder (its own Q-Former output), teacher-forced, vs the oracle's image -> tokens"
+                e["ok"] = e["ok"] and e["tokens_identical"] >= 0.9 * e["tokens_compared"]
+                res["parity_e2e_" + other] = e
+        if b32_tf is not None:
+            # BASELINE configs[2]/[3] per-GPU load: row 0 of a batch-32 prefill + decode (xstat32_k / xsplit32_k / throughput attention / flash
+            # prefill) against the same oracle rows
+            ht, hl = b32_tf(toks)
+            res["parity_b32"] = oracle_check(ht, hl, toks, rows, dtype_name, teacher_forced=True)
+            res["parity_b32"]["checked"] = "row 0 of a batch-32 run (31 other prompts, ragged padding), full depth, teacher-forced with the oracle's tokens"
+        if fp8_tf is not None:
+            # BASELINE configs[4], row 0 of the fp8 engine's batch-32 run (fp8 x fp8 prefill and decode kernels):
+            # (a) against the UN-QUANTISED oracle of the model dtype -- what a user of configs[4] gives up (reported, no bar: no reference fp8 exists);
+            ht, hl = fp8_tf(toks)
+            errs = [float((hl[s_].float() - rows[s_]).abs().max()) for s_ in range(len(toks))]
+            same = sum(int(a) == int(b) for a, b in zip(ht, toks))
+            top2 = [rows[s_].topk(2).values for s_ in range(len(toks))]
+            res["fp8_vs_unquantised"] = {
+                "checked": f"fp8 engine (e4m3 weights + activations, LoRA-A rows e4m3 too), row 0 of batch 32, teacher-forced with the {dtype_name} "
+                           f"oracle's tokens, against the UN-quantised {dtype_name} oracle's logits, full depth",
+                "tokens_identical": same, "tokens_compared": len(toks), "worst_logit_err": max(errs), "median_logit_err": sorted(errs)[len(errs) // 2],
+                "median_oracle_margin": sorted(float(t[0] - t[1]) for t in top2)[len(top2) // 2]}
+            # (b) against its own definition, the fake-quantised oracle (the fp8 line had no independent check): 16 steps, bar 0.5 =
+            # tests/test_gpu_parity.py FP8_TOL (e4m3 code flips bound the logits)
+            with torch.no_grad():
+                orc8 = oracle_for(dtype_name, fp8=True)
+                toks8, rows8, _, _ = _oracle_decode(orc8, ref_cpu, ids, q, 16)
+                del orc8
+            ht8, hl8 = fp8_tf(toks8)
+            res["parity_fp8"] = oracle_check(ht8, hl8, toks8, rows8, dtype_name, teacher_forced=True, bar=0.5)
+            res["parity_fp8"]["checked"] = ("fp8 engine, row 0 of batch 32, full depth, teacher-forced, against LlamaOracle(fp8=True) -- the reference math on "
+                                            "the same fake-quantised operands (the leg's own definition: no reference fp8 exists)")
     return res
 
 
@@ -232,14 +306,14 @@ def cpu_baseline(cfg, dtype_name, prompt_len, new_tokens, device, hip_tf=None):
 PARITY_ABS_BAR = {"f16": 6e-2, "bf16": 0.45}
 
 
-def oracle_check(hip_tokens, hip_logits, ref_tokens, ref_logits, dtype="bf16", teacher_forced=False):
+def oracle_check(hip_tokens, hip_logits, ref_tokens, ref_logits, dtype="bf16", teacher_forced=False, bar=None):
     """The engine's tokens / logits of the benchmarked configuration against the oracle's, step by step (tests/_parity.py's rules).
     `ok` needs BOTH (round 4): every compared step's worst logit difference under 1.5 x the absolute bar of the dtype (the number of
     steps over the bar itself is reported: the tests demand 99 % under it over 64 steps), and every differing argmax at an oracle top-2 margin <= 2 x the measured error of that step. Free-running
     (teacher_forced=False) the comparison ends at the first differing token -- later inputs differ; teacher-forced (the engine was fed
     the oracle's tokens through rdx_decode_step_ids) every step is compared."""
     n = min(len(ref_tokens), len(hip_tokens))
-    bar = PARITY_ABS_BAR[dtype]
+    bar = PARITY_ABS_BAR[dtype] if bar is None else bar
     same, worst, note, ok, over, compared = 0, 0.0, None, True, 0, 0
     for s in range(n):
         err = float((hip_logits[s].float().cpu() - ref_logits[s]).abs().max())
@@ -262,17 +336,77 @@ def oracle_check(hip_tokens, hip_logits, ref_tokens, ref_logits, dtype="bf16", t
                 break
             continue
         same += 1
+    # the tests' rule (tests/_parity.py): 99 % of the compared steps under the bar itself -- over 32 steps that is "at most one over"
+    # (short comparisons -- unit tests, a free-running leg cut at its first flip -- carry only the 1.5 x rule)
+    allowed_over = max(1, compared // 100) if compared >= 16 else compared
+    if over > allowed_over:
+        ok = False
+        note = note or f"{over} of {compared} steps over the absolute bar {bar} of {dtype} (at most {allowed_over} allowed)"
     return {"checked": "image -> tokens, full depth, rank 0 row 0 (outside the timed region)" + (", teacher-forced with the oracle's tokens" if teacher_forced else ""),
-            "dtype": dtype, "abs_bar": bar, "tokens_identical": same, "tokens_compared": compared, "steps_over_bar": over, "worst_logit_err": worst,
-            "divergence": note, "ok": ok}
+            "dtype": dtype, "abs_bar": bar, "tokens_identical": same, "tokens_compared": compared, "steps_over_bar": over,
+            "steps_over_bar_allowed": allowed_over, "worst_logit_err": worst, "divergence": note, "ok": ok}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+STUB = os.environ.get("RDX_BENCH_STUB") == "1"
+
+
+def _sync():
+    if not STUB:
+        torch.cuda.synchronize()
+
+
+class _StubEngine:
+    """RDX_BENCH_STUB=1 (tests/test_bench_multirank.py only): main()'s multi-rank control flow on a box without GPUs -- sleeps instead of kernels,
+    token ids that name (rank, row), and the 'communicator is up' branch of shard.allgather_tokens carried by the launcher's gloo group where
+    the real engine calls ncclAllGather. Never measured, never shipped: the line it produces says `"data": "STUB ..."`."""
+    def __init__(self, cfg, dtype="bf16", device=0, max_batch=1, max_len=512, lora=True, weights_fp8=False, **_):
+        self.cfg, self.device, self.max_batch, self._world, self._rank = cfg, torch.device("cpu"), max_batch, 0, 0
+
+    def load_weights(self, get, **_):
+        pass
+
+    def encode_image(self, image, want_image_embeds=True, **_):
+        time.sleep(0.001)
+        return torch.zeros(image.shape[0], self.cfg.qformer.n_query, self.cfg.qformer.hidden), None
+
+    def generate(self, ids, q, max_new, **_):
+        time.sleep(0.002 * (1 + self._rank))                   # rank r is the slower one: the clock must be the MAX over ranks
+        B = ids.shape[0]
+        toks = (torch.arange(B, dtype=torch.int32)[:, None] + 1000 * self._rank).expand(B, max_new).contiguous()
+        return toks, None, max_new
+
+    def comm_unique_id(self):
+        return bytes(128)
+
+    def comm_init(self, uid, rank, world):
+        self._rank, self._world = rank, world
+
+    @property
+    def comm_world(self):
+        return 0 if getattr(self, "comm_off", False) else self._world
+
+    def allgather_tokens(self, tokens):
+        import torch.distributed as dist
+        out = torch.empty(self._world * tokens.shape[0], tokens.shape[1], dtype=tokens.dtype)
+        if self._world > 1:
+            dist.all_gather_into_tensor(out, tokens.contiguous())
+        else:
+            out.copy_(tokens)
+        return out
+
+    def time_unit(self, what, iters):
+        return {0: 3.9, 1: 0.031, 6: 0.032, 7: 0.0376}.get(what, 0.01)
+
+    def close(self):
+        pass
+
+
 def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms, use_graph):
     """Per-phase numbers behind the headline (rank 0 only): encoder ms/img, prefill ms, mean decode step, the dominant kernel's
     live HIP-event duration and the roofline fractions."""
     lc = cfg.llama
-    torch.cuda.synchronize()
+    _sync()
     t1 = time.perf_counter()
     for _ in range(5):
         eng.encode_image(img, want_image_embeds=False)
@@ -281,11 +415,11 @@ def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms
     def wbytes(n_rows, k):        # bytes per streamed weight element of a decode projection: the fp8 engine holds (and streams) e4m3 only
         return 1 if args.fp8 else 2
 
-    torch.cuda.synchronize()
+    _sync()
     t2 = time.perf_counter()
     for _ in range(3):
         eng.generate(ids, out_q, max_new=1, eos_id=-1, pad_id=0, use_graph=use_graph)
-    torch.cuda.synchronize()
+    _sync()
     prefill_ms = (time.perf_counter() - t2) / 3 * 1e3
     avg_step_ms = (elapsed_per_step_ms - enc_ms * B - prefill_ms) / max(N - 1, 1)
     H_, I_ = lc.hidden, lc.inter
@@ -323,7 +457,7 @@ def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms
                 if ms_a > ms:
                     other[0], dom = ({"kernel": nm, "us_per_launch": ms * 1e3, "bytes_per_launch": nb, "achieved": nb / (ms * 1e-3) / 1e9,
                                       "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
-                                     (other[0]["kernel"], ms_a, nb_a, f"decode_attention B={B} {args.dtype}"))
+                                     (other[0]["kernel"], ms_a, nb_a, f"decode_attention_k B={B} {args.dtype}{' fp8' if args.fp8 else ''}"))
             except Exception:
                 pass
     name, k_ms, k_bytes, key = dom
@@ -334,7 +468,7 @@ def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms
     roof = {
         "bound": "hbm", "kernel": name,
         "achieved": k_bytes / (k_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(key),
+        "frac": k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic(key), "traffic_source": pmc_source(key),
         "bytes_per_launch": k_bytes, "us_per_launch": k_ms * 1e3, "second_kernel": other[0],
         "decode_step_ms": step_ms, "decode_step_weight_GBs": step_bytes / (step_ms * 1e-3) / 1e9,
         "decode_step_frac": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -366,10 +500,10 @@ def run_steps(eng, cfg, args, B, T, N, rank, world, dist, steps, warmup, use_gra
         return allgather_tokens(toks, world, engine=eng)          # librdx's ncclAllGather when a communicator is up, else identity
 
     def fence():
-        torch.cuda.synchronize()
+        _sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync()
 
     out = None
     for _ in range(warmup):
@@ -402,7 +536,7 @@ def fixture_check(dtype, B, fp8, tokens_row0):
 def cpu_baseline_pointer():
     """N > 1 lines: the CPU oracle is timed on rank 0 at N = 1 only (contract); multi-rank lines carry the committed N = 1 figure of this
     build so that SCALE records are self-contained."""
-    for name in ("r04_bench.json", "r03_bench.json"):
+    for name in ("r05_bench.json", "r04_bench.json", "r03_bench.json"):
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 cb = json.loads(f.read().strip().splitlines()[-1])["cpu_baseline"]
@@ -424,7 +558,7 @@ def spawn_ranks(args):
     GPU). The reference has no inference launcher to mirror (its only one is the training DDP of model/lavis/common/dist_utils.py:57-91)."""
     import socket
     n = args.gpus
-    vis = torch.cuda.device_count()
+    vis = n if STUB else torch.cuda.device_count()
     if vis < n:
         print(f"bench.py: --gpus {n} but only {vis} GPU(s) are visible to this process (torch.cuda.device_count()); refusing to "
               f"benchmark fewer GPUs than asked for", file=sys.stderr)
@@ -479,15 +613,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = world > 1 or "RANK" in os.environ      # by torch.distributed.run (also at --nproc-per-node 1)
-    if local_rank >= torch.cuda.device_count():
+    if not STUB and local_rank >= torch.cuda.device_count():
         print(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} GPU(s) are visible", file=sys.stderr)
         sys.exit(2)
     if launched:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
+        if not STUB:
+            torch.cuda.set_device(local_rank)
         # launcher-side plumbing only (RCCL id broadcast, barrier, max-over-ranks clock): a gloo group on the host. The data-path
         # collective is librdx's own RCCL communicator; `RDX_BENCH_PG=nccl` puts the plumbing on torch's RCCL group instead.
-        backend = os.environ.get("RDX_BENCH_PG", "gloo")
+        backend = "gloo" if STUB else os.environ.get("RDX_BENCH_PG", "gloo")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -498,17 +633,20 @@ def main():
     from radialog_amd.config import full_cfg
     from radialog_amd.engine import RdxEngine, synth_getter
     from radialog_amd.shard import init_comm
+    Engine = _StubEngine if STUB else RdxEngine
 
     cfg = full_cfg()
     T, N = args.prompt_len, args.new_tokens
     max_len = (T + N + 64 + 31) // 32 * 32
     use_graph = not args.no_graph
     host_dev = lambda e: e.device if (dist is not None and dist.get_backend() == "nccl") else "cpu"      # noqa: E731
+    want_oracle = world == 1 and not args.no_cpu_baseline and not STUB
 
-    def timed_run(B, fp8, steps, warmup, keep_engine=False):
+    def timed_run(B, fp8, steps, warmup, keep_engine=False, dtype=None):
         """One engine per rank (full weight replica), RCCL communicator inside librdx, `steps` timed steps between barriers, the MAX of
         the per-rank clocks. Every rank calls this (collectives inside); rank 0 also gets the per-phase detail."""
-        eng = RdxEngine(cfg, dtype=args.dtype, device=local_rank, max_batch=B, max_len=max_len, lora=True, weights_fp8=fp8)
+        dtype = dtype or args.dtype
+        eng = Engine(cfg, dtype=dtype, device=local_rank, max_batch=B, max_len=max_len, lora=True, weights_fp8=fp8)
         eng.load_weights(synth_getter(cfg, eng.device, lora=True))
         comm_note = None
         if launched:
@@ -529,14 +667,15 @@ def main():
             elapsed, per_rank = gather_clock(dist, elapsed, world, host_dev(eng))
             per_rank_ms = [t / steps * 1e3 for t in per_rank]
         assert out.shape[0] == B * world and out.shape[1] == N, f"gathered token matrix {tuple(out.shape)}, expected {(B * world, N)}"
-        r = {"B": B, "fp8": fp8, "steps": steps, "warmup": warmup, "elapsed": elapsed, "per_rank_ms": per_rank_ms, "comm_world": eng.comm_world,
+        r = {"B": B, "fp8": fp8, "dtype": dtype, "steps": steps, "warmup": warmup, "elapsed": elapsed, "per_rank_ms": per_rank_ms, "comm_world": eng.comm_world,
              "comm_note": comm_note, "tokens_row0": [int(t) for t in out[rank * B, :8].tolist()]}
         if rank == 0:
-            fp8_was, args.fp8 = args.fp8, fp8
+            fp8_was, dt_was = args.fp8, args.dtype
+            args.fp8, args.dtype = fp8, dtype
             r["enc_ms"], r["roof"] = measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed / steps * 1e3, use_graph)
-            args.fp8 = fp8_was
-            r["token_check"] = fixture_check(args.dtype, B, fp8, r["tokens_row0"])
-            if keep_engine:       # rank 0, batch 1: the timed engine stays up for the oracle's teacher-forced check (untimed, after the sub-runs)
+            args.fp8, args.dtype = fp8_was, dt_was
+            r["token_check"] = fixture_check(dtype, B, fp8, r["tokens_row0"])
+            if keep_engine:       # rank 0: the timed engine stays up for the oracle's teacher-forced check (untimed, after the sub-runs)
                 r["engine"], r["img"], r["ids"] = eng, img, ids
                 return r
         eng.close()
@@ -544,11 +683,12 @@ def main():
 
     def engine_tf(eng, img, ids, ref_tokens, ref_q):
         """The engine on row 0 of the benchmark's image and prompt: its encoder output against the oracle's (relative L2), and its decoder on
-        the oracle's Q-Former output, fed the oracle's tokens: (argmax per step, fp32 logits [n, V], encoder rel-L2)."""
+        the oracle's Q-Former output (ref_q None: on its OWN encoder output -- the end-to-end leg), fed the oracle's tokens: (argmax per step,
+        fp32 logits [n, V], encoder rel-L2)."""
         q, _ = eng.encode_image(img[:1], want_image_embeds=False)
-        erel = float((q.float().cpu() - ref_q).norm() / ref_q.norm())
+        erel = None if ref_q is None else float((q.float().cpu() - ref_q).norm() / ref_q.norm())
         n = len(ref_tokens)
-        _, lg = eng.prefill(ids[:1], ref_q, max_new=n, eos_id=-1)
+        _, lg = eng.prefill(ids[:1], q if ref_q is None else ref_q, max_new=n, eos_id=-1)
         rows = [lg[0].float().cpu().clone()]
         for s_ in range(1, n):
             _, lg = eng.decode_step(input_ids=torch.tensor([ref_tokens[s_ - 1]]))
@@ -556,30 +696,76 @@ def main():
         hl = torch.stack(rows)
         return hl.argmax(-1).tolist(), hl, erel
 
+    def engine_tf_rows(eng, img, ids, ids_row0, ref_tokens, ref_q):
+        """Row 0 of a BATCHED run (the batch 3-32 kernel family) teacher-forced with the oracle's tokens: the batch is the benchmark's own images
+        and prompts (ragged left padding) with row 0 replaced by the oracle's prompt and Q-Former output; the other rows run free (their own
+        argmax is fed back). -> (argmax of row 0 per step, fp32 logits of row 0 [n, V])."""
+        q, _ = eng.encode_image(img, want_image_embeds=False)
+        q = q.clone()
+        q[0] = ref_q[0].to(q.device)
+        ids = ids.clone()
+        ids[0] = ids_row0[0].to(ids.device)
+        n = len(ref_tokens)
+        _, lg = eng.prefill(ids, q, max_new=n, eos_id=-1)
+        rows = [lg[0].float().cpu().clone()]
+        for s_ in range(1, n):
+            nxt = lg.float().argmax(-1).to(torch.int32)
+            nxt[0] = int(ref_tokens[s_ - 1])
+            _, lg = eng.decode_step(input_ids=nxt)
+            rows.append(lg[0].float().cpu().clone())
+        hl = torch.stack(rows)
+        return hl.argmax(-1).tolist(), hl
+
     def sub_line(r, workload):
         roof = r["roof"]
-        return {"workload": workload, "value": r["steps"] * r["B"] * world / r["elapsed"], "unit": "reports/s", "n_gpus": world,
+        return {"workload": workload, "value": r["steps"] * r["B"] * world / r["elapsed"], "unit": "reports/s", "n_gpus": world, "dtype": r["dtype"] + ("+fp8w" if r["fp8"] else ""),
                 "per_gpu_batch": r["B"], "global_batch": r["B"] * world, "steps": r["steps"], "warmup": r["warmup"],
                 "ms_per_step": r["elapsed"] / r["steps"] * 1e3, "tokens_per_s": r["steps"] * r["B"] * world * N / r["elapsed"],
                 "per_rank_ms_per_step": r["per_rank_ms"], "rccl_ranks": r["comm_world"],
                 "encoder_ms_per_img": r["enc_ms"], "prefill_ms": roof["prefill_ms"], "decode_avg_step_ms": roof["decode_avg_step_ms"],
                 "decode_avg_frac": roof["decode_avg_frac"], "kernel": roof["kernel"], "kernel_frac": roof["frac"],
-                "kernel_us": roof["us_per_launch"], "traffic": roof["traffic"], "mfma": roof["mfma"], "token_check": r["token_check"]}
+                "kernel_us": roof["us_per_launch"], "traffic": roof["traffic"], "traffic_source": roof.get("traffic_source"), "mfma": roof["mfma"],
+                "token_check": r["token_check"]}
+
+    def enc_b256():
+        """encoder ms/img at the reference's embedding-dump batch (pretraining/train.py:139: batch 256), bf16 MFMA fraction: a vision-only context."""
+        from radialog_amd import synth
+        eb = 256
+        eng = RdxEngine(cfg, dtype=args.dtype, device=local_rank, max_batch=1, max_len=64, lora=True, llama=False)
+        eng.load_weights(synth_getter(cfg, eng.device, lora=True), llama=False)
+        img = synth.synth_images(eb, cfg.vision.img, device=eng.device, seed=16)
+        eng.encode_image(img, want_image_embeds=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng.encode_image(img, want_image_embeds=False)
+        ms = (time.perf_counter() - t0) / 3 / eb * 1e3
+        eng.close()
+        tf = encode_flops(cfg) / (ms * 1e-3) / 1e12
+        return {"workload": "image encode alone at the reference's embedding-dump batch (pretraining/train.py:139), 256 x 448 px", "batch": eb,
+                "encoder_ms_per_img": ms, "images_per_s": 1e3 / ms, "encode_tflops": tf, "encode_frac": tf / MFMA_PEAK_TFLOPS, "peak_tflops": MFMA_PEAK_TFLOPS}
 
     B = args.batch
-    main_r = timed_run(B, args.fp8, args.steps, args.warmup, keep_engine=(B == 1 and world == 1 and not args.no_cpu_baseline))
+    main_r = timed_run(B, args.fp8, args.steps, args.warmup, keep_engine=(B == 1 and want_oracle))
     subs = {}
     k2 = max(2, min(args.steps, 3))
     if B == 1 and not args.fp8 and not args.no_b32:
         # BASELINE configs[2] (one GPU) / configs[3] (8 GPUs: global batch 256, one all-gather of int32[32,256] per rank) in the same job
         # and JSON line: batch 32 per GPU, KV cache in HBM, hipGraph-captured decode step
-        subs["b32"] = (timed_run(32, False, k2, 1), f"configs[{2 if world == 1 else 3}]: per-GPU batch 32 (global {32 * world}), same pipeline, "
-                                                    "hipGraph-captured decode step" + (", RCCL all-gather of the token ids" if world > 1 else ""))
+        subs["b32"] = (timed_run(32, False, k2, 1, keep_engine=want_oracle),
+                       f"configs[{2 if world == 1 else 3}]: per-GPU batch 32 (global {32 * world}), same pipeline, "
+                       "hipGraph-captured decode step" + (", RCCL all-gather of the token ids" if world > 1 else ""))
     if B == 1 and not args.fp8 and not args.no_fp8:
         # BASELINE configs[4] per-GPU load: fp8 e4m3 decoder weights + per-row scale, LoRA epilogue, batch 32 per GPU
-        subs["fp8_b32"] = (timed_run(32, True, k2, 1), f"configs[4]: fp8 e4m3 decoder GEMM weights + per-row scale + un-merged LoRA epilogue, per-GPU "
-                                                       f"batch 32 (global {32 * world}); no reference fp8 path exists -- its oracle is the reference math on the "
-                                                       "same fake-quantised operands (tests/test_gpu_parity.py), i.e. unpinnable against the reference itself")
+        subs["fp8_b32"] = (timed_run(32, True, k2, 1, keep_engine=want_oracle),
+                           f"configs[4]: fp8 e4m3 decoder GEMM weights + per-row scale + un-merged LoRA epilogue, per-GPU "
+                           f"batch 32 (global {32 * world}); no reference fp8 path exists -- its oracle is the reference math on the "
+                           "same fake-quantised operands (cpu_baseline.parity_fp8 / tests/test_gpu_parity.py), i.e. unpinnable against the reference itself; "
+                           "cpu_baseline.fp8_vs_unquantised says what it costs against the un-quantised oracle")
+    f16_r = None
+    if B == 1 and not args.fp8 and args.dtype != "f16" and world == 1 and not args.no_f16 and not STUB:
+        # the reference's dtype, in which token identity with the CPU path actually holds (parity_f16): the same configs[1] workload timed in fp16
+        f16_r = timed_run(1, False, k2, 1, keep_engine=want_oracle, dtype="f16")
 
     if rank == 0:
         r, roof = main_r, main_r["roof"]
@@ -588,7 +774,8 @@ def main():
             "value": args.steps * B * world / r["elapsed"], "unit": "reports/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": r["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype + ("+fp8w" if args.fp8 else ""), "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype + ("+fp8w" if args.fp8 else ""),
+            "data": "synthetic" if not STUB else "STUB (RDX_BENCH_STUB=1: no GPU, fake timings -- control-flow test only)",
             "config": {"workload": f"configs[{1 if B == 1 else 2}]: per-GPU batch {B} BioViL-T(ResNet-50)+Q-Former encode 448px, "
                                    f"Vicuna-7B prefill T={T}, {N}-token greedy decode (LoRA r=8 un-merged, hipGraph step={use_graph}"
                                    + (", fp8 e4m3 decoder weights + per-row scale [configs[4] weight path]" if args.fp8 else "") + ")",
@@ -600,34 +787,75 @@ def main():
             "collective": ("rdx_allgather_tokens (ncclAllGather inside librdx), int32[%d,%d] per rank per step" % (B, N)) if r["comm_world"] else r["comm_note"],
             "roofline": roof, "token_check": r["token_check"],
         }
+        if args.dtype == "bf16" and not args.fp8:
+            res["dtype_note"] = ("bf16 is the THROUGHPUT dtype: against the CPU oracle its greedy tokens flip at near-ties (cpu_baseline.parity: teacher-forced "
+                                 "argmax identity, first flip, margin); token identity with the reference's CPU path holds in the reference's own dtype, fp16 -- "
+                                 "value_f16 is the same workload timed in fp16, cpu_baseline.parity_f16 its check")
         for key, (sr, wl) in subs.items():
             res[key] = sub_line(sr, wl)
-        if world == 1 and not args.no_cpu_baseline:
+        if f16_r is not None:
+            res["value_f16"] = f16_r["steps"] / f16_r["elapsed"]
+            res["f16_b1"] = sub_line(f16_r, "configs[1] in fp16 (the reference's dtype; token-identical to the CPU oracle over the checked horizon): per-GPU batch 1")
+        if world == 1 and B == 1 and not args.fp8 and not args.no_enc256 and not STUB:
+            try:
+                res["enc_b256"] = enc_b256()
+            except Exception as e:                       # a too-small GPU must not lose the line
+                res["enc_b256"] = {"error": f"{type(e).__name__}: {e}"}
+        if want_oracle:
+            ids1 = r["ids"] if r.get("ids") is not None else None
+
             def hip_tf(dn, ref_tokens, ref_q):
                 if dn == args.dtype and not args.fp8 and r.get("engine") is not None:
                     return engine_tf(r["engine"], r["img"], r["ids"], ref_tokens, ref_q)
+                if f16_r is not None and dn == "f16" and f16_r.get("engine") is not None:
+                    return engine_tf(f16_r["engine"], f16_r["img"], f16_r["ids"], ref_tokens, ref_q)
                 e2 = RdxEngine(cfg, dtype=dn, device=local_rank, max_batch=1, max_len=max_len, lora=True)       # the other dtype: a second engine
                 e2.load_weights(synth_getter(cfg, e2.device, lora=True))
                 try:
                     return engine_tf(e2, r["img"], r["ids"], ref_tokens, ref_q)
                 finally:
                     e2.close()
-            res["cpu_baseline"] = cpu_baseline(cfg, args.dtype, T, N, torch.device("cuda", local_rank), hip_tf=None if args.fp8 else hip_tf)
+
+            def e2e_tf(dn, ref_tokens):
+                ht, hl, _ = engine_tf(f16_r["engine"], f16_r["img"], f16_r["ids"], ref_tokens, None)
+                return ht, hl
+
+            box = {}          # the batched legs need the oracle's Q-Former output: cpu_baseline hands it to hip_tf first
+
+            def hip_tf_capture(dn, ref_tokens, ref_q):
+                box["q"] = ref_q
+                return hip_tf(dn, ref_tokens, ref_q)
+
+            def sub_tf(key):
+                sr = subs[key][0]
+                return lambda ref_tokens: engine_tf_rows(sr["engine"], sr["img"], sr["ids"], ids1, ref_tokens, box["q"])
+
+            have = lambda k: k in subs and subs[k][0].get("engine") is not None and ids1 is not None      # noqa: E731
+            res["cpu_baseline"] = cpu_baseline(cfg, args.dtype, T, N, torch.device("cuda", local_rank), hip_tf=None if args.fp8 else hip_tf_capture,
+                                               b32_tf=sub_tf("b32") if have("b32") else None, fp8_tf=sub_tf("fp8_b32") if have("fp8_b32") else None,
+                                               e2e_tf=e2e_tf if (f16_r is not None and f16_r.get("engine") is not None) else None)
         elif world > 1:
             res["cpu_baseline"] = cpu_baseline_pointer()
-        if r.get("engine") is not None:
-            r["engine"].close()
+        for rr in [r, f16_r] + [sr for sr, _ in subs.values()]:
+            if rr is not None and rr.get("engine") is not None:
+                rr["engine"].close()
         res["max_batch_per_gpu"] = 32                                       # librdx's decoder holds at most 32 rows per context (api.hip)
         cb = res.get("cpu_baseline", {})
-        fixtures = [res["token_check"]] + [res[k]["token_check"] for k in subs]
-        oracle_ok = all(cb.get(k, {"ok": True}).get("ok", True) for k in ("parity", "parity_f16"))
-        # fixture misses are FLAGGED, not fatal (the batch-32 / fp8 fixtures were written by this engine and a toolchain change that
-        # moves one ulp would fail them); a disagreement with the CPU oracle -- the independent checker -- is fatal (exit 3)
+        fixtures = [res["token_check"]] + [res[k]["token_check"] for k in subs] + ([res["f16_b1"]["token_check"]] if f16_r is not None else [])
+        parity_keys = [k for k in cb if k.startswith("parity")]
+        oracle_checked = len(parity_keys) > 0
+        oracle_ok = all(cb[k].get("ok", True) for k in parity_keys)
+        # the exit code gates on verification again. The CPU oracle -- the independent checker -- failing is fatal (exit 3). A fixture
+        # miss is only a WARNING when the oracle checked this very run (the batch-32 / fp8 fixtures were written by this engine, and a toolchain
+        # change that moves one ulp may move them); when NO oracle parity ran (N > 1, --no-cpu-baseline, --fp8) the fixtures are the only check
+        # there is, and a miss is fatal too.
+        res["oracle_checked"] = oracle_checked
+        res["oracle_legs"] = {k: bool(cb[k].get("ok")) for k in parity_keys}
         res["fixtures_match"] = all(c.get("ok", True) for c in fixtures)
-        res["results_verified"] = res["fixtures_match"] and oracle_ok
+        res["results_verified"] = (oracle_checked and oracle_ok) or (not oracle_checked and res["fixtures_match"] and not STUB)
         sys.stdout.flush()
         os.write(out_fd, (json.dumps(res) + "\n").encode())
-        rc = 0 if oracle_ok else 3
+        rc = 0 if (STUB or (oracle_ok and (oracle_checked or res["fixtures_match"]))) else 3
         if not res["fixtures_match"]:
             print("bench.py: WARNING: a timed configuration's first tokens differ from tests/golden/bench_tokens.json (token_check)", file=sys.stderr)
     else:
@@ -636,7 +864,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rc:
-        print("bench.py: the timed configuration's tokens do not match the committed fixture / the oracle (see token_check, cpu_baseline.parity)",
+        print("bench.py: the timed configuration's tokens do not match the committed fixture / the oracle (see token_check, cpu_baseline.parity*)",
               file=sys.stderr)
         sys.exit(rc)
 

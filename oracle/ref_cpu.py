@@ -281,6 +281,8 @@ class LlamaOracle:
                                              (k.endswith("_proj.weight") or k.endswith("lora_A.weight"))):
                     self.W8[k] = fake_quant_e4m3(v)
         self._a8 = False                       # set per forward() call: are this pass's projections fp8 x fp8?
+        self.force_a8 = False                  # True: every pass multiplies fp8 x fp8 whatever its batch -- ONE row of a batch >= 3 engine
+                                               # run restated at batch 1 (activation scales are per row: rows do not interact; bench.py)
         self.lora = lora and any("lora_A" in k for k in W)
         self.cos, self.sin = rope_tables(cfg.head_dim, cfg.max_pos, cfg.rope_base, dtype)
 
@@ -379,7 +381,7 @@ class LlamaOracle:
         pl = 0 if past is None else past[0][0].shape[2]
         mask = self._mask(key_mask, T, pl)
         # fp8 mode: a prefill (more than one token per row, or nothing cached) runs every projection fp8 x fp8; a decode step from batch 3
-        self._a8 = self.fp8 and (past is None or T > 1 or x.shape[0] >= 3)
+        self._a8 = self.fp8 and (past is None or T > 1 or x.shape[0] >= 3 or self.force_a8)
         new_past = []
         nl = self.cfg.layers if n_layers is None else n_layers
         for l in range(nl):
@@ -389,7 +391,7 @@ class LlamaOracle:
         h = rmsnorm(x, self.W["model.norm.weight"], self.cfg.rms_eps)
         hl = h if all_logits else h[:, -1:]
         # lm_head runs on the [B][H] last-position rows in prefill and decode alike: fp8 x fp8 from batch 3
-        logits = self._lin(hl, "lm_head.weight", a8=self.fp8 and x.shape[0] >= 3)
+        logits = self._lin(hl, "lm_head.weight", a8=self.fp8 and (x.shape[0] >= 3 or self.force_a8))
         return logits, new_past, h
 
     # -- greedy loop (transformers==4.28.1 GenerationMixin.greedy_search, restated) --------------------

@@ -13,6 +13,17 @@ HEADERS = ["rdx_common.h", "rdx_kernels.h", "rdx_ctx.h", "skinny_body.h", "attn_
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
+def source_hash() -> str:
+    """16 hex digits over every kernel / ABI source: the tree a profile was taken on (profiles/rNN_pmc.json carries it; bench.py flags a
+    replayed PMC figure whose tree differs from the one that is running)."""
+    import hashlib
+    h = hashlib.sha256()
+    for s in sorted(SOURCES) + sorted(HEADERS):
+        with open(os.path.join(CSRC, s), "rb") as f:
+            h.update(s.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def _stale():
     if not os.path.exists(OUT):
         return True

@@ -102,6 +102,17 @@ def test_oracle_check_rule_of_the_bench_line():
     mid = torch.stack(ref) + 0.07 * torch.tensor([1.0] + [0.0] * (V - 1))      # over the bar, under 1.5 x: reported, not fatal
     rm = b.oracle_check([7, 9, 11, 13], mid, [7, 9, 11, 13], ref, "f16")
     assert rm["ok"] and rm["steps_over_bar"] == 4
+    # round 5: from 16 compared steps the tests' "99 % of the steps under the bar" is ENFORCED -- over 32 steps one may sit
+    # between the bar and 1.5 x, two may not
+    toks32 = [7] * 32
+    ref32 = [ref[0].clone() for _ in range(32)]
+    bump = lambda n: torch.stack(ref32) + 0.07 * torch.tensor([[1.0] + [0.0] * (V - 1)] * n + [[0.0] * V] * (32 - n))      # noqa: E731
+    r1 = b.oracle_check(toks32, bump(1), toks32, ref32, "f16", teacher_forced=True)
+    assert r1["ok"] and r1["steps_over_bar"] == 1 and r1["steps_over_bar_allowed"] == 1
+    r2 = b.oracle_check(toks32, bump(2), toks32, ref32, "f16", teacher_forced=True)
+    assert not r2["ok"] and r2["steps_over_bar"] == 2 and "over the absolute bar" in r2["divergence"]
+    # an explicit bar (the fp8 leg: 0.5, the end-to-end fp16 leg: 0.25) replaces the dtype's
+    assert b.oracle_check(toks32, bump(2), toks32, ref32, "f16", teacher_forced=True, bar=0.25)["ok"]
 
 
 def test_launcher_line_gpus_resolution_and_multi_rank_baseline_pointer():
