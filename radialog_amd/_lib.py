@@ -13,6 +13,8 @@ import torch  # noqa: F401  -- must be imported BEFORE librdx.so is loaded so bo
 HERE = os.path.dirname(os.path.abspath(__file__))
 # RDX_LIB_PATH: a differently-built librdx of the same sources (tools/sanitize_host.sh: the host side under ASan / UBSan); never a fallback
 LIB_PATH = os.environ.get("RDX_LIB_PATH") or os.path.join(HERE, "librdx.so")
+# kernel-test / trace / microbenchmark hooks (include/rdx_hooks.h): a separate library, loaded only under RDX_DEBUG_HOOKS=1 (tests, tools)
+HOOKS_PATH = os.environ.get("RDX_HOOKS_PATH") or os.path.join(HERE, "librdx_hooks.so")
 
 RDX_DTYPE_F16, RDX_DTYPE_BF16 = 0, 1
 RDX_W_GEMM, RDX_W_TENSOR, RDX_W_F32, RDX_W_GEMM_FP8 = 0, 1, 2, 3
@@ -78,17 +80,61 @@ SYMBOLS = {
     "rdx_kv_read": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "rdx_hidden_read": (C.c_int, [_P, _P]),
     "rdx_time": (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "rdx_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
+}
+
+# include/rdx_hooks.h: every symbol of librdx_hooks.so
+HOOK_SYMBOLS = {
     "rdx_attn_trace": (C.c_int, [_P, C.c_int, _P]),
     "rdx_gemv_trace": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int]),
     "rdx_gemm_test": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_int]),
     "rdx_kernel_bench": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P, C.c_int]),
-    "rdx_set_option": (C.c_int, [_P, C.c_char_p, C.c_int]),
     "rdx_conv_test": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "rdx_l2_bench": (C.c_int, [_P, C.c_int, C.c_longlong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "rdx_logits_test": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int]),
 }
 
 _lib = None
+_hooks = None
+
+
+def hooks_enabled() -> bool:
+    return os.environ.get("RDX_DEBUG_HOOKS", "0") not in ("", "0")
+
+
+def _missing_hook(name):
+    def raiser(*_a, **_k):
+        raise RdxLibraryError(f"{name} is a kernel-test hook of librdx_hooks.so (include/rdx_hooks.h), not part of the product library: "
+                              "set RDX_DEBUG_HOOKS=1 before radialog_amd is loaded (tests/conftest.py and the tools/ scripts do)")
+    return raiser
+
+
+def load_hooks(lib):
+    """Bind the hooks of include/rdx_hooks.h onto `lib` (the ctypes handle the engine calls through). Under RDX_DEBUG_HOOKS=1 they come from
+    librdx_hooks.so (or from an RDX_LIB_PATH build that links them in: tools/sanitize_host.sh); otherwise every hook raises."""
+    global _hooks
+    if not hooks_enabled():
+        for name in HOOK_SYMBOLS:
+            setattr(lib, name, _missing_hook(name))
+        return
+    src = lib
+    if not hasattr(lib, next(iter(HOOK_SYMBOLS))):
+        if not os.path.exists(HOOKS_PATH):
+            raise RdxLibraryError(f"RDX_DEBUG_HOOKS is set but {HOOKS_PATH} is missing: build it with `python -m radialog_amd.build`")
+        try:
+            src = C.CDLL(HOOKS_PATH, mode=C.RTLD_GLOBAL)
+        except OSError as e:
+            raise RdxLibraryError(f"cannot load {HOOKS_PATH}: {e}") from e
+        _hooks = src
+    for name, (res, args) in HOOK_SYMBOLS.items():
+        try:
+            fn = getattr(src, name)
+        except AttributeError as e:
+            raise RdxLibraryError(f"{HOOKS_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+        if src is not lib:
+            setattr(lib, name, fn)
 
 
 def load():
@@ -101,7 +147,7 @@ def load():
             f"{LIB_PATH} not found: build it with `python -m radialog_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback for the RaDialog hot path.")
     try:
-        lib = C.CDLL(LIB_PATH)
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)      # RTLD_GLOBAL: librdx_hooks.so resolves the context / launcher symbols against it
     except OSError as e:
         raise RdxLibraryError(f"cannot load {LIB_PATH}: {e}") from e
     for name, (res, args) in SYMBOLS.items():
@@ -111,6 +157,7 @@ def load():
             raise RdxLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    load_hooks(lib)
     _lib = lib
     return lib
 

@@ -6,6 +6,9 @@ import pytest
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
+# the kernel-test hooks (include/rdx_hooks.h, librdx_hooks.so) are not part of the product library: the tests ask for them explicitly, before
+# radialog_amd._lib is imported
+os.environ.setdefault("RDX_DEBUG_HOOKS", "1")
 
 
 def pytest_configure(config):

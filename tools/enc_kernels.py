@@ -1,5 +1,7 @@
 """Per-shape timing of the encoder's GEMMs / convolutions through the production dispatch (rdx_kernel_bench):
 python tools/enc_kernels.py [batch]   -- prints us, TFLOP/s and GB/s (algorithmic bytes: in + out (+ residual) + weights)"""
+import os as _os
+_os.environ.setdefault("RDX_DEBUG_HOOKS", "1")      # this tool drives the kernel-test hooks of librdx_hooks.so (include/rdx_hooks.h)
 import sys
 from radialog_amd.config import small_cfg
 from radialog_amd.engine import RdxEngine

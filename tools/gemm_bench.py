@@ -1,5 +1,7 @@
 """Large-M GEMM throughput through rdx_gemm_test (includes weight packing; times the GEMM by differencing two iteration counts is
 not possible through this entry, so this uses the prefill path instead): python tools/gemm_bench.py"""
+import os as _os
+_os.environ.setdefault("RDX_DEBUG_HOOKS", "1")      # this tool drives the kernel-test hooks of librdx_hooks.so (include/rdx_hooks.h)
 import time, torch
 from radialog_amd import synth
 from radialog_amd.config import full_cfg

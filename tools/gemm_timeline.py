@@ -1,4 +1,6 @@
 """In-kernel timeline of gemm_dma_k for one GEMM shape: python tools/gemm_timeline.py M N K [epi]"""
+import os as _os
+_os.environ.setdefault("RDX_DEBUG_HOOKS", "1")      # this tool drives the kernel-test hooks of librdx_hooks.so (include/rdx_hooks.h)
 import sys, torch
 from radialog_amd.config import small_cfg
 from radialog_amd.engine import RdxEngine

@@ -1,4 +1,6 @@
 """Timeline inside a stand-alone decode GEMV (batch 1): python tools/gemv_trace.py"""
+import os as _os
+_os.environ.setdefault("RDX_DEBUG_HOOKS", "1")      # this tool drives the kernel-test hooks of librdx_hooks.so (include/rdx_hooks.h)
 import numpy as np, torch
 from radialog_amd import synth
 from radialog_amd.config import full_cfg

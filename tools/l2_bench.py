@@ -1,4 +1,6 @@
 """Per-CU operand bandwidth from L2 / MALL (rdx_l2_bench): python tools/l2_bench.py"""
+import os as _os
+_os.environ.setdefault("RDX_DEBUG_HOOKS", "1")      # this tool drives the kernel-test hooks of librdx_hooks.so (include/rdx_hooks.h)
 import ctypes as C
 from radialog_amd.config import small_cfg
 from radialog_amd.engine import RdxEngine

@@ -1,5 +1,7 @@
 """pconv_k (fragment-packed convolution) against the row-major production kernels: correctness on random data (small batch) and ms per
 launch at batch B for every trunk shape. python tools/pconv_check.py [B] [tiles...]"""
+import os as _os
+_os.environ.setdefault("RDX_DEBUG_HOOKS", "1")      # this tool drives the kernel-test hooks of librdx_hooks.so (include/rdx_hooks.h)
 import os, sys, torch
 from radialog_amd.config import small_cfg
 from radialog_amd.engine import RdxEngine

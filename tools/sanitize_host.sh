@@ -15,7 +15,7 @@ if [ "${1:-build}" = build ]; then
   SRCS=$(python - <<PY
 import sys; sys.path.insert(0, "$ROOT")
 from radialog_amd import build
-print(" ".join(build.SOURCES))
+print(" ".join(build.SOURCES + build.HOOK_SOURCES))     # one library: the hooks linked in (_lib.load_hooks takes them from RDX_LIB_PATH when it exports them)
 PY
 )
   pids=""

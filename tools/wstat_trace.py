@@ -1,5 +1,7 @@
 """In-kernel timeline of wstat_k (the single prompt's weight-stationary GEMM) for one shape:  python tools/wstat_trace.py M N K [epi]
 Per workgroup: entry, first row tile's K loop done (= weights + first ring landed), last row tile begins, end (100 MHz ticks)."""
+import os as _os
+_os.environ.setdefault("RDX_DEBUG_HOOKS", "1")      # this tool drives the kernel-test hooks of librdx_hooks.so (include/rdx_hooks.h)
 import os, sys
 os.environ["RDX_KB_WSTAT"] = "1"
 import torch

@@ -1,4 +1,6 @@
 """Timeline inside the batch-32 activation-stationary GEMM (xstat32.hip): python tools/xs_trace.py [what ...]  (1 gate/up, 2 qkv)"""
+import os as _os
+_os.environ.setdefault("RDX_DEBUG_HOOKS", "1")      # this tool drives the kernel-test hooks of librdx_hooks.so (include/rdx_hooks.h)
 import sys
 import numpy as np, torch
 from radialog_amd import synth
