@@ -108,7 +108,7 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
             at.O = c->patt; at.o_bs = (long)T * H; at.o_ts = H; at.o_hs = 128;
             at.B = B; at.H = f.heads; at.Tq = T; at.Tk = keep + T; at.causal = 1; at.k_perm = c->ld.k_perm; at.key_mask = c->key_mask; at.km_bs = f.max_len;
             at.flash_min = c->flash_min;
-        launch_attention(dt, 128, at, s);
+            launch_attention(dt, 128, at, s);
             launch_quant_rows(dt, c->patt, H, c->pxq, c->pxs, (int)M, H, 2, s);
             g8(L.wo, H, 2, c->px, H, c->px, EPI_RESID);
             launch_rmsnorm_fp8(dt, c->px, L.mlp_norm, c->pxq, c->pxs, (int)M, H, f.rms_eps, s);
@@ -328,7 +328,9 @@ static int decode_loop(rdx_ctx* c, int B, int max_new, int eos_id, void* scores,
             rc = build_graph(c, scores);
             if (rc) return rc;
         }
-        const int check_every = 16;
+        // EOS poll: a 4-byte-per-row copy + stream sync every 4th step (round 4: every 16th -- up to 15 wasted 3.9-ms steps per finished
+        // batch); the sync costs one launch-queue drain (~20 us) per 4 steps of 2.6-3.9 ms. RDX_EOS_POLL overrides (tools/eos_time.py)
+        static const int check_every = [] { const char* e = getenv("RDX_EOS_POLL"); const int v = e ? atoi(e) : 4; return v > 0 ? v : 4; }();
         while (done < max_new) {
             if (use_graph) {
                 HIPCHK(c, hipGraphLaunch(c->graph, c->stream));

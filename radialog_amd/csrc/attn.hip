@@ -329,7 +329,11 @@ __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* 
                 ko[e] = fromf<T>(rope_one<T>(k8[e], kp, c, sn));
             }
             stg16(qout + row * H + n0, as_u4<T>(qo));
-            stg16(kcache + ((size_t)b * d.heads + hh) * d.max_len * D + kperm(slot0 + t, dd, d.k_perm), as_u4<T>(ko));     // fragment order per 16 positions
+            // (dd re-derived behind an opaque move: its loop-invariant kperm() address part was hoisted into a register the 128-register build then
+            // spilled, and the reload inside the token loop came with an s_waitcnt vmcnt(0) -- round 5: no scratch)
+            int dd_k = dd;
+            asm volatile("" : "+v"(dd_k));
+            stg16(kcache + ((size_t)b * d.heads + hh) * d.max_len * D + kperm(slot0 + t, dd_k, d.k_perm), as_u4<T>(ko));     // fragment order per 16 positions
         }
     }
 }

@@ -147,7 +147,6 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
     }
     const int slot = a.slot_b[b];
     const int nk = slot + 1;
-    const int km_new = km[min(slot, d.max_len - 1)];   // mask byte of the new position, off the critical path
     long long* trc = (a.trace && h == 0 && b == 0 && tid == 0) ? a.trace : nullptr;
 #define ATT_T(i) do { if (trc) trc[i] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
     ATT_T(0);
@@ -155,10 +154,9 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
     ATT_T(1);
 
     // ---- new token (wave 0 only, in registers): LoRA add + RoPE for dims doct*8 .. +8 of this head -------------------
-    float q8n[8], k8[8], v8[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { q8n[e] = 0.f; k8[e] = 0.f; v8[e] = 0.f; }
+    float s_new = 0.f;                            // wave 0: q . k of the new position (fp32 sum, rounded where it is stored)
     if (w == 0) {
+        float q8n[8], k8[8], v8[8];
         if (HAS_WAIT) load_newtok();
         const V8 qv = as_vec8<T>(nq), kv = as_vec8<T>(nk_), vv = as_vec8<T>(nv), cv = as_vec8<T>(ncos), sv_ = as_vec8<T>(nsin);
 #pragma unroll
@@ -197,6 +195,19 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
             *reinterpret_cast<u4*>(qT + doct * 8) = as_u4<T>(qo);
             stg16(kc + kperm(slot, doct * 8, d.k_perm), as_u4<T>(ko));      // K rows live in the 16-position fragment order (rdx_common.h)
             stg16(vc + (size_t)slot * D + doct * 8, as_u4<T>(vo));
+            // the new row's V (fp32) waits in wave 0's own slice of `part` until P.V: the same lanes read it back, and only then does wave 0
+            // overwrite the slice with its partial output -- LDS serves a wave's operations in order, no barrier involved
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part[doct * 8 + e] = v8[e];
+        }
+        // q . k of the new position, finished HERE: q8n / k8 / v8 (24 registers in every wave of the launch, used by wave 0 only) are dead
+        // before the cache phases start -- they used to stay live through scores, softmax and P.V, and at the 128-register cap of the
+        // 4-workgroups-per-CU and 16-wave builds the allocator spilled three to five dwords around them (round 5: no scratch)
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc += q8n[e] * k8[e];
+            s_new = row16_sum(acc);
         }
     }
     if (owns_rows) {                             // upper half of the window, now that the context length is known
@@ -209,6 +220,7 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
 
     // ---- scores: S[j] = T(T(k_j . q) / sqrt(D)) on the matrix cores ----------------------------------------------------------
     const float div = sqrtf((float)D);
+    const int km_new = km[min(slot, d.max_len - 1)];   // mask byte of the new position: requested here, consumed behind the cached groups' scores
     u4 qb[4];                                    // B operand: q[32c + 8g .. +8], the same in all 16 columns
 #pragma unroll
     for (int c = 0; c < 4; ++c) qb[c] = *reinterpret_cast<const u4*>(qT + c * 32 + g * 8);
@@ -250,13 +262,7 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
             if (two) score_group(kf[1], mw[1], (gi + CW) * 16);      // positions >= slot are not stored
         }
     }
-    if (w == 0) {                                                               // the new position itself
-        float acc = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc += q8n[e] * k8[e];
-        acc = row16_sum(acc);
-        if (lane == 0) S[slot] = km_new ? rnd<T>(rnd<T>(acc) / div) : -INFINITY;
-    }
+    if (w == 0 && lane == 0) S[slot] = km_new ? rnd<T>(rnd<T>(s_new) / div) : -INFINITY;      // the new position itself
     __syncthreads();
     ATT_T(4);
 
@@ -330,7 +336,7 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
     if (w == 0 && jsub == 0) {
         const float p = rnd<T>(expf(S[slot] - mx) / sum);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o8[e] += p * v8[e];
+        for (int e = 0; e < 8; ++e) o8[e] += p * part[doct * 8 + e];
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) o8[e] = xor32_sum(xor16_sum(o8[e]));

@@ -236,7 +236,7 @@ class LlamaForCausalLM:
                                                 mask=attention_mask, output_scores=output_scores,
                                                 reuse_prefix=bool(getattr(self, "reuse_prefix_kv", False)) and attention_mask is None)
         toks = toks[:, :n].to(torch.int64)
-        # HF stops as soon as every row has emitted EOS; the engine checks every 16 steps, so trim the all-pad tail
+        # HF stops as soon as every row has emitted EOS; the engine polls every 4th step (api_llama.hip decode_loop), so trim the all-pad tail
         if eos >= 0 and n > 0:
             done = (toks == eos).cumsum(1).clamp(max=1)
             if bool(done[:, -1].all()):

@@ -66,3 +66,47 @@ def test_lds_dma_loops_hold_no_compiler_drain(unit, families, tmp_path):
     assert all(seen.values()), f"no LDS-DMA + MFMA loop found in {[f for f, n in seen.items() if not n]}: the scan no longer matches the code"
     assert not offenders, f"compiler-inserted vmcnt(0) in front of LDS fragment reads: {offenders[:4]}"
     shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+def _asm(unit, tmp_path):
+    out = tmp_path / (unit + ".s")
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", "-I" + CSRC, os.path.join(CSRC, unit), "-o", str(out)]
+    p = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path))
+    assert p.returncode == 0 and out.exists(), p.stderr[-2000:]
+    return out.read_text()
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_fp8_prefill_mfma_is_the_unscaled_encoding(tmp_path):
+    """gemm8.hip passes constant-zero scale operands to __builtin_amdgcn_mfma_scale_f32_*_f8f6f4 and relies on hipcc selecting the
+    UNSCALED f8f6f4 encoding (hardware scale 1.0). A toolchain that emitted the scaled form with E8M0 code 0 (= 2^-127) would make every fp8
+    prefill output collapse to ~0 and only the GPU tests would notice: pin the instruction selection at build time."""
+    asm = _asm("gemm8.hip", tmp_path)
+    n_f8 = len(re.findall(r"\bv_mfma_f32_(?:32x32x64|16x16x128)_f8f6f4\b", asm))
+    assert n_f8 > 100, f"the fp8 prefill kernels no longer use the f8f6f4 MFMAs ({n_f8} found)"
+    scaled = re.findall(r"\bv_mfma_scale_\w+|\bv_mfma_ld_scale\w*", asm)
+    assert not scaled, f"hipcc selected the block-SCALED MFMA encoding {sorted(set(scaled))[:3]}: with zero scale operands that multiplies by 2^-127"
+    shutil.rmtree(tmp_path, ignore_errors=True)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("unit", ["attn.hip", "chain.hip", "xstat32.hip"])
+def test_decode_kernels_hold_no_scratch(unit, tmp_path):
+    """VERDICT r4 "next" 1c / 7: the decode-step kernels (decode_attention_k, attn_oproj16_k, decode_chain_k, xstat32_k / xsplit32_k) and
+    rope_kv_prefill_k are built at their register caps (128 at four workgroups or sixteen waves per CU, 256 for the activation-stationary GEMMs)
+    and must not spill: a spilled dword comes back through scratch behind an `s_waitcnt vmcnt(0)` that drains the wave's whole K / V / weight
+    window (round 4 carried 8-20 bytes in three of them)."""
+    asm = _asm(unit, tmp_path)
+    sizes = re.findall(r"\.amdhsa_kernel (\S+)|\.amdhsa_private_segment_fixed_size (\d+)", asm)
+    cur, bad, n = None, [], 0
+    for k, sz in sizes:
+        if k:
+            cur = k
+        elif sz:
+            n += 1
+            if int(sz):
+                bad.append((cur, int(sz)))
+    assert n >= 4, "no kernel descriptors found: the scan no longer matches hipcc's assembly"
+    assert not bad, f"kernels with a private (scratch) segment: {bad}"
+    assert "scratch_" not in asm
+    shutil.rmtree(tmp_path, ignore_errors=True)
