@@ -1,0 +1,10 @@
+#!/bin/bash
+# Round 5: the whole-suite run on the GPU box: the whole -m gpu suite (timed), smoke(), the default bench line.
+set -u
+ROOT=$PWD
+export PYTHONPATH=$ROOT TMPDIR=/tmp
+OUT=$ROOT/gpurun_out/r05full
+mkdir -p $OUT
+( time python -m pytest tests/ -x -q -m gpu --durations=12 ) > $OUT/pytest_gpu.log 2>&1; echo "rc $?" >> $OUT/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc $?" >> $OUT/smoke.log
+python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc $?" >> $OUT/bench.err
