@@ -100,6 +100,29 @@ void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split) {
     }
 }
 
+bool xs16_ok(rdx_ctx* c, int B) {
+    if (!c->xs16 || !xs16_rows_ok(B) || c->ll.empty()) return false;
+    const rdx_config& f = c->cfg;
+    const LlamaLayer& L = c->ll[0];
+    GemmArgs q = gargs(c->dx, f.hidden, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); q.N = L.wqkv.Npad; q.norm_w = L.attn_norm;
+    GemmArgs gu = gargs(c->dx, f.hidden, L.wgu, nullptr, c->dgu, f.inter, B); gu.norm_w = L.mlp_norm;
+    GemmArgs lm = gargs(c->dx, f.hidden, c->lm_head, nullptr, nullptr, f.vocab, B); lm.N = c->lm_head.Npad; lm.norm_w = c->final_norm;
+    GemmArgs o = gargs(c->datt, f.hidden, L.wo, nullptr, c->dx, f.hidden, B); o.resid = c->dx; o.ldr = f.hidden; o.xpacked = 1;
+    GemmArgs d = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, f.hidden, B); d.resid = c->dx; d.ldr = f.hidden; d.xpacked = 1;
+    return xstat16_supported(q, EPI_NONE) && xstat16_supported(gu, EPI_SILU_MUL) && xstat16_supported(lm, EPI_LOGITS) && xrow16_supported(o) &&
+           xrow16_supported(d);
+}
+
+void xs16_proj(rdx_ctx* c, GemmArgs a, int epi) {
+    launch_xstat16(c->cfg.dtype, a, epi, c->stream);
+}
+
+void xs16_row(rdx_ctx* c, const void* xpacked, const GemmW& W, int B) {
+    GemmArgs a = gargs(xpacked, W.K, W, nullptr, c->dx, c->cfg.hidden, B);
+    a.resid = c->dx; a.ldr = c->cfg.hidden; a.xpacked = 1;
+    launch_xrow16(c->cfg.dtype, a, c->stream);
+}
+
 void run_gemm(rdx_ctx* c, GemmArgs a, int epi) {
     if (!a.W && a.W8 && a.M > 32) { c->unsupported = "fp8 weights: this GEMM has no fp8 kernel (only the Llama projections are quantised)"; return; }
     ConvGeom cg;

@@ -87,8 +87,15 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
     };
     if (stem_pool_supported(f.v_stem)) {
         // conv1 + bn1 + relu + maxpool in one launch: the 224^2 x 64 stem output never goes to HBM (stem.hip)
-        launch_stem_pool(dt, c->vin, c->v_conv1.w, c->v_conv1_b, c->vbuf[1], B, Hp, Hc, S_ / 4, f.v_stem,
-                         packed ? mtiles((long)B * (S_ / 4) * (S_ / 4)) : 0, s);
+        const long rows0 = (long)B * (S_ / 4) * (S_ / 4);
+        if (packed && (rows0 & 15)) {
+            // the pad rows of the last 16-row tile are MFMA B columns of every consumer: zero them (once per chunk of 32 channels: that tile is
+            // one KiB of [C / 32][tiles][64][8]) instead of feeding whatever the buffer held (448 px has no pad rows, 488 px has)
+            const int mt0 = mtiles(rows0);
+            for (int kc = 0; kc < f.v_stem / 32; ++kc)
+                HIPCHK(c, hipMemsetAsync((char*)c->vbuf[1] + ((size_t)kc * mt0 + (mt0 - 1)) * 1024, 0, 1024, s));
+        }
+        launch_stem_pool(dt, c->vin, c->v_conv1.w, c->v_conv1_b, c->vbuf[1], B, Hp, Hc, S_ / 4, f.v_stem, packed ? mtiles(rows0) : 0, s);
     } else {
         conv_gemm(c, c->vin, c->v_conv1, c->v_conv1_b, nullptr, c->vbuf[0], B, Hp, Hp, 4, 7, 8, 2, 0, Hc, Hc, EPI_RELU);
         launch_maxpool(dt, c->vbuf[0], c->vbuf[1], B, Hc, Hc, f.v_stem, s);

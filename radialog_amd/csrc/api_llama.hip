@@ -32,7 +32,8 @@ static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, c
     a.norm_w = c->final_norm; a.eps = f.rms_eps;
     a.part_val = c->part_val; a.part_idx = c->part_idx;
     a.out_step = out_step; a.out_step_stride = step_stride;
-    skinny(c, a, EPI_LOGITS);
+    if (x == c->dx && xs16_ok(c, B)) xs16_proj(c, a, EPI_LOGITS);        // batch 3-16 decode: the final RMSNorm is the kernel's prologue
+    else skinny(c, a, EPI_LOGITS);
     launch_greedy_step(f.dtype, c->part_val, c->part_idx, c->n_vtiles, B, c->cur_eos, c->cur_pad, c->cur_max_new,
                        c->cur_tokens, c->d_unf, advance ? c->d_pos : nullptr, advance ? c->d_slot : nullptr, c->d_step,
                        c->embed, f.vocab, c->dx, f.hidden, c->d_pos, c->rope_cos, c->rope_sin, c->d_cur_rope,
@@ -198,6 +199,27 @@ bool decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, long step
         ca.dx = c->dx; ca.dqkv = c->dqkv; ca.dgu = c->dgu; ca.ctr = c->d_cctr; ca.err = c->d_err; ca.naps = c->chain_naps;
         const LlamaLayer& L0 = c->ll[0];        // fp8 weights: the chained roles stream the e4m3 bytes too
         ca.w8 = (L0.wqkv.w8 && L0.wdown.w8 && f.hidden % 64 == 0 && f.inter % 64 == 0) ? 1 : 0;
+    }
+    if (!chain && xs16_ok(c, B)) {
+        // batch 3-16 (xs16.hip): five launches per layer -- QKV with the RMSNorm as its prologue, attention (output fragment-packed), o_proj with the
+        // residual epilogue, gate/up with the RMSNorm prologue (SwiGLU output fragment-packed), down_proj with the residual epilogue
+        for (int l = 0; l < f.layers; ++l) {
+            const LlamaLayer& L = c->ll[l];
+            { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps;
+              xs16_proj(c, a, EPI_NONE); }
+            DecAttnArgs at;
+            at.d = c->ld; at.qkv = c->dqkv; at.lbq = L.lora_bq; at.lbv = L.lora_bv; at.cos_t = c->rope_cos; at.sin_t = c->rope_sin;
+            at.pos = c->d_pos; at.slot_b = c->d_slot; at.key_mask = c->key_mask; at.cur_rope = c->d_cur_rope;
+            at.kcache = kv_ptr(c, c->kcache, l); at.vcache = kv_ptr(c, c->vcache, l); at.out = c->datt;
+            at.out_packed = 1;
+            launch_decode_attention(dt, at, B, s);
+            xs16_row(c, c->datt, L.wo, B);
+            { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; a.out_packed = 1;
+              xs16_proj(c, a, EPI_SILU_MUL); }
+            xs16_row(c, c->dgu, L.wdown, B);
+        }
+        lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
+        return false;
     }
     for (int l = 0; l < f.layers; ++l) {
         const LlamaLayer& L = c->ll[l];

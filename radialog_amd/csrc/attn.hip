@@ -230,16 +230,16 @@ void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s)
     dim3 grid((a.Tq + 15) / 16, a.H, a.B), block(256);
     RDX_DISPATCH_T(dtype, T, {
         if (head_dim == 128) {
-            static bool attr128 = false;
-            if (!attr128) { hipFuncSetAttribute((const void*)attention_k<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr128 = true; }
+            static DevOnce attr128;
+            if (attr128.first()) { hipFuncSetAttribute((const void*)attention_k<T, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
             hipLaunchKernelGGL((attention_k<T, 128>), grid, block, smem, s, a, TkP);
         } else if (head_dim == 32) {
-            static bool attr32 = false;
-            if (!attr32) { hipFuncSetAttribute((const void*)attention_k<T, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr32 = true; }
+            static DevOnce attr32;
+            if (attr32.first()) { hipFuncSetAttribute((const void*)attention_k<T, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
             hipLaunchKernelGGL((attention_k<T, 32>), grid, block, smem, s, a, TkP);
         } else {
-            static bool attr64 = false;
-            if (!attr64) { hipFuncSetAttribute((const void*)attention_k<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr64 = true; }
+            static DevOnce attr64;
+            if (attr64.first()) { hipFuncSetAttribute((const void*)attention_k<T, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }
             hipLaunchKernelGGL((attention_k<T, 64>), grid, block, smem, s, a, TkP);
         }
     });

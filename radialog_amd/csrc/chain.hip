@@ -320,11 +320,10 @@ void launch_decode_chain(int dtype, ChainArgs ca, bool with_next_qkv, hipStream_
     const size_t smem = sm_gemm > (size_t)84 * 1024 ? sm_gemm : (size_t)84 * 1024;
     dim3 grid(ca.nwg_down + nwg_qkv), block(CH_THREADS);
     RDX_DISPATCH_T(dtype, T, {
-        static bool attr_set = false;
-        if (!attr_set) {
+        static DevOnce attr_set;
+        if (attr_set.first()) {
             hipFuncSetAttribute((const void*)decode_chain_k<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
             hipFuncSetAttribute((const void*)decode_chain_k<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-            attr_set = true;
         }
         if (ca.w8) hipLaunchKernelGGL((decode_chain_k<T, true>), grid, block, smem, s, ca);
         else hipLaunchKernelGGL((decode_chain_k<T, false>), grid, block, smem, s, ca);

@@ -174,8 +174,8 @@ static void launch_cs(const GemmArgs& a, const ConvGeom& cg, hipStream_t s) {
     const size_t smem = (size_t)NT * KC * 1024 + (size_t)CS_WAVES * 16 * MT * CS_ROWB + (size_t)NT * 16 * sizeof(float);
     int gx = std::max(1, 256 / slices);
     gx = std::min(gx, (tiles + CS_WAVES - 1) / CS_WAVES);
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)conv1x1_stream_k<T, EPI, KC, NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+    static DevOnce attr;
+    if (attr.first()) { hipFuncSetAttribute((const void*)conv1x1_stream_k<T, EPI, KC, NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
     hipLaunchKernelGGL((conv1x1_stream_k<T, EPI, KC, NT, MT>), dim3(gx, slices), dim3(CS_THREADS), smem, s, a, cg, tiles);
 }
 

@@ -401,11 +401,10 @@ static void launch_gemm8_epi(const GemmArgs& a, hipStream_t s) {
         const int MB3 = (a.M + 319) / 320;
         const long c256 = (long)((MB2 * NB2 + 255) / 256) * 256, c320 = (long)((MB3 * NB2 + 255) / 256) * 320;
         constexpr size_t sm8 = (size_t)G8B_NS * 32 * 64 * 16, sm10 = (size_t)G8B_NS * 36 * 64 * 16;   // 128 / 144 KiB
-        static bool attr = false;
-        if (!attr) {
+        static DevOnce attr;
+        if (attr.first()) {
             (void)hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 8, G8B_NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm8);
             (void)hipFuncSetAttribute((const void*)gemm8_256_k<T, EPI, 10, G8B_NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm10);
-            attr = true;
         }
         if (c320 * 115 < c256 * 100) hipLaunchKernelGGL((gemm8_256_k<T, EPI, 10, G8B_NS>), dim3(MB3 * NB2), dim3(512), sm10, s, a);
         else hipLaunchKernelGGL((gemm8_256_k<T, EPI, 8, G8B_NS>), dim3(MB2 * NB2), dim3(512), sm8, s, a);
@@ -413,8 +412,8 @@ static void launch_gemm8_epi(const GemmArgs& a, hipStream_t s) {
     }
     const int MB = (a.M + G8_BM - 1) / G8_BM, NB = (a.N + G8_BN - 1) / G8_BN;
     const size_t smem = (size_t)2 * 2 * 16 * 64 * sizeof(u4);           // 64 KiB
-    static bool attr1 = false;
-    if (!attr1) { hipFuncSetAttribute((const void*)gemm8_k<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr1 = true; }
+    static DevOnce attr1;
+    if (attr1.first()) { hipFuncSetAttribute((const void*)gemm8_k<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
     hipLaunchKernelGGL((gemm8_k<T, EPI>), dim3(MB * NB), dim3(256), smem, s, a);
 }
 

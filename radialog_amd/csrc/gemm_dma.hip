@@ -383,19 +383,17 @@ static void launch_dma_epi(const GemmArgs& a_in, float* ws, size_t ws_floats, hi
             const long c256 = (long)((MB2 * NB2 + 255) / 256) * 256, c320 = (long)((MB3 * NB2 + 255) / 256) * 320;
             if (allow320 && c320 * 115 < c256 * 100) {
                 const size_t smem3 = (size_t)G2_NS * (16 + 20) * 64 * sizeof(u4);   // 144 KiB
-                static bool attr3 = false;
-                if (!attr3) {
+                static DevOnce attr3;
+                if (attr3.first()) {
                     hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 10, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem3);
-                    attr3 = true;
                 }
                 hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 10, 1>), dim3(MB3 * NB2), dim3(512), smem3, s, a);
                 return;
             }
             const size_t smem2 = (size_t)G2_NS * 2 * 16 * 64 * sizeof(u4);   // 128 KiB
-            static bool attr2 = false;
-            if (!attr2) {
+            static DevOnce attr2;
+            if (attr2.first()) {
                 hipFuncSetAttribute((const void*)gemm_dma256_k<T, EPI, 8, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem2);
-                attr2 = true;
             }
             hipLaunchKernelGGL((gemm_dma256_k<T, EPI, 8, 1>), dim3(MB2 * NB2), dim3(512), smem2, s, a);
             return;
@@ -413,19 +411,17 @@ static void launch_dma_epi(const GemmArgs& a_in, float* ws, size_t ws_floats, hi
     const size_t smem = (size_t)2 * 2 * 16 * 64 * sizeof(u4);       // 64 KiB
     dim3 grid(blocks, 1, splits), block(256);
     if (splits > 1) {
-        static bool attr = false;
-        if (!attr) {
+        static DevOnce attr;
+        if (attr.first()) {
             hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            attr = true;
         }
         hipLaunchKernelGGL((gemm_dma_k<T, EPI, true>), grid, block, smem, s, a, ws, per, ConvGeom(), nullptr);
         const size_t total = (size_t)a.M * (a.N >> 2);
         hipLaunchKernelGGL((splitk_reduce_k<T, EPI>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, ws, splits);
     } else {
-        static bool attr = false;
-        if (!attr) {
+        static DevOnce attr;
+        if (attr.first()) {
             hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-            attr = true;
         }
         hipLaunchKernelGGL((gemm_dma_k<T, EPI, false>), grid, block, smem, s, a, nullptr, nsteps, ConvGeom(), nullptr);
     }
@@ -462,11 +458,10 @@ static void launch_dma_conv_epi(const GemmArgs& a, const ConvGeom& cg, const voi
     }
     const int per = (nsteps + splits - 1) / splits;
     splits = (nsteps + per - 1) / per;
-    static bool attr = false;
-    if (!attr) {
+    static DevOnce attr;
+    if (attr.first()) {
         hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipFuncSetAttribute((const void*)gemm_dma_k<T, EPI, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        attr = true;
     }
     if (splits > 1) {
         hipLaunchKernelGGL((gemm_dma_k<T, EPI, true, true>), dim3(blocks, 1, splits), dim3(256), smem, s, a, ws, per, cg, zero16);

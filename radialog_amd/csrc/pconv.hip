@@ -30,6 +30,8 @@
 #include <algorithm>
 #include <stdlib.h>
 
+#include <stdio.h>
+#include <stdlib.h>
 #include "rdx_common.h"
 #include "rdx_kernels.h"
 
@@ -448,6 +450,8 @@ static void launch_pc1(const PConvArgs& a, int taps, int stride, bool rowout, in
 }
 
 void launch_pconv(int dtype, PConvArgs a, int taps, int stride, int epi, bool rowout, hipStream_t s) {
+    // a 1 x 1 stride-1 convolution reads input tile mt for output tile mt (no gather): the two tensors must have the same tiling
+    if (taps == 1 && stride == 1 && a.mt_in != a.mt_out) { fprintf(stderr, "launch_pconv: mt_in %d != mt_out %d for a 1 x 1 stride-1 convolution\n", a.mt_in, a.mt_out); abort(); }
     a.clog = ilog2(a.Cin / 32);
     int mtw = 1, ntw = 2, ks = 1;
     pconv_pick(a, taps, &mtw, &ntw, &ks);

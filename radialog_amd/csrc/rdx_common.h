@@ -176,6 +176,15 @@ __host__ __device__ __forceinline__ size_t packed_elems(int n, int k) { return (
 }  // namespace rdx
 
 // ---- host side ---------------------------------------------------------------------------------------------------
+// hipFuncSetAttribute is per DEVICE: a process may own contexts on several GPUs (one per GPU is the rule, but nothing enforces it), so the
+// "set once" guards of the launchers are keyed by the current device
+namespace rdx {
+struct DevOnce {
+    bool done[64] = {};
+    bool first() { int d = 0; (void)hipGetDevice(&d); d &= 63; if (done[d]) return false; done[d] = true; return true; }
+};
+}  // namespace rdx
+
 #define RDX_DISPATCH_T(dt, T, ...)                         \
     do {                                                   \
         if ((dt) == rdx::DT_F16) { typedef rdx::f16 T; __VA_ARGS__; } \

@@ -91,6 +91,8 @@ struct rdx_ctx {
                                      // ONE 16-wave launch with a fence-free hand-off (chain.hip: attn_oproj16_k)
     bool chain_mlp = true;           // RDX_CHAIN=0 (tests): one kernel per unit. Default at batch <= 2: down(l) -> QKV(l+1) as one chained
                                      // launch, one workgroup per CU (chain.hip: decode_chain_k)
+    bool xs16 = true;                // batch 3-16 decode on the one-row-tile family (xs16.hip: norm-prologue projections + un-split o_proj / down, 5 launches
+                                     // per layer); RDX_XS16=0 at create / rdx_set_option("xs16", 0): the 32-row family of xstat32.hip (7 launches; A/B leg of the tests)
     int chain_naps = 1;              // poll back-off of the chained launch (x s_sleep(8) between polls)
     GemmW cls_fc1, cls_fc2; const float *cls_fc1_b = nullptr, *cls_fc2_b = nullptr;   // findings classifier head
     void *cls_pooled = nullptr, *cls_h = nullptr, *cls_out = nullptr;
@@ -162,6 +164,10 @@ void skinny(rdx_ctx* c, GemmArgs a, int epi);
 bool down_split_ok(rdx_ctx* c, const LlamaLayer& L, int B);
 void launch_ksplit(rdx_ctx* c, const GemmArgs& a);
 void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split);
+// batch 3-16, model-dtype weights, hidden 4096: the decode step's projections on xs16.hip (no stand-alone RMSNorm, no K-split slabs)
+bool xs16_ok(rdx_ctx* c, int B);
+void xs16_proj(rdx_ctx* c, GemmArgs a, int epi);          // a.norm_w set, a.X = the row-major residual stream
+void xs16_row(rdx_ctx* c, const void* xpacked, const GemmW& W, int B);     // dx += T(xpacked . W^T), in place
 void run_gemm(rdx_ctx* c, GemmArgs a, int epi);
 void conv_gemm(rdx_ctx* c, const void* X, const GemmW& W, const float* bias, const void* resid, void* out, int B,
                int Hin, int Win, int Cin, int KH, int KW, int stride, int pad, int Hout, int Wout, int epi);

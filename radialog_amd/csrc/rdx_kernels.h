@@ -99,6 +99,14 @@ void launch_xstat32(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 int xsplit32_groups(const GemmArgs& a);
 void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s);
 int xs_min_rows();        // smallest batch on the xstat32 / xsplit32 path (3)
+// batch 3-16 decode (xs16.hip): activation-stationary K = 4096 projection over ONE row tile with the RMSNorm as its prologue (a.norm_w: X is the
+// row-major residual stream; otherwise X is the fragment-packed 32-row block, xpacked 1), and the un-split o_proj / down_proj with the residual
+// epilogue (X fragment-packed, xpacked 1; resid / out row-major)
+bool xs16_rows_ok(int M);
+bool xstat16_supported(const GemmArgs& a, int epi);
+void launch_xstat16(int dtype, const GemmArgs& a, int epi, hipStream_t s);
+bool xrow16_supported(const GemmArgs& a);
+void launch_xrow16(int dtype, const GemmArgs& a, hipStream_t s);
 void launch_tiled_gemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, hipStream_t s);
 // LDS-DMA GEMM for plain row-major activations (M > 32, K % 64 == 0); `ws` = fp32 split-K workspace (nullable)
 bool gemm_dma_supported(const GemmArgs& a);

@@ -119,8 +119,8 @@ void launch_stem_pool(int dtype, const void* in, const void* Wp, const float* bi
     RDX_DISPATCH_T(dtype, T, {
         if (stem == 64) {
             const size_t smem = (size_t)ST_CR * ST_SEG * 16 * (64 + 8) * sizeof(T);
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)stem_pool_k<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+            static DevOnce attr;
+            if (attr.first()) { (void)hipFuncSetAttribute((const void*)stem_pool_k<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
             hipLaunchKernelGGL((stem_pool_k<T, 4>), grid, block, smem, s, (const T*)in, (const u4*)Wp, bias, (T*)out, Hp, Hc, Ho, packed_mt);
         } else {
             const size_t smem = (size_t)ST_CR * ST_SEG * 16 * (32 + 8) * sizeof(T);

@@ -242,8 +242,8 @@ template <typename T, int EPI, int NT, int MT, int WAVES, bool CONV>
 static void launch_ws_cfg(const GemmArgs& a, const ConvGeom& cg, const void* zero16, hipStream_t s) {
     const int MB = (a.M + WAVES * 16 * MT - 1) / (WAVES * 16 * MT), NB = (a.N + NT * 16 - 1) / (NT * 16);
     const size_t smem = std::max((size_t)3 * NT * 2 * 1024, (size_t)WAVES * 16 * MT * WS_ROWB);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)wsgemm_k<T, EPI, NT, MT, WAVES, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+    static DevOnce attr;
+    if (attr.first()) { (void)hipFuncSetAttribute((const void*)wsgemm_k<T, EPI, NT, MT, WAVES, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
     hipLaunchKernelGGL((wsgemm_k<T, EPI, NT, MT, WAVES, CONV>), dim3(MB * NB), dim3(WAVES * 64), smem, s, a, cg, zero16);
 }
 

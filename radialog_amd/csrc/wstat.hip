@@ -200,8 +200,8 @@ template <typename T, int EPI, int NT, int WAVES, int CPW, int RING>
 static void launch_ws1(const GemmArgs& a, hipStream_t s) {
     const int ntiles = (a.N + 15) >> 4;
     const size_t smem = (size_t)4 * WAVES * NT * 256 * sizeof(float);
-    static bool attr = false;
-    if (!attr && smem > 48 * 1024) { (void)hipFuncSetAttribute((const void*)wstat_k<T, EPI, NT, WAVES, CPW, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+    static DevOnce attr;
+    if (smem > 48 * 1024 && attr.first()) { (void)hipFuncSetAttribute((const void*)wstat_k<T, EPI, NT, WAVES, CPW, RING>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
     hipLaunchKernelGGL((wstat_k<T, EPI, NT, WAVES, CPW, RING>), dim3((ntiles + NT - 1) / NT), dim3(WAVES * 64), smem, s, a);
 }
 
