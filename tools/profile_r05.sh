@@ -1,0 +1,41 @@
+#!/bin/bash
+# Round-5 profiling passes (run on the GPU box from the repo root); text summaries only -> gpurun_out/prof/.
+#   bash tools/profile_r05.sh decode     kernel tables of a 256-token decode at batch 16 (xs16 on / off) and batch 32
+#   bash tools/profile_r05.sh bench      kernel table of the default bench command
+#   bash tools/profile_r05.sh pmc        FETCH_SIZE / WRITE_SIZE passes of bench.py at batch 1 / 32 / 32 fp8 (one counter per pass; tools/pmc_to_json.py r05)
+set -u
+ROOT=$PWD
+export PYTHONPATH=$ROOT TMPDIR=/tmp OUT=$ROOT/gpurun_out/prof
+mkdir -p $OUT
+trace() {  # name, iterations (0 = none), command...
+  local name=$1 iters=$2; shift 2
+  rm -rf /tmp/rp_$name
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/rp_$name -o $name --output-format rocpd -- "$@" > /tmp/rp_$name.log 2>&1)
+  local db=$(find /tmp/rp_$name -name "*.db" 2>/dev/null | head -1)
+  if [ -n "$db" ]; then python $ROOT/tools/prof_summary.py $db $OUT/$name.md $iters > /dev/null; else tail -5 /tmp/rp_$name.log > $OUT/$name.md; fi
+  grep -E "^\{|ms/img|prefill B|^decode B" /tmp/rp_$name.log | tail -1 | cut -c1-600 >> $OUT/$name.md
+}
+pmc1() {  # run tag, counter, bench args...
+  local tag=$1 ctr=$2; shift 2
+  rm -rf /tmp/pmc_${tag}_$ctr
+  (cd /tmp && rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_${tag}_$ctr -o pmc --output-format rocpd -- python $ROOT/bench.py "$@" > /tmp/pmc_${tag}_$ctr.log 2>&1)
+  local db=$(find /tmp/pmc_${tag}_$ctr -name "*.db" 2>/dev/null | head -1)
+  if [ -n "$db" ]; then python $ROOT/tools/pmc_summary.py $db > $OUT/pmc_${tag}_$ctr.txt 2>&1; else tail -8 /tmp/pmc_${tag}_$ctr.log > $OUT/pmc_${tag}_$ctr.txt; fi
+}
+what=${1:-decode}
+if [ $what = decode ]; then
+  trace dec_b16_xs16 0 python $ROOT/tools/decode_only.py 16 256 1
+  trace dec_b16_old 0 python $ROOT/tools/decode_only.py 16 256 0
+  trace dec_b32 0 python $ROOT/tools/decode_only.py 32 256 1
+fi
+if [ $what = bench ]; then
+  trace bench_default 0 python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
+fi
+if [ $what = pmc ]; then
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    pmc1 b1 $ctr --steps 1 --warmup 0 --new-tokens 64 --no-cpu-baseline --no-b32 --no-fp8 --no-f16 --no-enc256
+    pmc1 b32 $ctr --batch 32 --steps 1 --warmup 0 --new-tokens 256 --no-cpu-baseline
+    pmc1 b32fp8 $ctr --batch 32 --fp8 --steps 1 --warmup 0 --new-tokens 256 --no-cpu-baseline
+  done
+fi
+du -sh $OUT
