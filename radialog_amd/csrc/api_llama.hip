@@ -135,6 +135,10 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
     auto prompt_gemm = [&](GemmArgs a, int epi, bool packed_out) {
         if (!ws) { run_gemm(c, a, epi); return; }
         a.xpacked = 3; a.mtiles = mtl; a.out_packed = packed_out ? 3 : 0;
+        // round 5: up to 192 rows the K = 4096 projections run activation-stationary in row blocks of 32 whose workgroups share an XCD's L2
+        // (xstat32_k<.., BLK>: the weights cross each CU once per row block instead of the activations once per 32 columns); down_proj
+        // (K = 11008) and longer prompts keep the weight-stationary kernel
+        if (c->prompt_blk && xstat_blk_supported(a, epi)) { launch_xstat_blk(dt, a, epi, s); return; }
         launch_wstat(dt, a, epi, s);
     };
     for (int l = 0; l < f.layers; ++l) {

@@ -99,6 +99,9 @@ void launch_xstat32(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 int xsplit32_groups(const GemmArgs& a);
 void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s);
 int xs_min_rows();        // smallest batch on the xstat32 / xsplit32 path (3)
+// one prompt's K = 4096 projections in row blocks of 32, the row blocks of a tile walker sharing an XCD's L2 (xstat32_k<.., BLK>): X xpacked 3
+bool xstat_blk_supported(const GemmArgs& a, int epi);
+void launch_xstat_blk(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 // batch 3-16 decode (xs16.hip): activation-stationary K = 4096 projection over ONE row tile with the RMSNorm as its prologue (a.norm_w: X is the
 // row-major residual stream; otherwise X is the fragment-packed 32-row block, xpacked 1), and the un-split o_proj / down_proj with the residual
 // epilogue (X fragment-packed, xpacked 1; resid / out row-major)

@@ -33,9 +33,14 @@ __device__ __forceinline__ v4f xs_mfma8(const u4& a, const u4& b, v4f c) {
 // A8 (with W8): the activations arrive as e4m3 bytes in the 64-deep fragment order (xpacked 4, written by rmsnorm4096_k<T, 4> with one scale per
 // row): a piece is 16 bytes per lane like a weight piece, two fp8 MFMAs per pair, half the activation registers and half the start-up fetch;
 // the fp32 sum is scaled by wscale[n] * xscale[m] in the epilogue.
-template <typename T, int EPI, bool W8, bool A8 = false>
+// BLK (round 5: ONE prompt's prefill, M <= 192 rows): the rows are cut into blocks of 32 and every (tile walker, row block) pair is a workgroup of
+// its own -- the NB row-block workgroups of a walker sit on the SAME XCD (workgroup ids are dealt round-robin over the 8 XCDs: id % 8) and walk the
+// same tile sequence, so a weight fragment comes from HBM once and from that XCD's L2 NB - 1 times. X is the prompt's fragment-packed
+// [k / 32][mtiles][lane][8] (xpacked 3, what rmsnorm_k<T, 3> / attention_k / the SwiGLU epilogue write); row block mb reads row tiles 2 mb, 2 mb + 1.
+template <typename T, int EPI, bool W8, bool A8 = false, bool BLK = false>
 __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
     static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
+    static_assert(!BLK || !W8, "the row-block mode is model-dtype only");
     constexpr int TPI = W8 ? 2 : 1;                   // tiles per trip
     constexpr int LPT = W8 ? XS_CPW / 2 : XS_CPW;     // 16-byte weight loads per wave per tile
     constexpr int RING = TPI * LPT;                   // 16
@@ -45,9 +50,15 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
     const int lane = threadIdx.x & 63, wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int ntiles = (a.N + 15) >> 4;
-    const int G = gridDim.x;
-    const int ngroups = (ntiles + TPI - 1) / TPI;     // trips in total; this workgroup takes blockIdx, blockIdx + G, ...
-    const int nit = (ngroups - (int)blockIdx.x + G - 1) / G;
+    // walker id and walker count: plain mode = the grid; BLK: id = 8 slot + xcd, the 32 slots of an XCD are WPX walkers x NB row blocks
+    int wid = (int)blockIdx.x, G = (int)gridDim.x, mb = 0;
+    if (BLK) {
+        const int NB = (a.mtiles + 1) >> 1, WPX = 32 / NB, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3;
+        if (slot >= WPX * NB) return;
+        wid = xcd * WPX + slot / NB; mb = slot % NB; G = 8 * WPX;
+    }
+    const int ngroups = (ntiles + TPI - 1) / TPI;     // trips in total; this workgroup takes wid, wid + G, ...
+    const int nit = (ngroups - wid + G - 1) / G;
     if (nit <= 0) return;
     // debug timeline (rdx_gemv_trace): 0 entry, 1 first trip's K loop done, 2 first trip done, 3 last trip begins, 4 its K loop done, 5 end
     long long* trc = (a.trace && threadIdx.x == 0) ? a.trace + (size_t)blockIdx.x * 8 : nullptr;
@@ -60,7 +71,7 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
 
     u4 ring[RING];
     {
-        const int t0 = (int)blockIdx.x * TPI;
+        const int t0 = wid * TPI;
 #pragma unroll
         for (int q = 0; q < TPI; ++q) {
             const u4* wp = tile_ptr(t0 + q);
@@ -85,6 +96,10 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
             const u4* x8 = reinterpret_cast<const u4*>(a.X) + (size_t)((wa * (XS_CPW / 2)) * 2 + mt) * 64 + lane;
 #pragma unroll
             for (int c = 0; c < NXF; ++c) xf[mt][c] = ldg16(x8 + (size_t)c * 128);
+        } else if (BLK) {
+            const int mtg = min(2 * mb + mt, a.mtiles - 1);             // a ragged last block re-reads the last row tile (its rows are never stored)
+#pragma unroll
+            for (int c = 0; c < NXF; ++c) xf[mt][c] = ldg16(X + ((size_t)(((wa * XS_CPW + c) * a.mtiles + mtg) * 64 + lane) << 3));
         } else {
             const T* xr = xp ? X + (size_t)(((wa * XS_CPW) * 2 + mt) * 64 + lane) * 8
                              : X + (size_t)min(mt * 16 + r, a.M - 1) * a.ldx + wa * (XS_CPW * 32);
@@ -103,11 +118,11 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
     if (a.out_step && out) out += (size_t)(*a.out_step) * a.out_step_stride;
 
     // epilogue coordinates of this thread: one output per tile of the trip; idx = m_local * 16 + n_local
-    const int e_mt = threadIdx.x >> 8, e_idx = threadIdx.x & 255, e_m = e_mt * 16 + (e_idx >> 4), e_nl = e_idx & 15;
+    const int e_mt = threadIdx.x >> 8, e_idx = threadIdx.x & 255, e_m = (BLK ? 32 * mb : 0) + e_mt * 16 + (e_idx >> 4), e_nl = e_idx & 15;
 
     auto trip = [&](int it, auto pf_tag) {
         constexpr bool PF = decltype(pf_tag)::value;
-        const int grp = (int)blockIdx.x + it * G, t0 = grp * TPI;
+        const int grp = wid + it * G, t0 = grp * TPI;
         // operands the epilogue needs come first in the (in-order) load queue, ahead of the ring refills
         float e_res[TPI], e_sc[TPI], e_bias[TPI];
         const float e_xs = A8 ? a.xscale[e_m] : 1.f;                   // xscale[32]: one per row of the block (rows >= M: 1)
@@ -173,7 +188,13 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
             } else if (EPI == EPI_SILU_MUL) {
                 // rows 0-7 of a tile are gate, 8-15 the matching up rows: the partner sits 8 lanes away in the same DPP row
                 const float u = dpp_mov<DPP_ROR8>(v);
-                if (a.out_packed) {
+                if (BLK && a.out_packed) {
+                    // the prompt's fragment-packed [k / 32][mtiles][lane][8] (out_packed 3: what wstat_k / this kernel's BLK mode read)
+                    const int mtg = 2 * mb + e_mt;
+                    if (e_nl < 8 && t_o < ntiles && mtg < a.mtiles)
+                        out[((((size_t)(t_o >> 2) * a.mtiles + mtg) * 64 + (t_o & 3) * 16 + (e_idx >> 4)) << 3) + e_nl] =
+                            e_m < a.M ? fromf<T>(swiglu<T>(v, u)) : fromf<T>(0.f);
+                } else if (a.out_packed) {
                     // fragment-packed [f = k / 32][mt][lane (g = (k % 32) / 8, r = m % 16)][8] for the K-split consumer (xsplit32_k):
                     // this tile's 8 outputs k = 8 t_o .. + 8 of row m are one lane's 16-byte piece; rows >= M are zero-filled
                     // (out_packed 2, fp8 consumer: the 64-deep order -- piece t_o is fragment 2 (t_o / 8) + (t_o & 1), g = (t_o & 7) / 2)
@@ -447,6 +468,23 @@ static void launch_xstat32_t(const GemmArgs& a, int epi, hipStream_t s) {
         case EPI_LOGITS: hipLaunchKernelGGL((xstat32_k<T, EPI_LOGITS, W8, A8>), grid, block, smem, s, a); break;
         default: break;
     }
+}
+
+// ONE prompt's projections (K = 4096) in row blocks of 32: see BLK above. X fragment-packed (xpacked 3, a.mtiles row tiles), epilogues NONE / RESID /
+// SILU_MUL (out_packed 3: the same packed order for the next projection). Every XCD runs 32 / NB walkers with NB = ceil(mtiles / 2) row blocks each.
+bool xstat_blk_supported(const GemmArgs& a, int epi) {
+    return a.xpacked == 3 && a.mtiles >= 1 && a.mtiles <= 12 && a.M <= a.mtiles * 16 && a.M > (a.mtiles - 1) * 16 && a.K == XS_K && a.W && !a.W8 && !a.norm_w &&
+           !a.bias && (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL) && (a.out_packed == 0 || (a.out_packed == 3 && epi == EPI_SILU_MUL)) &&
+           (a.N + 15) / 16 >= 128;
+}
+
+void launch_xstat_blk(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
+    const size_t smem = (size_t)2 * XS_WAVES * 2 * 256 * 4;
+    RDX_DISPATCH_T(dtype, T, {
+        if (epi == EPI_NONE) hipLaunchKernelGGL((xstat32_k<T, EPI_NONE, false, false, true>), dim3(256), dim3(XS_THREADS), smem, s, a);
+        else if (epi == EPI_RESID) hipLaunchKernelGGL((xstat32_k<T, EPI_RESID, false, false, true>), dim3(256), dim3(XS_THREADS), smem, s, a);
+        else if (epi == EPI_SILU_MUL) hipLaunchKernelGGL((xstat32_k<T, EPI_SILU_MUL, false, false, true>), dim3(256), dim3(XS_THREADS), smem, s, a);
+    });
 }
 
 void launch_xstat32(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
