@@ -61,6 +61,7 @@ def parse(argv=None):
     ap.add_argument("--no-b32", action="store_true", help="skip the configs[2] (batch 32) sub-run of a batch-1 single-GPU bench")
     ap.add_argument("--no-fp8", action="store_true", help="skip the configs[4] (fp8 weights, batch 32) sub-run of a batch-1 bench")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-b64", action="store_true", help="skip the 64-reports-per-GPU sub-run of a batch-1 bench")
     ap.add_argument("--no-f16", action="store_true", help="skip the fp16 (the reference's dtype) timed run of a batch-1 bf16 bench (value_f16)")
     ap.add_argument("--no-enc256", action="store_true", help="skip the batch-256 image-encode timing (enc_b256)")
     return ap.parse_args(argv)
@@ -440,6 +441,14 @@ def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms
                    ms, nb, f"decode_chain_k B={B} {args.dtype}{' fp8' if args.fp8 else ''}")
         except Exception:
             dom = None
+    if dom is None and B > 32:
+        # 33-64 rows (the row-block family): the decode attention is the dominant launch; timed at the mean context of the timed decode
+        eng.generate(ids, out_q, max_new=max(N // 2, 8), eos_id=-1, pad_id=0, use_graph=use_graph)
+        L_ctx = T + max(N // 2, 8)
+        ms_a = eng.time_unit(6, 10)
+        nb_a = B * (2 * L_ctx * H_ * 2 + 2 * H_ * 2 + 3 * H_ * 2 + H_ * 2)
+        dom = (f"decode_attention_k<{args.dtype}> (throughput variant at {B} rows; LoRA-B + RoPE + KV append + softmax.V)", ms_a, nb_a,
+               f"decode_attention_k B={B} {args.dtype}")
     if dom is None:
         ms = eng.time_unit(1, 10)
         wb = wbytes(2 * I_, H_)
@@ -766,6 +775,10 @@ def main():
                            f"batch 32 (global {32 * world}); no reference fp8 path exists -- its oracle is the reference math on the "
                            "same fake-quantised operands (cpu_baseline.parity_fp8 / tests/test_gpu_parity.py), i.e. unpinnable against the reference itself; "
                            "cpu_baseline.fp8_vs_unquantised says what it costs against the un-quantised oracle")
+    if B == 1 and not args.fp8 and not args.no_b64 and not STUB:
+        # round 5: 64 reports per GPU (33-64 decoder rows: the row-block family) -- not a BASELINE configuration (those stop at 32 per GPU): what the
+        # 288 GB of HBM buy when the 13.2 GB weight stream of a decode step is amortised over twice the reports
+        subs["b64"] = (timed_run(64, False, 2, 1), f"per-GPU batch 64 (global {64 * world}): beyond BASELINE configs[2]/[3]'s 32 per GPU, same pipeline, hipGraph step")
     f16_r = None
     if B == 1 and not args.fp8 and args.dtype != "f16" and world == 1 and not args.no_f16 and not STUB:
         # the reference's dtype, in which token identity with the CPU path actually holds (parity_f16): the same configs[1] workload timed in fp16
@@ -843,7 +856,7 @@ def main():
         for rr in [r, f16_r] + [sr for sr, _ in subs.values()]:
             if rr is not None and rr.get("engine") is not None:
                 rr["engine"].close()
-        res["max_batch_per_gpu"] = 32                                       # librdx's decoder holds at most 32 rows per context (api.hip)
+        res["max_batch_per_gpu"] = 64                                       # librdx's decoder holds at most 64 rows per context (rdx_ctx.h RDX_MAX_ROWS)
         cb = res.get("cpu_baseline", {})
         fixtures = [res["token_check"]] + [res[k]["token_check"] for k in subs] + ([res["f16_b1"]["token_check"]] if f16_r is not None else [])
         parity_keys = [k for k in cb if k.startswith("parity")]

@@ -42,7 +42,7 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
             return fail(nullptr, -1, "rdx_create: hidden/inter/qformer_dim must be multiples of 32");
         if (cfg->max_len % 32 || cfg->max_len <= 0 || cfg->max_len > 1536)
             return fail(nullptr, -1, "rdx_create: max_len must be a multiple of 32 in (0, 1536]");
-        if (cfg->max_batch <= 0 || cfg->max_batch > 32) return fail(nullptr, -1, "rdx_create: max_batch must be in [1, 32]");
+        if (cfg->max_batch <= 0 || cfg->max_batch > RDX_MAX_ROWS) return fail(nullptr, -1, "rdx_create: max_batch must be in [1, %d]", RDX_MAX_ROWS);
         if (cfg->lora_r != 0 && cfg->lora_r != 8) return fail(nullptr, -1, "rdx_create: lora_r must be 0 or 8");
     }
     if (cfg->enable_vision) {
@@ -265,10 +265,12 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         c->n_vtiles = c->lm_head.Npad / 16;
         ALLOC(c, c->part_val, (size_t)B * c->n_vtiles * sizeof(float));
         ALLOC(c, c->part_idx, (size_t)B * c->n_vtiles * sizeof(int));
-        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)(B > 2 ? std::max(B, 32) : B) * H * 2);
+        // decode activations between kernels: from batch 3 whole fragment-packed blocks -- 32 rows (xstat32.hip / xs16.hip), or the row tiles of 33-64 rows
+        const int Bp = B > 2 ? std::max(32, (B + 15) / 16 * 16) : B;
+        ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)Bp * H * 2);
         if (B > 2) ALLOC(c, c->kslab, (size_t)4 * 32 * H * sizeof(float)); ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
         ALLOC(c, c->dxs, 32 * sizeof(float));
-        ALLOC(c, c->datt, (size_t)(B > 2 ? std::max(B, 32) : B) * H * 2); ALLOC(c, c->dgu, (size_t)(B > 2 ? std::max(B, 32) : B) * I * 2);
+        ALLOC(c, c->datt, (size_t)Bp * H * 2); ALLOC(c, c->dgu, (size_t)Bp * I * 2);
         ALLOC(c, c->pqe, (size_t)B * 32 * f.qformer_dim * 2); ALLOC(c, c->pimg, (size_t)B * 32 * H * 2);      // image splice rows
     }
     if (f.enable_vision) {

@@ -28,6 +28,7 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
     const int dt = f.dtype, H = f.hidden, B = c->cur_B;
     const bool same_layer = what >= 10;   // what = 10 + k: unit k on layer 0 only (weights stay cache resident)
     if (same_layer) what -= 10;
+    if (B > 32 && what >= 1 && what <= 5) return fail(c, -1, "rdx_time: the per-projection units time the <= 32-row kernel families; at %d rows use unit 0 (step) or 6 (attention)", B);
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0));
     HIPCHK(c, hipEventCreate(&e1));

@@ -32,7 +32,15 @@ static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, c
     a.norm_w = c->final_norm; a.eps = f.rms_eps;
     a.part_val = c->part_val; a.part_idx = c->part_idx;
     a.out_step = out_step; a.out_step_stride = step_stride;
-    if (x == c->dx && xs16_ok(c, B)) xs16_proj(c, a, EPI_LOGITS);        // batch 3-16 decode: the final RMSNorm is the kernel's prologue
+    if (B > 32) {
+        // 33-64 rows: final RMSNorm into the fragment-packed row tiles, lm_head in two row blocks (xstat32_k<EPI_LOGITS, BLK>)
+        if (!blk64_ok(c, B)) { c->unsupported = "more than 32 decoder rows need model-dtype weights at hidden 4096 / inter 11008 (the row-block family)"; return; }
+        const int mtl = (B + 15) / 16;
+        launch_rmsnorm_packed(f.dtype, x, c->final_norm, c->dxn, B, mtl, f.hidden, f.rms_eps, c->stream);
+        a.X = c->dxn; a.norm_w = nullptr; a.xpacked = 3; a.mtiles = mtl;
+        launch_xstat_blk(f.dtype, a, EPI_LOGITS, c->stream);
+    }
+    else if (x == c->dx && xs16_ok(c, B)) xs16_proj(c, a, EPI_LOGITS);        // batch 3-16 decode: the final RMSNorm is the kernel's prologue
     else skinny(c, a, EPI_LOGITS);
     launch_greedy_step(f.dtype, c->part_val, c->part_idx, c->n_vtiles, B, c->cur_eos, c->cur_pad, c->cur_max_new,
                        c->cur_tokens, c->d_unf, advance ? c->d_pos : nullptr, advance ? c->d_slot : nullptr, c->d_step,
@@ -85,6 +93,7 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
     launch_embed_splice(dt, ids, c->d_img_pos, c->embed, f.vocab, c->pimg, 32, c->px, B, T, H, qformer_embs ? 1 : 0, s);
 
     const bool fp8 = fp8_weights(c->ll[0].wqkv);
+    if (B > 32 && !blk64_ok(c, B)) return fail(c, -8, "rdx_prefill: more than 32 rows per context need model-dtype weights at the Vicuna-7B widths (the 33-64 row decode family)");
     if (fp8) {
         // fp8 weights (BASELINE configs[4]): every projection of the prompt is an fp8 x fp8 MFMA GEMM (gemm8.hip) over e4m3 activations with one
         // scale per row and K group -- 1 group behind an RMSNorm (quantised in its epilogue), 2 for o_proj, 4 for down_proj (quant_rows_k on the
@@ -203,6 +212,29 @@ bool decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, long step
         ca.dx = c->dx; ca.dqkv = c->dqkv; ca.dgu = c->dgu; ca.ctr = c->d_cctr; ca.err = c->d_err; ca.naps = c->chain_naps;
         const LlamaLayer& L0 = c->ll[0];        // fp8 weights: the chained roles stream the e4m3 bytes too
         ca.w8 = (L0.wqkv.w8 && L0.wdown.w8 && f.hidden % 64 == 0 && f.inter % 64 == 0) ? 1 : 0;
+    }
+    if (B > 32) {
+        // 33-64 rows: the row-block family (api_dispatch.hip blk64_ok): 7 launches per layer, no K-split slabs
+        if (!blk64_ok(c, B)) { c->unsupported = "more than 32 decoder rows need model-dtype weights at hidden 4096 / inter 11008 (the row-block family)"; return false; }
+        const int mtl = (B + 15) / 16;
+        auto pk = [&](GemmArgs a, int outp) { a.xpacked = 3; a.mtiles = mtl; a.out_packed = outp; return a; };
+        for (int l = 0; l < f.layers; ++l) {
+            const LlamaLayer& L = c->ll[l];
+            launch_rmsnorm_packed(dt, c->dx, L.attn_norm, c->dxn, B, mtl, H, f.rms_eps, s);
+            { GemmArgs a = gargs(c->dxn, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; launch_xstat_blk(dt, pk(a, 0), EPI_NONE, s); }
+            DecAttnArgs at;
+            at.d = c->ld; at.qkv = c->dqkv; at.lbq = L.lora_bq; at.lbv = L.lora_bv; at.cos_t = c->rope_cos; at.sin_t = c->rope_sin;
+            at.pos = c->d_pos; at.slot_b = c->d_slot; at.key_mask = c->key_mask; at.cur_rope = c->d_cur_rope;
+            at.kcache = kv_ptr(c, c->kcache, l); at.vcache = kv_ptr(c, c->vcache, l); at.out = c->datt;
+            at.out_packed = 1; at.out_mt = mtl;
+            launch_decode_attention(dt, at, B, s);
+            { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; launch_xstat_blk(dt, pk(a, 0), EPI_RESID, s); }
+            launch_rmsnorm_packed(dt, c->dx, L.mlp_norm, c->dxn, B, mtl, H, f.rms_eps, s);
+            { GemmArgs a = gargs(c->dxn, H, L.wgu, nullptr, c->dgu, f.inter, B); launch_xstat_blk(dt, pk(a, 3), EPI_SILU_MUL, s); }
+            { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; launch_wstat(dt, pk(a, 0), EPI_RESID, s); }
+        }
+        lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
+        return false;
     }
     if (!chain && xs16_ok(c, B)) {
         // batch 3-16 (xs16.hip): five launches per layer -- QKV with the RMSNorm as its prologue, attention (output fragment-packed), o_proj with the

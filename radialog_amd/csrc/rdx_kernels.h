@@ -171,6 +171,7 @@ struct DecAttnArgs {
     void *kcache, *vcache, *out;
     long long* trace = nullptr;      // debug: 8 timestamps (100 MHz ticks) of workgroup (b=0,h=0)
     int out_packed = 0;              // stand-alone launches, batch 3-32: write `out` fragment-packed for xsplit32_k (attn_body.h)
+    int out_mt = 2;                  // row tiles of that packed block: 2 (the 32-row block), 3-4 for 33-64 rows ([k / 32][out_mt][lane][8], xpacked 3)
 };
 void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s);
 // Chained decode launches of the batch <= 2 step (chain.hip): units run as roles of one launch, chained by a fence-free counter

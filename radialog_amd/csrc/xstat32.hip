@@ -474,7 +474,7 @@ static void launch_xstat32_t(const GemmArgs& a, int epi, hipStream_t s) {
 // SILU_MUL (out_packed 3: the same packed order for the next projection). Every XCD runs 32 / NB walkers with NB = ceil(mtiles / 2) row blocks each.
 bool xstat_blk_supported(const GemmArgs& a, int epi) {
     return a.xpacked == 3 && a.mtiles >= 1 && a.mtiles <= 12 && a.M <= a.mtiles * 16 && a.M > (a.mtiles - 1) * 16 && a.K == XS_K && a.W && !a.W8 && !a.norm_w &&
-           !a.bias && (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL) && (a.out_packed == 0 || (a.out_packed == 3 && epi == EPI_SILU_MUL)) &&
+           !a.bias && (epi == EPI_NONE || epi == EPI_RESID || epi == EPI_SILU_MUL || epi == EPI_LOGITS) && (a.out_packed == 0 || (a.out_packed == 3 && epi == EPI_SILU_MUL)) &&
            (a.N + 15) / 16 >= 128;
 }
 
@@ -484,6 +484,7 @@ void launch_xstat_blk(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
         if (epi == EPI_NONE) hipLaunchKernelGGL((xstat32_k<T, EPI_NONE, false, false, true>), dim3(256), dim3(XS_THREADS), smem, s, a);
         else if (epi == EPI_RESID) hipLaunchKernelGGL((xstat32_k<T, EPI_RESID, false, false, true>), dim3(256), dim3(XS_THREADS), smem, s, a);
         else if (epi == EPI_SILU_MUL) hipLaunchKernelGGL((xstat32_k<T, EPI_SILU_MUL, false, false, true>), dim3(256), dim3(XS_THREADS), smem, s, a);
+        else if (epi == EPI_LOGITS) hipLaunchKernelGGL((xstat32_k<T, EPI_LOGITS, false, false, true>), dim3(256), dim3(XS_THREADS), smem, s, a);
     });
 }
 

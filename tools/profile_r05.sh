@@ -38,4 +38,12 @@ if [ $what = pmc ]; then
     pmc1 b32fp8 $ctr --batch 32 --fp8 --steps 1 --warmup 0 --new-tokens 256 --no-cpu-baseline
   done
 fi
+
+if [ $what = prefill ]; then
+  trace prefill_b1 11 python $ROOT/tools/prefill_only.py 1 160 10
+  RDX_PBLK=0 trace prefill_b1_wstat 11 python $ROOT/tools/prefill_only.py 1 160 10
+fi
 du -sh $OUT
+if [ $what = prefill64 ]; then
+  trace prefill_b1_t64 11 python $ROOT/tools/prefill_only.py 1 64 10
+fi
