@@ -36,7 +36,9 @@ static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, c
         // 33-64 rows: final RMSNorm into the fragment-packed row tiles, lm_head in two row blocks (xstat32_k<EPI_LOGITS, BLK>)
         if (!blk64_ok(c, B)) { c->unsupported = "more than 32 decoder rows need model-dtype weights at hidden 4096 / inter 11008 (the row-block family)"; return; }
         const int mtl = (B + 15) / 16;
-        launch_rmsnorm_packed(f.dtype, x, c->final_norm, c->dxn, B, mtl, f.hidden, f.rms_eps, c->stream);
+        const int pend = (x == c->dx) ? c->pend_groups : 0;       // the last layer's K-split down_proj left its slabs (and the residual add) to this norm
+        if (pend) { c->pend_groups = 0; launch_rmsnorm_packed_slab(f.dtype, c->dx, c->final_norm, c->dxn, B, mtl, f.rms_eps, c->kslab, pend, c->stream); }
+        else launch_rmsnorm_packed(f.dtype, x, c->final_norm, c->dxn, B, mtl, f.hidden, f.rms_eps, c->stream);
         a.X = c->dxn; a.norm_w = nullptr; a.xpacked = 3; a.mtiles = mtl;
         launch_xstat_blk(f.dtype, a, EPI_LOGITS, c->stream);
     }
@@ -220,7 +222,8 @@ bool decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, long step
         auto pk = [&](GemmArgs a, int outp) { a.xpacked = 3; a.mtiles = mtl; a.out_packed = outp; return a; };
         for (int l = 0; l < f.layers; ++l) {
             const LlamaLayer& L = c->ll[l];
-            launch_rmsnorm_packed(dt, c->dx, L.attn_norm, c->dxn, B, mtl, H, f.rms_eps, s);
+            if (c->pend_groups) { launch_rmsnorm_packed_slab(dt, c->dx, L.attn_norm, c->dxn, B, mtl, f.rms_eps, c->kslab, c->pend_groups, s); c->pend_groups = 0; }
+            else launch_rmsnorm_packed(dt, c->dx, L.attn_norm, c->dxn, B, mtl, H, f.rms_eps, s);
             { GemmArgs a = gargs(c->dxn, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; launch_xstat_blk(dt, pk(a, 0), EPI_NONE, s); }
             DecAttnArgs at;
             at.d = c->ld; at.qkv = c->dqkv; at.lbq = L.lora_bq; at.lbv = L.lora_bv; at.cos_t = c->rope_cos; at.sin_t = c->rope_sin;
@@ -231,7 +234,12 @@ bool decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, long step
             { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; launch_xstat_blk(dt, pk(a, 0), EPI_RESID, s); }
             launch_rmsnorm_packed(dt, c->dx, L.mlp_norm, c->dxn, B, mtl, H, f.rms_eps, s);
             { GemmArgs a = gargs(c->dxn, H, L.wgu, nullptr, c->dgu, f.inter, B); launch_xstat_blk(dt, pk(a, 3), EPI_SILU_MUL, s); }
-            { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; launch_wstat(dt, pk(a, 0), EPI_RESID, s); }
+            // down_proj: K-split over 4 workgroups per tile into fp32 slabs, combined (+ residual) by the next RMSNorm (xsplit32_k<.., BLK>: 21 us against
+            // 29.5 us for the prompt's weight-stationary kernel at 64 rows); RDX_BLK_DOWN=0: wstat_k, the A/B leg
+            { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, H, B); a.resid = c->dx; a.ldr = H; a = pk(a, 0);
+              static const bool split_down = !(getenv("RDX_BLK_DOWN") && atoi(getenv("RDX_BLK_DOWN")) == 0);
+              if (split_down && xsplit_blk_supported(a)) { launch_xsplit_blk(dt, a, c->kslab, s); c->pend_groups = 4; }
+              else launch_wstat(dt, a, EPI_RESID, s); }
         }
         lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
         return false;

@@ -140,7 +140,8 @@ void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, i
 // statistics and the scaling. Same arithmetic and rounding points as rmsnorm_k.
 template <typename T, int PACK>
 __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __restrict__ w, T* __restrict__ out, float eps, int n_rows,
-                                                     const float* __restrict__ slab, int groups, T* xw, float* __restrict__ xscale = nullptr) {
+                                                     const float* __restrict__ slab, int groups, T* xw, float* __restrict__ xscale = nullptr, int mtl = 0) {
+    // PACK 6 (round 5, 33-64 decoder rows): the PACK 3 order over `mtl` row tiles WITH the pending K-split slabs [groups][16 mtl][H] folded in first
     typedef typename Vec8<T>::type V8;
     constexpr int H = 4096;
     __shared__ float red[32];
@@ -148,17 +149,17 @@ __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __rest
     auto dst = [&](int i) -> T* {
         if (PACK == 0) return out + row * H + i;
         const int f = PACK != 2 ? (i >> 5) : (2 * (i >> 6) + ((i & 15) >> 3)), g = PACK != 2 ? ((i & 31) >> 3) : ((i & 63) >> 4);
-        return out + ((size_t)((f * (PACK == 3 ? groups : 2) + (int)(row >> 4)) * 64 + g * 16 + (int)(row & 15)) << 3);
+        return out + ((size_t)((f * (PACK == 3 ? groups : PACK == 6 ? mtl : 2) + (int)(row >> 4)) * 64 + g * 16 + (int)(row & 15)) << 3);
     };
     const int i0 = threadIdx.x * 8, i1 = i0 + 2048;
-    if (PACK >= 4 && (int)row >= n_rows) {
+    if ((PACK == 4 || PACK == 5) && (int)row >= n_rows) {
         unsigned char* o8 = reinterpret_cast<unsigned char*>(out);
         *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row, i0, H)) = (u2){0u, 0u};
         *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row, i1, H)) = (u2){0u, 0u};
         if (threadIdx.x == 0) xscale[row] = 1.0f;
         return;
     }
-    if (PACK && PACK < 4 && (int)row >= n_rows) {
+    if (PACK && (PACK < 4 || PACK == 6) && (int)row >= n_rows) {
         stg16(dst(i0), (u4){0u, 0u, 0u, 0u});
         stg16(dst(i1), (u4){0u, 0u, 0u, 0u});
         return;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __rest
         for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const float* p = slab + ((size_t)min(gq, groups - 1) * 32 + row) * H + (k ? i1 : i0);
+                const float* p = slab + ((size_t)min(gq, groups - 1) * (PACK == 6 ? 16 * mtl : 32) + row) * H + (k ? i1 : i0);
                 sp[gq][k][0] = *reinterpret_cast<const float4*>(p);
                 sp[gq][k][1] = *reinterpret_cast<const float4*>(p + 4);
             }
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __rest
     for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[k][j] = fromf<T>(tof<T>(wv[k][j]) * rnd<T>(tof<T>(v[k][j]) * rs));
-    if (PACK >= 4) {
+    if (PACK == 4 || PACK == 5) {
         const float am = block_max(fmaxf(amax8<T>(o[0]), amax8<T>(o[1])), red);
         float sc, inv;
         fp8_scale(am, sc, inv);
@@ -224,6 +225,13 @@ void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, i
     }
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T, 3>), dim3(mtiles * 16), dim3(256), 0, s, (const T*)x, (const T*)w,
                                                 (T*)out, H, eps, rows, (const float*)nullptr, mtiles, (T*)nullptr));
+}
+
+// 33-64 decoder rows: x += T(sum of the `groups` pending K-split slabs [groups][16 mtiles][H]) (written back), then RMSNorm into the fragment-packed
+// [k / 32][mtiles][lane][8] the row-block kernels read. H = 4096.
+void launch_rmsnorm_packed_slab(int dtype, void* x, const void* w, void* out, int rows, int mtiles, float eps, const float* slab, int groups, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm4096_k<T, 6>), dim3(mtiles * 16), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, eps, rows, slab, groups,
+                                                (T*)x, (float*)nullptr, mtiles));
 }
 
 void launch_rmsnorm(int dtype, const void* x, const void* w, void* out, int rows, int H, float eps, hipStream_t s) {

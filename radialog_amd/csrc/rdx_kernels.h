@@ -131,6 +131,10 @@ void launch_conv1x1_stream(int dtype, const GemmArgs& a, const ConvGeom& cg, int
 bool wstat_supported(const GemmArgs& a, int epi);
 void launch_wstat(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, int rows, int mtiles, int H, float eps, hipStream_t s);
+void launch_rmsnorm_packed_slab(int dtype, void* x, const void* w, void* out, int rows, int mtiles, float eps, const float* slab, int groups, hipStream_t s);   // H = 4096
+// K-split down_proj / o_proj over 33-64 rows (xsplit32_k<.., BLK>): X xpacked 3 over a.mtiles row tiles, slabs [groups][16 mtiles][N]
+bool xsplit_blk_supported(const GemmArgs& a);
+void launch_xsplit_blk(int dtype, const GemmArgs& a, float* slab, hipStream_t s);
 bool wsgemm_supported(const GemmArgs& a, const ConvGeom& cg, int epi);
 void launch_wsgemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, const void* zero16, hipStream_t s);
 

@@ -253,9 +253,12 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
 // A8 (with W8): the workgroup quantises ITS K range of the (model-dtype, fragment-packed) activations to e4m3 at start-up -- one absmax / 448
 // scale per row over the range (cross-wave maximum through LDS) -- and multiplies fp8 x fp8; the partial carries wscale[n] * that scale. The
 // ranges of the KGN groups are the `xgroups` K groups of the fp8 scheme (gemm8.hip; whole 128-deep blocks): o_proj 2, down_proj 4.
-template <typename T, int KC, int KGN, bool W8, int TPI, bool A8 = false>
+// BLK (round 5, 33-64 decoder rows): the rows in blocks of 32, the row-block workgroups of a (tile slot, K group) pair on one XCD like xstat32_k<.., BLK>;
+// X is the fragment-packed [k / 32][mtiles][lane][8], the slabs are [KGN][16 mtiles][N].
+template <typename T, int KC, int KGN, bool W8, int TPI, bool A8 = false, bool BLK = false>
 __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __restrict__ slab) {
     static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
+    static_assert(!BLK || !W8, "the row-block mode is model-dtype only");
     constexpr int SLOTS = XS_WAVES * KGN, CPW = (KC + SLOTS - 1) / SLOTS, FPL = W8 ? 2 : 1;   // fragments (MFMAs per row tile) per load
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
     float* red = reinterpret_cast<float*>(smx);       // [2 bufs][TPI][8 waves][2 mt][256]
@@ -263,7 +266,12 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
     const int lane = threadIdx.x & 63, wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int ntiles = (a.N + 15) >> 4;
-    const int nts = (int)gridDim.x / KGN, kg = (int)blockIdx.x % KGN, ts = (int)blockIdx.x / KGN;
+    int nts = (int)gridDim.x / KGN, kg = (int)blockIdx.x % KGN, ts = (int)blockIdx.x / KGN, mb = 0;
+    if (BLK) {
+        const int NB = (a.mtiles + 1) >> 1, PS = 32 / NB, xcd = (int)blockIdx.x & 7, slot = (int)blockIdx.x >> 3, p = slot / NB;
+        if (slot >= PS * NB || p >= (PS / KGN) * KGN) return;
+        mb = slot % NB; kg = p % KGN; nts = 8 * (PS / KGN); ts = xcd * (PS / KGN) + p / KGN;
+    }
     if (ts >= nts) return;
     const int ntl = (ntiles - ts + nts - 1) / nts;    // tiles of this workgroup: ts, ts + nts, ...
     const int nit = (ntl + TPI - 1) / TPI;
@@ -300,13 +308,14 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 #pragma unroll
         for (int j = 0; j < CPW * FPL; ++j) {
             const int f = (c0 + min(j / FPL, cnt - 1)) * FPL + (j % FPL);          // packed fragment index (32-deep, or 2 per 64-deep chunk)
-            const u4 v = ldg16(X + ((size_t)((f * 2 + mt) * 64 + lane) << 3));
+            const u4 v = BLK ? ldg16(X + ((size_t)((f * a.mtiles + min(2 * mb + mt, a.mtiles - 1)) * 64 + lane) << 3))
+                             : ldg16(X + ((size_t)((f * 2 + mt) * 64 + lane) << 3));
             xf[mt][j] = (j / FPL) < cnt ? v : (u4){0u, 0u, 0u, 0u};
         }
     __builtin_amdgcn_sched_barrier(0);
 
-    const int e_mt = threadIdx.x >> 8, e_idx = threadIdx.x & 255, e_m = e_mt * 16 + (e_idx >> 4), e_nl = e_idx & 15;
-    float* sl = slab + ((size_t)kg * 32 + e_m) * a.N;
+    const int e_mt = threadIdx.x >> 8, e_idx = threadIdx.x & 255, e_m = (BLK ? 32 * mb : 0) + e_mt * 16 + (e_idx >> 4), e_nl = e_idx & 15;
+    float* sl = slab + ((size_t)kg * (BLK ? 16 * a.mtiles : 32) + e_m) * a.N;
     u4 xq[2][A8 ? CPW : 1];
     float e_xs = 1.f;
     if (A8) {
@@ -441,6 +450,16 @@ void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
             else hipLaunchKernelGGL((xsplit32_k<T, 128, 2, false, 1>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
         }
     });
+}
+
+bool xsplit_blk_supported(const GemmArgs& a) {
+    return a.xpacked == 3 && a.mtiles >= 3 && a.mtiles <= 4 && a.M <= a.mtiles * 16 && a.M > (a.mtiles - 1) * 16 && a.K == 11008 && a.W && !a.W8 && !a.norm_w && !a.bias &&
+           (a.N + 15) / 16 >= 128 && (a.N + 15) / 16 <= 512;
+}
+
+void launch_xsplit_blk(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
+    const size_t smem = (size_t)2 * XS_WAVES * 2 * 256 * 4;
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((xsplit32_k<T, 344, 4, false, 1, false, true>), dim3(256), dim3(XS_THREADS), smem, s, a, slab));
 }
 
 bool xstat32_supported(const GemmArgs& a, int epi) {

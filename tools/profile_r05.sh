@@ -47,3 +47,6 @@ du -sh $OUT
 if [ $what = prefill64 ]; then
   trace prefill_b1_t64 11 python $ROOT/tools/prefill_only.py 1 64 10
 fi
+if [ $what = dec64 ]; then
+  trace dec_b64 0 python $ROOT/tools/decode_only.py 64 256 1
+fi
