@@ -100,7 +100,7 @@ void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split) {
     }
 }
 
-// 33-64 rows (round 5; VERDICT r4 "missing" 3): the decoder's rows as two 32-row blocks. Every K = 4096 projection runs activation-stationary per block,
+// 33-128 rows (round 5; VERDICT r4 "missing" 3): the decoder's rows as NB = ceil(rows / 32) blocks of 32. Every K = 4096 projection runs activation-stationary per block,
 // the two block workgroups of a tile walker on one XCD (xstat32_k<.., BLK>: a weight fragment comes from HBM once, from that L2 once more); o_proj is
 // un-split (final rows: no slabs), down_proj (K = 11008) takes the prompt's weight-stationary kernel; the RMSNorms write the fragment-packed
 // [k / 32][row tiles][lane][8] the consumers read. Model-dtype weights only.

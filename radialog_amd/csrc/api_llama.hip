@@ -33,7 +33,7 @@ static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, c
     a.part_val = c->part_val; a.part_idx = c->part_idx;
     a.out_step = out_step; a.out_step_stride = step_stride;
     if (B > 32) {
-        // 33-64 rows: final RMSNorm into the fragment-packed row tiles, lm_head in two row blocks (xstat32_k<EPI_LOGITS, BLK>)
+        // 33-128 rows: final RMSNorm into the fragment-packed row tiles, lm_head in two row blocks (xstat32_k<EPI_LOGITS, BLK>)
         if (!blk64_ok(c, B)) { c->unsupported = "more than 32 decoder rows need model-dtype weights at hidden 4096 / inter 11008 (the row-block family)"; return; }
         const int mtl = (B + 15) / 16;
         const int pend = (x == c->dx) ? c->pend_groups : 0;       // the last layer's K-split down_proj left its slabs (and the residual add) to this norm
@@ -216,7 +216,7 @@ bool decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, long step
         ca.w8 = (L0.wqkv.w8 && L0.wdown.w8 && f.hidden % 64 == 0 && f.inter % 64 == 0) ? 1 : 0;
     }
     if (B > 32) {
-        // 33-64 rows: the row-block family (api_dispatch.hip blk64_ok): 7 launches per layer, no K-split slabs
+        // 33-128 rows: the row-block family (api_dispatch.hip blk64_ok): 7 launches per layer, no K-split slabs
         if (!blk64_ok(c, B)) { c->unsupported = "more than 32 decoder rows need model-dtype weights at hidden 4096 / inter 11008 (the row-block family)"; return false; }
         const int mtl = (B + 15) / 16;
         auto pk = [&](GemmArgs a, int outp) { a.xpacked = 3; a.mtiles = mtl; a.out_packed = outp; return a; };

@@ -141,7 +141,7 @@ void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, i
 template <typename T, int PACK>
 __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __restrict__ w, T* __restrict__ out, float eps, int n_rows,
                                                      const float* __restrict__ slab, int groups, T* xw, float* __restrict__ xscale = nullptr, int mtl = 0) {
-    // PACK 6 (round 5, 33-64 decoder rows): the PACK 3 order over `mtl` row tiles WITH the pending K-split slabs [groups][16 mtl][H] folded in first
+    // PACK 6 (round 5, 33-128 decoder rows): the PACK 3 order over `mtl` row tiles WITH the pending K-split slabs [groups][16 mtl][H] folded in first
     typedef typename Vec8<T>::type V8;
     constexpr int H = 4096;
     __shared__ float red[32];
@@ -227,7 +227,7 @@ void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, i
                                                 (T*)out, H, eps, rows, (const float*)nullptr, mtiles, (T*)nullptr));
 }
 
-// 33-64 decoder rows: x += T(sum of the `groups` pending K-split slabs [groups][16 mtiles][H]) (written back), then RMSNorm into the fragment-packed
+// 33-128 decoder rows: x += T(sum of the `groups` pending K-split slabs [groups][16 mtiles][H]) (written back), then RMSNorm into the fragment-packed
 // [k / 32][mtiles][lane][8] the row-block kernels read. H = 4096.
 void launch_rmsnorm_packed_slab(int dtype, void* x, const void* w, void* out, int rows, int mtiles, float eps, const float* slab, int groups, hipStream_t s) {
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm4096_k<T, 6>), dim3(mtiles * 16), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out, eps, rows, slab, groups,

@@ -18,9 +18,9 @@
 
 using namespace rdx;
 
-// decoder rows per context: batch 1-2 chained launches, 3-16 xs16.hip, 3-32 xstat32.hip, 33-64 the row-block family (two 32-row blocks per tile walker
-// sharing an XCD's L2: xstat32_k<.., BLK> + wstat_k; model-dtype weights only)
-constexpr int RDX_MAX_ROWS = 64;
+// decoder rows per context: batch 1-2 chained launches, 3-16 xs16.hip, 3-32 xstat32.hip, 33-128 the row-block family (NB = ceil(rows / 32) row blocks per
+// tile walker sharing an XCD's L2: xstat32_k / xsplit32_k<.., BLK>; model-dtype weights only). 128 rows x 512 slots of KV = 68 GB of the 288.
+constexpr int RDX_MAX_ROWS = 128;
 
 struct GemmW { void* w = nullptr; int N = 0, K = 0, Npad = 0; void* w8 = nullptr; float* scale = nullptr; };   // w8/scale: fp8 copy
 struct RawW { void* p = nullptr; int64_t rows = 0, cols = 0; };
@@ -170,7 +170,7 @@ bool down_split_ok(rdx_ctx* c, const LlamaLayer& L, int B);
 void launch_ksplit(rdx_ctx* c, const GemmArgs& a);
 void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split);
 // batch 3-16, model-dtype weights, hidden 4096: the decode step's projections on xs16.hip (no stand-alone RMSNorm, no K-split slabs)
-bool blk64_ok(rdx_ctx* c, int B);      // 33-64 rows: the row-block decode family
+bool blk64_ok(rdx_ctx* c, int B);      // 33-128 rows: the row-block decode family
 bool xs16_ok(rdx_ctx* c, int B);
 void xs16_proj(rdx_ctx* c, GemmArgs a, int epi);          // a.norm_w set, a.X = the row-major residual stream
 void xs16_row(rdx_ctx* c, const void* xpacked, const GemmW& W, int B);     // dx += T(xpacked . W^T), in place

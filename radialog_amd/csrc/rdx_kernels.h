@@ -132,7 +132,7 @@ bool wstat_supported(const GemmArgs& a, int epi);
 void launch_wstat(int dtype, const GemmArgs& a, int epi, hipStream_t s);
 void launch_rmsnorm_packed(int dtype, const void* x, const void* w, void* out, int rows, int mtiles, int H, float eps, hipStream_t s);
 void launch_rmsnorm_packed_slab(int dtype, void* x, const void* w, void* out, int rows, int mtiles, float eps, const float* slab, int groups, hipStream_t s);   // H = 4096
-// K-split down_proj / o_proj over 33-64 rows (xsplit32_k<.., BLK>): X xpacked 3 over a.mtiles row tiles, slabs [groups][16 mtiles][N]
+// K-split down_proj / o_proj over 33-128 rows (xsplit32_k<.., BLK>): X xpacked 3 over a.mtiles row tiles, slabs [groups][16 mtiles][N]
 bool xsplit_blk_supported(const GemmArgs& a);
 void launch_xsplit_blk(int dtype, const GemmArgs& a, float* slab, hipStream_t s);
 bool wsgemm_supported(const GemmArgs& a, const ConvGeom& cg, int epi);
@@ -175,7 +175,7 @@ struct DecAttnArgs {
     void *kcache, *vcache, *out;
     long long* trace = nullptr;      // debug: 8 timestamps (100 MHz ticks) of workgroup (b=0,h=0)
     int out_packed = 0;              // stand-alone launches, batch 3-32: write `out` fragment-packed for xsplit32_k (attn_body.h)
-    int out_mt = 2;                  // row tiles of that packed block: 2 (the 32-row block), 3-4 for 33-64 rows ([k / 32][out_mt][lane][8], xpacked 3)
+    int out_mt = 2;                  // row tiles of that packed block: 2 (the 32-row block), 3-4 for 33-128 rows ([k / 32][out_mt][lane][8], xpacked 3)
 };
 void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s);
 // Chained decode launches of the batch <= 2 step (chain.hip): units run as roles of one launch, chained by a fence-free counter

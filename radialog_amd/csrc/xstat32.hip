@@ -253,7 +253,7 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
 // A8 (with W8): the workgroup quantises ITS K range of the (model-dtype, fragment-packed) activations to e4m3 at start-up -- one absmax / 448
 // scale per row over the range (cross-wave maximum through LDS) -- and multiplies fp8 x fp8; the partial carries wscale[n] * that scale. The
 // ranges of the KGN groups are the `xgroups` K groups of the fp8 scheme (gemm8.hip; whole 128-deep blocks): o_proj 2, down_proj 4.
-// BLK (round 5, 33-64 decoder rows): the rows in blocks of 32, the row-block workgroups of a (tile slot, K group) pair on one XCD like xstat32_k<.., BLK>;
+// BLK (round 5, 33-128 decoder rows): the rows in blocks of 32, the row-block workgroups of a (tile slot, K group) pair on one XCD like xstat32_k<.., BLK>;
 // X is the fragment-packed [k / 32][mtiles][lane][8], the slabs are [KGN][16 mtiles][N].
 template <typename T, int KC, int KGN, bool W8, int TPI, bool A8 = false, bool BLK = false>
 __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __restrict__ slab) {
@@ -453,7 +453,7 @@ void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
 }
 
 bool xsplit_blk_supported(const GemmArgs& a) {
-    return a.xpacked == 3 && a.mtiles >= 3 && a.mtiles <= 4 && a.M <= a.mtiles * 16 && a.M > (a.mtiles - 1) * 16 && a.K == 11008 && a.W && !a.W8 && !a.norm_w && !a.bias &&
+    return a.xpacked == 3 && a.mtiles >= 3 && a.mtiles <= 8 && a.M <= a.mtiles * 16 && a.M > (a.mtiles - 1) * 16 && a.K == 11008 && a.W && !a.W8 && !a.norm_w && !a.bias &&
            (a.N + 15) / 16 >= 128 && (a.N + 15) / 16 <= 512;
 }
 

@@ -341,7 +341,8 @@ def _prefix_err(scores, ref_scores, tok_a, tok_b, N):
     (5, False, 1, ("bf16",)), (3, False, 1, ("f16",)), (4, True, 1, ("bf16",)), (1, False, 1, ("f16", "bf16")),
     (2, False, 1, ("f16",)), (1, True, 1, ("bf16",)), (20, False, 2, ("bf16",)), (1, False, 2, ("f16",)),
     (12, False, 1, ("f16", "bf16")), (16, False, 2, ("f16",)),       # round 5: the reference's eval batch (test.py:279,:344) and a full row tile on xs16.hip
-    (48, False, 1, ("f16",)), (64, False, 1, ("f16", "bf16")), (40, False, 2, ("bf16",))])      # round 5: 33-64 rows, the row-block family (ragged last block at 40 / 48)
+    (48, False, 1, ("f16",)), (64, False, 1, ("f16", "bf16")), (40, False, 2, ("bf16",)),       # round 5: 33-128 rows, the row-block family (ragged last block at 40 / 48),
+    (88, False, 1, ("bf16",)), (128, False, 1, ("f16",))])                                      # three (one workgroup slot in four idle) and four row blocks per tile walker
 def test_production_width_layers_match_oracle(B, fp8, layers, dtypes):
     """Every decode kernel family at the production widths (hidden 4096, inter 11008, vocab 32001; one or two decoder layers so
     that the oracle finishes in seconds; two layers add the down_proj -> next QKV seam): batch 1-2 fused / chained GEMV launches,
