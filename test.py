@@ -23,7 +23,8 @@ from radialog_amd.shard import allgather_ragged, shard_range               # noq
 from radialog_amd.tokenizer import load_tokenizer                          # noqa: E402
 
 
-ENGINE_ROWS = 32      # librdx's decoder holds at most 32 rows (api.hip: max_batch)
+ENGINE_ROWS = 32      # rows this script asks of one context: the reference's loops run batch 12 (x beams). librdx itself holds up to 128 greedy rows per
+                      # context in the model dtype (rdx_ctx.h RDX_MAX_ROWS, round 5), 32 with fp8 weights; beam search is tested up to 32 rows
 
 
 def engine_rows(batch_size, num_beams, bin_qa=False, all_qa=False):
