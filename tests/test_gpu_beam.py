@@ -57,6 +57,38 @@ def test_beam_search_matches_oracle(k, B):
     lm._engine.close()
 
 
+def test_beam_search_at_the_references_eval_batch_36_rows_in_one_pass():
+    """test.py runs batch 12 with num_beams 3 (test.py:267,:279,:467): 36 beam rows. Rounds 1-4 held 32 rows per context and chunked that call;
+    round 5's row-block decode family (33-128 rows) takes it in one pass. Production width, one layer, against the oracle's restatement of
+    transformers 4.28.1 beam search: the first step's log-probs of every prompt, and the returned hypotheses per prompt (a prompt whose sequence
+    differs must come from a batch with a pruning decision closer than 6 fp16 ulps; at least 9 of the 12 prompts identical outright)."""
+    from oracle import ref_cpu
+    from radialog_amd.config import LlamaCfg
+    from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM
+    lcfg = LlamaCfg(layers=1, qformer_dim=192)
+    W = synth.make_weights(synth.llama_specs(lcfg, lora=True))
+    orc = ref_cpu.LlamaOracle(W, lcfg, torch.float16, lora=True)
+    B, k, T, N = 12, 3, 64, 6
+    lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.float16, cfg=lcfg, max_batch=B * k, max_len=96, synthetic=True).eval()
+    ids = synth.synth_prompt_ids(B, T, vocab=lcfg.vocab, img_offset=6, pad_rows=True, seed=77)
+    qf = synth.synth("t.qfb36", (B, 32, lcfg.qformer_dim), -1.0, 1.0)
+    with torch.no_grad():
+        ref = orc.generate_beam(ids, qf, k, N, eos_id=-1, pad_id=0)
+        km = ids.ne(0).long()
+        lp0 = torch.nn.functional.log_softmax(orc.forward(orc.embed(ids, qf), km, ref_cpu.positions_from_mask(km))[0][:, -1], dim=-1)
+    out = lm.generate(input_ids=ids, qformer_embs=qf, num_beams=k, max_new_tokens=N, eos_token_id=-1, pad_token_id=0,
+                      return_dict_in_generate=True, output_scores=True)
+    assert out.sequences.shape == ref["sequences"].shape and out.scores[0].shape == (B * k, lcfg.vocab)
+    err0 = float((out.scores[0].float().cpu()[::k] - lp0.float()).abs().max())
+    assert err0 < 1.5e-2, f"first-step log-probs differ by {err0}"
+    same = [bool(torch.equal(out.sequences[b].cpu(), ref["sequences"][b])) for b in range(B)]
+    print(f"beam k={k} over {B * k} rows in one pass: {sum(same)}/{B} prompts identical to the oracle (min decision gap {ref['min_gap']:.4f})")
+    if not all(same):
+        assert ref["min_gap"] <= 6 * 2.0 ** -8, f"prompts {[b for b in range(B) if not same[b]]} differ although every decision was > 6 ulps apart"
+    assert sum(same) >= 9
+    lm._engine.close()
+
+
 def test_beam_reorder_moves_only_the_diverging_suffix_and_changes_nothing(monkeypatch):
     """_reorder_cache (modeling_llama_imgemb.py:838-843) is `past[:, beam_idx]`; rdx_beam_search moves, per re-parented row, only the cache
     positions from the first token at which the row's old history and its new parent's differ (rounded down to the 16-position group) --

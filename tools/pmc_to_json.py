@@ -4,8 +4,8 @@
 python tools/pmc_to_json.py r05. traffic_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH doubled per the gfx950 correction of
 MI355X_MICROARCH.md; `pick` = which statistic of a kernel's dispatches stands for the typical launch. Round 5: the file is stamped with the hash of
 the kernel sources it was taken on (`_tree` = radialog_amd.build.source_hash(); bench.py flags a replayed figure whose tree is not the running one) and
-every entry carries `algorithmic_bytes` AT THE PROFILED STATE (the batch-32 passes decode 256 tokens, so a kernel's average dispatch is its average
-over contexts 160 .. 415 -- the mean context 288 bench.py prices the decode attention at)."""
+every entry carries `algorithmic_bytes` AT THE PROFILED STATE (the batch-32 passes run a 280-token prompt + 8 tokens, so the decode attention is
+profiled at the mean context 288 bench.py prices it at; flash_prefill_k / the prefill GEMMs are then those of a 280-token prompt)."""
 import json
 import os
 import re
@@ -22,10 +22,10 @@ KERNELS = {
     "qkv B=32 bf16": ("b32", r"xstat32_kIDF16bLi0ELb0ELb0", "avg", "xstat32_k<EPI_NONE> QKV + LoRA-A rows; algorithmic 100.8 MB"),
     "down B=32 bf16": ("b32", r"xsplit32_kIDF16bLi344", "avg", "xsplit32_k down_proj, K split 4 ways; algorithmic 90.2 MB + activations"),
     "o_proj B=32 bf16": ("b32", r"xsplit32_kIDF16bLi128", "avg", "xsplit32_k o_proj, K split 2 ways; algorithmic 33.55 MB"),
-    "decode_attention_k B=32 bf16": ("b32", r"decode_attention_kIDF16bLi4", "avg", "batch-32 decode attention averaged over the 256-token decode (contexts 160 .. 415, mean 288): KV 32 x 32 x 2 x 288 x 256 B = 151 MB algorithmic"),
-    "flash_prefill_k B=32 bf16": ("b32", r"flash_prefill_kIDF16b", "avg", "K twice + V once per 64-query block, three blocks per (row, head); algorithmic 167.8 MB"),
-    "gemm_dma256_k gate_up prefill B=32 bf16": ("b32", r"gemm_dma256_kIDF16bLi4ELi8", "avg", "5120 x 22016 x 4096 bf16, XCD-compact tile order; algorithmic 222 MB in + 113 MB out"),
-    "gemm8_256_k gate_up prefill B=32 fp8": ("b32fp8", r"gemm8_256_kIDF16bLi4ELi8", "avg", "5120 x 22016 x 4096 e4m3 x e4m3, XCD-compact tile order; algorithmic 111 MB in + 113 MB out"),
+    "decode_attention_k B=32 bf16": ("b32", r"decode_attention_kIDF16bLi4", "avg", "batch-32 decode attention at contexts 280 .. 295 (a 280-token prompt + 8 tokens: the mean context of the benchmark's decode is 288): KV 32 x 32 x 2 x 288 x 256 B = 151 MB algorithmic"),
+    "flash_prefill_k B=32 bf16": ("b32", r"flash_prefill_kIDF16b", "avg", "K twice + V once per 64-query block, five blocks per (row, head) at T = 280; algorithmic = Q, K, V read + O written"),
+    "gemm_dma256_k gate_up prefill B=32 bf16": ("b32", r"gemm_dma256_kIDF16bLi4ELi8", "avg", "8960 x 22016 x 4096 bf16 (32 prompts of 280 tokens), XCD-compact tile order"),
+    "gemm8_256_k gate_up prefill B=32 fp8": ("b32fp8", r"gemm8_256_kIDF16bLi4ELi8", "avg", "8960 x 22016 x 4096 e4m3 x e4m3 (32 prompts of 280 tokens), XCD-compact tile order"),
     "gate_up B=32 bf16 fp8": ("b32fp8", r"xstat32_kIDF16bLi4ELb1ELb1", "avg", "xstat32_k<W8, A8>; algorithmic 90.7 MB"),
     "decode_attention_k B=32 bf16 fp8": ("b32fp8", r"decode_attention_kIDF16bLi4", "avg", "as the bf16 run (the KV cache stays bf16)"),
 }
@@ -35,8 +35,8 @@ ALGO = {   # algorithmic bytes per launch at the profiled state (SURVEY 8d shape
     "decode_chain_k B=1 bf16": 191043104, "attn_oproj16_k B=1 bf16": 33554432 + 2 * 192 * 8192 + 5 * 8192, "gate_up B=1 bf16": 180363264 + 8192 + 22016,
     "gate_up B=32 bf16": 180363264 + 262144 + 704512, "qkv B=32 bf16": 100794368 + 262144 + 787456, "down B=32 bf16": 90177536 + 704512 + 2097152,
     "o_proj B=32 bf16": 33554432 + 262144 + 1048576, "decode_attention_k B=32 bf16": 32 * (2 * 288 * 4096 * 2 + 6 * 4096 * 2),
-    "flash_prefill_k B=32 bf16": 4 * 32 * 160 * 4096 * 2, "gemm_dma256_k gate_up prefill B=32 bf16": 5120 * 4096 * 2 + 22016 * 4096 * 2 + 5120 * 11008 * 2,
-    "gemm8_256_k gate_up prefill B=32 fp8": 5120 * 4096 + 22016 * 4096 + 5120 * 11008 * 2, "gate_up B=32 bf16 fp8": 90181632 + 131072 + 704512,
+    "flash_prefill_k B=32 bf16": 4 * 32 * 280 * 4096 * 2, "gemm_dma256_k gate_up prefill B=32 bf16": 8960 * 4096 * 2 + 22016 * 4096 * 2 + 8960 * 11008 * 2,
+    "gemm8_256_k gate_up prefill B=32 fp8": 8960 * 4096 + 22016 * 4096 + 8960 * 11008 * 2, "gate_up B=32 bf16 fp8": 90181632 + 131072 + 704512,
     "decode_attention_k B=32 bf16 fp8": 32 * (2 * 288 * 4096 * 2 + 6 * 4096 * 2),
 }
 

@@ -33,9 +33,11 @@ if [ $what = bench ]; then
 fi
 if [ $what = pmc ]; then
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    pmc1 b1 $ctr --steps 1 --warmup 0 --new-tokens 64 --no-cpu-baseline --no-b32 --no-fp8 --no-f16 --no-enc256
-    pmc1 b32 $ctr --batch 32 --steps 1 --warmup 0 --new-tokens 256 --no-cpu-baseline
-    pmc1 b32fp8 $ctr --batch 32 --fp8 --steps 1 --warmup 0 --new-tokens 256 --no-cpu-baseline
+    # short runs: a PMC pass serialises every dispatch (a 256-token decode under counters did not finish in 30 minutes). The batch-32 passes use a
+    # 280-token prompt + 8 tokens so that the decode attention is profiled at the MEAN context of the benchmark's decode (160 .. 415 -> 288)
+    pmc1 b1 $ctr --steps 1 --warmup 0 --new-tokens 8 --no-cpu-baseline --no-b32 --no-fp8 --no-f16 --no-enc256 --no-b64 --no-graph
+    pmc1 b32 $ctr --batch 32 --steps 1 --warmup 0 --prompt-len 280 --new-tokens 8 --no-cpu-baseline --no-graph
+    pmc1 b32fp8 $ctr --batch 32 --fp8 --steps 1 --warmup 0 --prompt-len 280 --new-tokens 8 --no-cpu-baseline --no-graph
   done
 fi
 
