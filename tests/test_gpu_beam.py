@@ -68,8 +68,8 @@ def test_beam_search_at_the_references_eval_batch_36_rows_in_one_pass():
     lcfg = LlamaCfg(layers=1, qformer_dim=192)
     W = synth.make_weights(synth.llama_specs(lcfg, lora=True))
     orc = ref_cpu.LlamaOracle(W, lcfg, torch.float16, lora=True)
-    B, k, T, N = 12, 3, 64, 6
-    lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.float16, cfg=lcfg, max_batch=B * k, max_len=96, synthetic=True).eval()
+    B, k, T, N = 12, 3, 96, 6
+    lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.float16, cfg=lcfg, max_batch=B * k, max_len=128, synthetic=True).eval()
     ids = synth.synth_prompt_ids(B, T, vocab=lcfg.vocab, img_offset=6, pad_rows=True, seed=77)
     qf = synth.synth("t.qfb36", (B, 32, lcfg.qformer_dim), -1.0, 1.0)
     with torch.no_grad():
