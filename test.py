@@ -23,22 +23,24 @@ from radialog_amd.shard import allgather_ragged, shard_range               # noq
 from radialog_amd.tokenizer import load_tokenizer                          # noqa: E402
 
 
-ENGINE_ROWS = 32      # rows this script asks of one context: the reference's loops run batch 12 (x beams). librdx itself holds up to 128 greedy rows per
-                      # context in the model dtype (rdx_ctx.h RDX_MAX_ROWS, round 5), 32 with fp8 weights; beam search is tested up to 32 rows
+ENGINE_ROWS = 128     # librdx holds up to 128 decoder rows per context in the model dtype (rdx_ctx.h RDX_MAX_ROWS; round 5: the row-block decode family) ...
+ENGINE_ROWS_FP8 = 32  # ... and 32 with fp8 weights (the fp8 x fp8 decode kernels are the 32-row family)
 
 
-def engine_rows(batch_size, num_beams, bin_qa=False, all_qa=False):
+def engine_rows(batch_size, num_beams, bin_qa=False, all_qa=False, fp8=False):
     """Rows the engine must hold at once -> (max_batch, report-loop batch size, findings-QA batch size): the report loop runs batch_size
-    prompts x num_beams beam rows (chunked when that exceeds the engine's 32 rows); the binary QA pass is greedy (14 questions per study,
-    test.py:548-590); the findings QA runs batches of 5 with beams (test.py:610-650)."""
+    prompts x num_beams beam rows -- the reference's 12 x 3 = 36 (test.py:267,:279) in ONE pass since round 5 (chunked only when that exceeds the
+    engine's rows: 128, 32 with fp8 weights); the binary QA pass is greedy (14 questions per study, test.py:548-590); the findings QA runs
+    batches of 5 with beams (test.py:610-650)."""
+    rows = ENGINE_ROWS_FP8 if fp8 else ENGINE_ROWS
     beams = max(num_beams, 1)
     if beams > 8:
         raise ValueError(f"--num_beams {beams}: rdx_beam_search supports at most 8 beams")
-    if batch_size * beams > ENGINE_ROWS:
-        chunk = max(1, ENGINE_ROWS // beams)
-        print(f"note: --batch_size {batch_size} x --num_beams {beams} exceeds the engine's {ENGINE_ROWS} rows; the report loop runs in chunks of {chunk}")
+    if batch_size * beams > rows:
+        chunk = max(1, rows // beams)
+        print(f"note: --batch_size {batch_size} x --num_beams {beams} exceeds the engine's {rows} rows; the report loop runs in chunks of {chunk}")
         batch_size = chunk
-    qa_batch = max(1, min(5, ENGINE_ROWS // beams))
+    qa_batch = max(1, min(5, rows // beams))
     max_batch = max(batch_size * beams, 14 if bin_qa else 0, qa_batch * beams if all_qa else 0, beams, 1)
     return max_batch, batch_size, qa_batch
 
@@ -76,7 +78,7 @@ def main(argv=None):
     tok = load_tokenizer(args.vicuna)
     dt = torch.float16 if args.dtype == "f16" else torch.bfloat16
     try:
-        max_batch, args.batch_size, qa_batch = engine_rows(args.batch_size, args.num_beams, args.do_cp_bin_qa, args.do_cp_all_qa)
+        max_batch, args.batch_size, qa_batch = engine_rows(args.batch_size, args.num_beams, args.do_cp_bin_qa, args.do_cp_all_qa, fp8=args.fp8)
     except ValueError as e:
         p.error(str(e))
     beams = max(args.num_beams, 1)
