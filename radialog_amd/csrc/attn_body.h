@@ -58,6 +58,10 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
     constexpr int VR = 4 * KG;                   // V rows per lane held in registers (same coverage: KG*CW*16 positions)
     constexpr int SPAN = CW * 4;                 // positions covered by one block-wide V row sweep
     constexpr bool V_EARLY = V_EARLY_;           // enough registers to have K and V in flight together
+    // tail trips of contexts beyond the register window: K groups of 16 positions / V rows per lane and trip. Round 5 measured fatter trips in the
+    // 4-wave build (it has 19 VGPRs to spare since the new token's registers are retired early): 3 groups, 8 rows or both are 1.0-1.3 us SLOWER at
+    // every context from 96 to 448 (30.8 -> 31.9-32.1 us at 288) -- as with every earlier attempt to put more of this kernel's requests in flight
+    constexpr int KT = 2, VT = 4;
     const LlamaDims& d = a.d;
     const T* qkv = reinterpret_cast<const T*>(a.qkv);
     const T* lbq = reinterpret_cast<const T*>(a.lbq);
@@ -245,21 +249,21 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
         // (the register window is dead by now); a group past the context is loaded from a clamped row and stores nothing
         // (the second group of the last trip may lie past the context: wave-uniform skip -- it would store nothing, and its
         // loads are real HBM traffic: at batch 32 the clamped rows were a fifth of the kernel's bytes)
-        for (int gi = KG * CW + cw; gi * 16 < slot; gi += 2 * CW) {
-            u4 kf[2][4];
-            unsigned mw[2];
-            const bool two = (gi + CW) * 16 < slot;                   // wave-uniform
+        for (int gi = KG * CW + cw; gi * 16 < slot; gi += KT * CW) {
+            u4 kf[KT][4];
+            unsigned mw[KT];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                if (t == 1 && !two) break;
+            for (int t = 0; t < KT; ++t) {
+                if (t > 0 && !((gi + t * CW) * 16 < slot)) break;       // wave-uniform: a group past the context would store nothing, and its loads are real HBM traffic
                 const int gb = (gi + t * CW) * 16;
                 const int j = min(gb + r, d.max_len - 1);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) kf[t][c] = ldg16(kc + kperm(j, c * 32 + g * 8, d.k_perm));
                 mw[t] = *reinterpret_cast<const unsigned*>(km + min(gb + 4 * g, d.max_len - 4));
             }
-            score_group(kf[0], mw[0], gi * 16);
-            if (two) score_group(kf[1], mw[1], (gi + CW) * 16);      // positions >= slot are not stored
+#pragma unroll
+            for (int t = 0; t < KT; ++t)
+                if (t == 0 || (gi + t * CW) * 16 < slot) score_group(kf[t], mw[t], (gi + t * CW) * 16);      // positions >= slot are not stored
         }
     }
     if (w == 0 && lane == 0) S[slot] = km_new ? rnd<T>(rnd<T>(s_new) / div) : -INFINITY;      // the new position itself
@@ -308,18 +312,18 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
             }
         }
         // contexts beyond the register window: four rows per trip, loads first (clamped rows get P = 0)
-        for (int j0 = VR * SPAN; j0 < slot; j0 += 4 * SPAN) {
-            u4 vt[4];
-            float pt[4];
+        for (int j0 = VR * SPAN; j0 < slot; j0 += VT * SPAN) {
+            u4 vt[VT];
+            float pt[VT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < VT; ++t) {
                 const int j = j0 + t * SPAN + cw * 4 + jsub;
                 // rows of a whole wave past the context (wave-uniform test) are not fetched: zero row, P = 0
                 vt[t] = (j0 + t * SPAN + cw * 4 < slot) ? ldg16(vc + (size_t)min(j, d.max_len - 1) * D + doct * 8) : (u4){0u, 0u, 0u, 0u};
                 pt[t] = j < slot ? rnd<T>(expf(S[j] - mx) / sum) : 0.f;
             }
 #pragma unroll
-            for (int t = 0; t < 4; t += 2) {
+            for (int t = 0; t < VT; t += 2) {
                 const unsigned pp = (unsigned)bits16<T>(fromf<T>(pt[t])) | ((unsigned)bits16<T>(fromf<T>(pt[t + 1])) << 16);
                 const unsigned a0[4] = {vt[t].x, vt[t].y, vt[t].z, vt[t].w};
                 const unsigned a1[4] = {vt[t + 1].x, vt[t + 1].y, vt[t + 1].z, vt[t + 1].w};
