@@ -12,12 +12,13 @@ static int ensure_prefill_ws(rdx_ctx* c, size_t rows) {
     // release the old buffers, then allocate; a failure leaves prefill_rows = 0 so the next call starts over
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->prefill_rows = 0;
-    dfree(c, c->px); dfree(c, c->pxn); dfree(c, c->pqkv); dfree(c, c->pq); dfree(c, c->patt); dfree(c, c->pgu); dfree(c, c->pxq); dfree(c, c->pxs);
+    dfree(c, c->px); dfree(c, c->pxn); dfree(c, c->pqkv); dfree(c, c->pq); dfree(c, c->patt); dfree(c, c->pgu); dfree(c, c->pxq); dfree(c, c->pxs); dfree(c, c->pslab);
     if (fp8_weights(c->ll[0].wqkv)) {       // e4m3 activations of the fp8 x fp8 prefill GEMMs (gemm8.hip) and their per-(row, K group) scales
         ALLOC(c, c->pxq, rows * (size_t)std::max(f.hidden, f.inter));
         ALLOC(c, c->pxs, rows * 4 * sizeof(float));
     }
     ALLOC(c, c->px, rows * f.hidden * 2); ALLOC(c, c->pxn, rows * f.hidden * 2);
+    ALLOC(c, c->pslab, (size_t)4 * std::min<size_t>(rows, 192) * f.hidden * sizeof(float));
     ALLOC(c, c->pqkv, rows * c->ld.qkv_ld * 2); ALLOC(c, c->pq, rows * f.hidden * 2);
     ALLOC(c, c->patt, rows * f.hidden * 2); ALLOC(c, c->pgu, rows * f.inter * 2);
     c->prefill_rows = rows;
@@ -152,11 +153,15 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
         if (c->prompt_blk && xstat_blk_supported(a, epi)) { launch_xstat_blk(dt, a, epi, s); return; }
         launch_wstat(dt, a, epi, s);
     };
+    // round 5: down_proj of a prompt of <= 192 rows K-split over 4 workgroups per tile into fp32 slabs (xsplit32_k<.., BLK>), combined (+ residual) by the next
+    // layer's RMSNorm -- after the last layer by one more norm launch whose packed output nobody reads
+    int pend = 0;
     for (int l = 0; l < f.layers; ++l) {
         const LlamaLayer& L = c->ll[l];
         void* kc = kv_ptr(c, c->kcache, l);
         void* vc = kv_ptr(c, c->vcache, l);
-        if (ws) launch_rmsnorm_packed(dt, c->px, L.attn_norm, c->pxn, (int)M, mtl, H, f.rms_eps, s);
+        if (ws && pend) { launch_rmsnorm_packed_slab(dt, c->px, L.attn_norm, c->pxn, (int)M, mtl, f.rms_eps, c->pslab, pend, s); pend = 0; }
+        else if (ws) launch_rmsnorm_packed(dt, c->px, L.attn_norm, c->pxn, (int)M, mtl, H, f.rms_eps, s);
         else launch_rmsnorm(dt, c->px, L.attn_norm, c->pxn, (int)M, H, f.rms_eps, s);
         { GemmArgs a = gargs(c->pxn, H, L.wqkv, nullptr, c->pqkv, c->ld.qkv_ld, (int)M); a.N = L.wqkv.Npad; prompt_gemm(a, EPI_NONE, false); }
         // new K/V rows land behind the kept slots
@@ -175,8 +180,12 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
         if (ws) launch_rmsnorm_packed(dt, c->px, L.mlp_norm, c->pxn, (int)M, mtl, H, f.rms_eps, s);
         else launch_rmsnorm(dt, c->px, L.mlp_norm, c->pxn, (int)M, H, f.rms_eps, s);
         { GemmArgs a = gargs(c->pxn, H, L.wgu, nullptr, c->pgu, f.inter, (int)M); prompt_gemm(a, EPI_SILU_MUL, true); }
-        { GemmArgs a = gargs(c->pgu, f.inter, L.wdown, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H; prompt_gemm(a, EPI_RESID, false); }
+        { GemmArgs a = gargs(c->pgu, f.inter, L.wdown, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H;
+          GemmArgs b = a; b.xpacked = 3; b.mtiles = mtl;
+          if (ws && c->prompt_blk && M <= 192 && xsplit_blk_supported(b)) { launch_xsplit_blk(dt, b, c->pslab, s); pend = 4; }
+          else prompt_gemm(a, EPI_RESID, false); }
     }
+    if (pend) launch_rmsnorm_packed_slab(dt, c->px, c->ll[0].attn_norm, c->pxn, (int)M, mtl, f.rms_eps, c->pslab, pend, s);
     }
     launch_gather_last(dt, c->px, c->datt, B, T, H, s);      // datt doubles as the [B][H] last-position buffer
     lm_head_and_greedy(c, c->datt, B, logits, nullptr, 0, /*advance=*/0);

@@ -87,6 +87,7 @@ struct rdx_ctx {
     int pend_groups = 0;             // launch-time state: slabs written by the last xsplit32 launch, not yet added into dx
     void *px = nullptr, *pxn = nullptr, *pqkv = nullptr, *pq = nullptr, *patt = nullptr, *pgu = nullptr, *pqe = nullptr, *pimg = nullptr;
     size_t prefill_rows = 0;
+    float* pslab = nullptr;          // one prompt's prefill (<= 192 rows): fp32 slabs [4][rows][hidden] of the K-split down_proj (xsplit32_k<.., BLK>)
     int cur_B = 0, cur_T = 0, cur_max_new = 0, cur_eos = -1, cur_pad = 0;
     int cur_steps = 0;               // tokens selected since the last prefill (1 after it): bounds rdx_decode_step
     int32_t* cur_tokens = nullptr;

@@ -453,7 +453,7 @@ void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
 }
 
 bool xsplit_blk_supported(const GemmArgs& a) {
-    return a.xpacked == 3 && a.mtiles >= 3 && a.mtiles <= 8 && a.M <= a.mtiles * 16 && a.M > (a.mtiles - 1) * 16 && a.K == 11008 && a.W && !a.W8 && !a.norm_w && !a.bias &&
+    return a.xpacked == 3 && a.mtiles >= 3 && a.mtiles <= 12 && a.M <= a.mtiles * 16 && a.M > (a.mtiles - 1) * 16 && a.K == 11008 && a.W && !a.W8 && !a.norm_w && !a.bias &&
            (a.N + 15) / 16 >= 128 && (a.N + 15) / 16 <= 512;
 }
 
