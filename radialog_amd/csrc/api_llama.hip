@@ -153,7 +153,7 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
         if (c->prompt_blk && xstat_blk_supported(a, epi)) { launch_xstat_blk(dt, a, epi, s); return; }
         launch_wstat(dt, a, epi, s);
     };
-    // round 5: down_proj of a prompt of <= 192 rows K-split over 4 workgroups per tile into fp32 slabs (xsplit32_k<.., BLK>), combined (+ residual) by the next
+    // round 5: down_proj of a prompt of <= 128 rows (<= 4 row blocks: 160 rows measured 55.9 us against wstat_k 49.5; 64 rows 3.96 -> 3.69 ms per prefill) K-split over 4 workgroups per tile into fp32 slabs (xsplit32_k<.., BLK>), combined (+ residual) by the next
     // layer's RMSNorm -- after the last layer by one more norm launch whose packed output nobody reads
     int pend = 0;
     for (int l = 0; l < f.layers; ++l) {
@@ -182,7 +182,7 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
         { GemmArgs a = gargs(c->pxn, H, L.wgu, nullptr, c->pgu, f.inter, (int)M); prompt_gemm(a, EPI_SILU_MUL, true); }
         { GemmArgs a = gargs(c->pgu, f.inter, L.wdown, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H;
           GemmArgs b = a; b.xpacked = 3; b.mtiles = mtl;
-          if (ws && c->prompt_blk && M <= 192 && xsplit_blk_supported(b)) { launch_xsplit_blk(dt, b, c->pslab, s); pend = 4; }
+          if (ws && c->prompt_blk && M <= 128 && xsplit_blk_supported(b)) { launch_xsplit_blk(dt, b, c->pslab, s); pend = 4; }
           else prompt_gemm(a, EPI_RESID, false); }
     }
     if (pend) launch_rmsnorm_packed_slab(dt, c->px, c->ll[0].attn_norm, c->pxn, (int)M, mtl, f.rms_eps, c->pslab, pend, s);
