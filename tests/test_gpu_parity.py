@@ -578,6 +578,38 @@ def test_multi_turn_prefix_kv_reuse_matches_full_recompute_and_oracle(cfg, cpu_w
         eng.close()
 
 
+@pytest.mark.parametrize("blk", [1, 0])
+def test_multi_turn_append_at_production_width_on_the_row_block_prompt_kernels(blk):
+    """Round 5: one prompt's K = 4096 projections (and, up to 128 rows, its down_proj) run on row blocks of 32 sharing an XCD's L2
+    (xstat32_k / xsplit32_k<.., BLK>; `prompt_blk` 0 = the weight-stationary wstat_k of rounds 2-4). Production width, two layers: a 100-token
+    first turn (four row blocks, the last one ragged), then a follow-up whose 48-token tail is prefilled behind the kept prefix
+    (rdx_generate_append: two row blocks) -- logits and tokens of both turns against the oracle on the whole sequence."""
+    from oracle import ref_cpu
+    from radialog_amd.engine import RdxEngine, synth_getter
+    cfg, cpu_w = _production_width_weights(2)
+    T1, N1, TQ, N2 = 100, 6, 43, 6
+    ids1 = synth.synth_prompt_ids(1, T1, vocab=cfg.llama.vocab, seed=91)
+    qf = synth.synth("t.qfmtp", (1, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    question = torch.randint(3, 31999, (1, TQ), generator=torch.Generator().manual_seed(9))
+    for dtype in ("f16", "bf16"):
+        eng = RdxEngine(cfg, dtype=dtype, device=0, max_batch=1, max_len=256, lora=True, vision=False)
+        eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+        eng.set_option("prompt_blk", blk)
+        t1, s1, n1 = eng.generate(ids1, qf, max_new=N1, eos_id=-1, pad_id=0, output_scores=True, reuse_prefix=True)
+        t1, s1 = t1.cpu().long().clone(), s1.float().cpu().clone()
+        ids2 = torch.cat([ids1, t1, question], dim=1)
+        t2, s2, n2 = eng.generate(ids2, qf, max_new=N2, eos_id=-1, pad_id=0, output_scores=True, reuse_prefix=True)
+        assert eng.last_kept_prefix == T1 + N1 - 1
+        with torch.no_grad():
+            orc = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True)
+            r1 = orc.generate_greedy(ids1, qf, max_new=N1, eos_id=-1, pad_id=0)
+            r2 = orc.generate_greedy(ids2, qf, max_new=N2, eos_id=-1, pad_id=0)
+        tol = PROD_TOL[dtype] * 2 ** 0.5
+        SMALL_LEGS[dtype].add(check_greedy(t1, s1, r1, tol, 0.0, f"{dtype} prompt_blk={blk} turn 1"))
+        SMALL_LEGS[dtype].add(check_greedy(t2.cpu().long(), s2.float().cpu(), r2, tol, 0.0, f"{dtype} prompt_blk={blk} turn 2 (appended tail)"))
+        eng.close()
+
+
 def test_prefill_append_rejects_what_the_cache_does_not_hold(cfg):
     from radialog_amd.engine import RdxEngine, synth_getter
     from radialog_amd._lib import RdxError
