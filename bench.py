@@ -779,6 +779,7 @@ def main():
         # round 5: 64 reports per GPU (33-64 decoder rows: the row-block family) -- not a BASELINE configuration (those stop at 32 per GPU): what the
         # 288 GB of HBM buy when the 13.2 GB weight stream of a decode step is amortised over twice the reports
         subs["b64"] = (timed_run(64, False, 2, 1), f"per-GPU batch 64 (global {64 * world}): beyond BASELINE configs[2]/[3]'s 32 per GPU, same pipeline, hipGraph step")
+        subs["b128"] = (timed_run(128, False, 2, 1), f"per-GPU batch 128 (global {128 * world}), the most one context holds (RDX_MAX_ROWS): four 32-row blocks per tile walker")
     f16_r = None
     if B == 1 and not args.fp8 and args.dtype != "f16" and world == 1 and not args.no_f16 and not STUB:
         # the reference's dtype, in which token identity with the CPU path actually holds (parity_f16): the same configs[1] workload timed in fp16
@@ -856,7 +857,7 @@ def main():
         for rr in [r, f16_r] + [sr for sr, _ in subs.values()]:
             if rr is not None and rr.get("engine") is not None:
                 rr["engine"].close()
-        res["max_batch_per_gpu"] = 64                                       # librdx's decoder holds at most 64 rows per context (rdx_ctx.h RDX_MAX_ROWS)
+        res["max_batch_per_gpu"] = 128                                      # librdx's decoder holds at most 128 rows per context (rdx_ctx.h RDX_MAX_ROWS)
         cb = res.get("cpu_baseline", {})
         fixtures = [res["token_check"]] + [res[k]["token_check"] for k in subs] + ([res["f16_b1"]["token_check"]] if f16_r is not None else [])
         parity_keys = [k for k in cb if k.startswith("parity")]

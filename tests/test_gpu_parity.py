@@ -341,7 +341,7 @@ def _prefix_err(scores, ref_scores, tok_a, tok_b, N):
     (5, False, 1, ("bf16",)), (3, False, 1, ("f16",)), (4, True, 1, ("bf16",)), (1, False, 1, ("f16", "bf16")),
     (2, False, 1, ("f16",)), (1, True, 1, ("bf16",)), (20, False, 2, ("bf16",)), (1, False, 2, ("f16",)),
     (12, False, 1, ("f16", "bf16")), (16, False, 2, ("f16",)),       # round 5: the reference's eval batch (test.py:279,:344) and a full row tile on xs16.hip
-    (48, False, 1, ("f16",)), (64, False, 1, ("f16", "bf16")), (40, False, 2, ("bf16",)),       # round 5: 33-128 rows, the row-block family (ragged last block at 40 / 48),
+    (64, False, 1, ("f16", "bf16")), (40, False, 2, ("bf16",)),       # round 5: 33-128 rows, the row-block family (ragged last block at 40),
     (88, False, 1, ("bf16",)), (128, False, 1, ("f16",))])                                      # three (one workgroup slot in four idle) and four row blocks per tile walker
 def test_production_width_layers_match_oracle(B, fp8, layers, dtypes):
     """Every decode kernel family at the production widths (hidden 4096, inter 11008, vocab 32001; one or two decoder layers so
@@ -367,7 +367,7 @@ prefill (gemm8.hip) and from batch 3 in decode (xstat32.hip); the oracle runs th
         with torch.no_grad():
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True, fp8=fp8).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
             # the exactly-accumulated evaluation costs as much again: on the legs that span the kernel families (batch 1, 20, 32)
-            with_exact = (not fp8) and layers == 1 and B in (1, 12, 20, 32, 64)
+            with_exact = (not fp8) and layers == 1 and B in (1, 12, 20, 32)
             truth = (ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True, exact=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
                      if with_exact else None)
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
