@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5: the whole-suite run on the GPU box: the -m gpu suite (timed), smoke(), the default bench line; `prof` adds the rocprofv3 kernel table of the
-# default bench command and the FETCH_SIZE / WRITE_SIZE passes (tools/profile_r05.sh).
+# default bench command and the (short) FETCH_SIZE / WRITE_SIZE passes (tools/profile_r05.sh).
 set -u
 ROOT=$PWD
 export PYTHONPATH=$ROOT TMPDIR=/tmp
@@ -10,6 +10,6 @@ mkdir -p $OUT
 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc $?" >> $OUT/smoke.log
 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc $?" >> $OUT/bench.err
 if [ "${1:-}" = prof ]; then
-  bash tools/profile_r05.sh bench > /dev/null 2>&1
-  bash tools/profile_r05.sh pmc > /dev/null 2>&1
+  timeout 600 bash tools/profile_r05.sh pmc > /dev/null 2>&1
+  timeout 600 bash tools/profile_r05.sh bench > /dev/null 2>&1
 fi
