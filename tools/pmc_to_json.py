@@ -70,7 +70,10 @@ def main():
                     "algorithmic_bytes": ALGO.get(key)}
     sys.path.insert(0, REPO)
     from radialog_amd import build as _b
-    out["_tree"] = _b.source_hash()          # run this on the tree the passes were taken on
+    try:                                     # the hash the GPU box computed next to the passes; else this tree's (run it on the tree the passes were taken on)
+        out["_tree"] = open(os.path.join(SRC, "pmc_tree.txt")).read().strip() or _b.source_hash()
+    except OSError:
+        out["_tree"] = _b.source_hash()
     json.dump(out, open(os.path.join(REPO, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
     open(os.path.join(REPO, "profiles", f"{tag}_pmc_hbm_traffic.md"), "w").write("\n".join(md))
     for k, v in out.items():

@@ -32,6 +32,7 @@ if [ $what = bench ]; then
   trace bench_default 0 python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
 fi
 if [ $what = pmc ]; then
+  python -c "from radialog_amd import build; print(build.source_hash())" > $OUT/pmc_tree.txt      # the kernel sources these passes ran on (tools/pmc_to_json.py stamps it)
   for ctr in FETCH_SIZE WRITE_SIZE; do
     # short runs: a PMC pass serialises every dispatch (a 256-token decode under counters did not finish in 30 minutes). The batch-32 passes use a
     # 280-token prompt + 8 tokens so that the decode attention is profiled at the MEAN context of the benchmark's decode (160 .. 415 -> 288)
