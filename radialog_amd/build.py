@@ -22,7 +22,8 @@ def source_hash() -> str:
     replayed PMC figure whose tree differs from the one that is running)."""
     import hashlib
     h = hashlib.sha256()
-    for s in sorted(SOURCES + HOOK_SOURCES) + sorted(HEADERS):
+    # kernels, launchers and the ABI implementation; the two public headers under include/ (declarations and prose) are not part of it
+    for s in sorted(SOURCES + HOOK_SOURCES) + sorted(h for h in HEADERS if not h.startswith("..")):
         with open(os.path.join(CSRC, s), "rb") as f:
             h.update(s.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
