@@ -12,7 +12,7 @@
 //               one contiguous KiB), takes the row statistics (lanes -> waves through LDS, fixed order), scales and rounds exactly like
 //               rmsnorm4096_k -- T(w * T(x * rstd)) -- and turns the rows into MFMA B fragments through a wave-private, conflict-free LDS
 //               patch (ds_write_b128 / ds_read_b128; the direct gather from row-major memory is 16 rows x 64 B per load instruction). The
-//               first weight ring is in flight before any of that starts.
+//               rows are requested first and the first weight ring right behind them, so the arithmetic runs under the weights' flight.
 //   xrow16_k    o_proj / down_proj (+ residual): one 16-wave workgroup per output tile, K split over its waves, weight fragments (HBM,
 //               non-temporal) AND activation fragments (fragment-packed by the producer's epilogue, L2) streamed through one register ring,
 //               fixed-order LDS reduction, residual epilogue writing the final rows -- no slabs, nothing left for a later launch.
@@ -29,10 +29,9 @@ constexpr int X16_WAVES = 8, X16_THREADS = 512, X16_K = 4096, X16_CPW = X16_K / 
 constexpr int X16_TPI = 2, X16_RING = X16_TPI * X16_CPW;                                             // 32 fragments = 32 KiB per wave in flight
 constexpr int X16_TR_ROW = 1024 + 16;       // bytes per row of a wave's transpose patch: 16 rows land 4 banks apart (b128 accesses, 16 lanes per pass)
 constexpr int X16_TR_WAVE = 16 * X16_TR_ROW;
-constexpr size_t X16_RED_BYTES = (size_t)2 * X16_TPI * X16_WAVES * 256 * 4;                           // [2 bufs][2 tiles][8 waves][256] fp32
 constexpr size_t X16_SMEM = (size_t)X16_WAVES * X16_TR_WAVE + 1024;                                   // patches (the partial buffers alias them) + statistics
 
-template <typename T, int EPI, bool NORM>
+template <typename T, int EPI>
 __global__ __launch_bounds__(X16_THREADS) void xstat16_k(GemmArgs a) {
     typedef typename Vec8<T>::type V8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
@@ -60,13 +59,11 @@ __global__ __launch_bounds__(X16_THREADS) void xstat16_k(GemmArgs a) {
             __builtin_amdgcn_sched_barrier(0);               // issue order = consume order (the loop's counted waits rely on it)
         }
     };
-    // the first tile's weights go in flight before anything else; with the RMSNorm prologue the second tile's follow BEHIND it (its scaling
-    // temporaries and a 32-fragment ring do not fit the register file together: 56 bytes of scratch when both were issued up front)
     // ---- activations -> B fragments xf[c]: column = row r of X, k = 512 wa + 32 c + 8 g .. + 8 ------------------------------------------
     const T* X = reinterpret_cast<const T*>(a.X);
     u4 xf[X16_CPW];
-    u4 nw4 = (u4){0u, 0u, 0u, 0u};
-    if (NORM) {
+    u4 nw4;
+    {
         // row-major rows, this wave's k range: lane holds k = 512 wa + 8 lane .. + 8 of every row. These 17 KiB per wave are
         // requested FIRST (whole-KiB row segments, L2 hits after the first workgroup of an XCD) and the weight ring right behind them, so the
         // prologue's arithmetic runs under the flight of the first weights and its wait (vmcnt = ring) does not drain them
@@ -77,11 +74,10 @@ __global__ __launch_bounds__(X16_THREADS) void xstat16_k(GemmArgs a) {
                                                                                                 // vmcnt(0)); rows >= M repeat the last row: never stored
         __builtin_amdgcn_sched_barrier(0);
     }
-    // the first tile's weights; with the RMSNorm prologue the second tile's follow BEHIND it (its scaling temporaries and a 32-fragment ring do
-    // not fit the register file together: 56 bytes of scratch when both were issued up front)
+    // the first tile's weights; the second tile's follow BEHIND the prologue (its scaling temporaries and a 32-fragment ring do not fit the register
+    // file together: 56 bytes of scratch when both were issued up front)
     first_ring(0);
-    if (!NORM) first_ring(1);
-    if (NORM) {
+    {
         // LlamaRMSNorm (:85-93): fp32 mean of squares per row -- lanes (DPP), then waves through LDS in wave order
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -118,10 +114,6 @@ __global__ __launch_bounds__(X16_THREADS) void xstat16_k(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         first_ring(1);
         __syncthreads();                        // every wave has its fragments: the partial buffers may overwrite the patches
-    } else {
-        // fragment-packed 32-row block (rmsnorm4096_k<T, 1>): fragment (f, mt = 0) is one contiguous KiB
-#pragma unroll
-        for (int c = 0; c < X16_CPW; ++c) xf[c] = ldg16(X + (size_t)((((wa * X16_CPW + c) * 2) * 64 + lane) * 8));
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -135,8 +127,7 @@ __global__ __launch_bounds__(X16_THREADS) void xstat16_k(GemmArgs a) {
         constexpr bool PF = decltype(pf_tag)::value;
         const int grp = (int)blockIdx.x + it * G, t0 = grp * X16_TPI;
         const int t_o = t0 + e_q, n = t_o * 16 + e_nl;
-        float e_res = 0.f, e_bias = 0.f;
-        if (EPI == EPI_RESID) e_res = tof<T>(reinterpret_cast<const T*>(a.resid)[(size_t)min(e_m, a.M - 1) * a.ldr + min(n, a.N - 1)]);
+        float e_bias = 0.f;
         if (a.bias) e_bias = a.bias[min(n, a.N - 1)];
         v4f acc[X16_TPI];
 #pragma unroll
@@ -163,8 +154,6 @@ __global__ __launch_bounds__(X16_THREADS) void xstat16_k(GemmArgs a) {
         const bool ok = (e_m < a.M) && (t_o < ntiles) && (n < a.N);
         if (EPI == EPI_NONE) {
             if (ok) out[(size_t)e_m * a.ldo + n] = fromf<T>(v);
-        } else if (EPI == EPI_RESID) {
-            if (ok) out[(size_t)e_m * a.ldo + n] = fromf<T>(e_res + rnd<T>(v));
         } else if (EPI == EPI_SILU_MUL) {
             // rows 0-7 of a tile are gate, 8-15 the matching up rows: the partner sits 8 lanes away in the same DPP row
             const float u = dpp_mov<DPP_ROR8>(v);
@@ -265,16 +254,15 @@ __global__ __launch_bounds__(XR_THREADS) void xrow16_k(GemmArgs a) {
 bool xs16_rows_ok(int M) { return M >= 3 && M <= 16; }
 
 bool xstat16_supported(const GemmArgs& a, int epi) {
-    return xs16_rows_ok(a.M) && a.K == X16_K && a.W && !a.W8 && (a.N + 15) / 16 >= 512 && (a.norm_w ? a.ldx % 8 == 0 : a.xpacked == 1) &&
+    return xs16_rows_ok(a.M) && a.K == X16_K && a.W && !a.W8 && (a.N + 15) / 16 >= 512 && a.norm_w && a.ldx % 8 == 0 && !a.xpacked &&
            (epi == EPI_NONE || epi == EPI_SILU_MUL || epi == EPI_LOGITS);
 }
 
 template <typename T, int EPI>
 static void launch_xstat16_e(const GemmArgs& a, dim3 grid, hipStream_t s) {
     static DevOnce attr;
-    if (attr.first()) (void)hipFuncSetAttribute((const void*)xstat16_k<T, EPI, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X16_SMEM);
-    if (a.norm_w) hipLaunchKernelGGL((xstat16_k<T, EPI, true>), grid, dim3(X16_THREADS), X16_SMEM, s, a);
-    else hipLaunchKernelGGL((xstat16_k<T, EPI, false>), grid, dim3(X16_THREADS), X16_RED_BYTES, s, a);
+    if (attr.first()) (void)hipFuncSetAttribute((const void*)xstat16_k<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)X16_SMEM);
+    hipLaunchKernelGGL((xstat16_k<T, EPI>), grid, dim3(X16_THREADS), X16_SMEM, s, a);          // always with the RMSNorm prologue (xstat16_supported)
 }
 
 void launch_xstat16(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
