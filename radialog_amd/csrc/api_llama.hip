@@ -18,8 +18,7 @@ static int ensure_prefill_ws(rdx_ctx* c, size_t rows) {
         ALLOC(c, c->pxs, rows * 4 * sizeof(float));
     }
     ALLOC(c, c->px, rows * f.hidden * 2); ALLOC(c, c->pxn, rows * f.hidden * 2);
-    // fp32 slabs of one prompt's K-split projections (<= 192 rows): 4 x hidden (down_proj, xsplit32_k<.., BLK>) or 2 x 2 inter (gate/up, xprompt64_k) per row
-    ALLOC(c, c->pslab, std::min<size_t>(rows, 192) * std::max<size_t>((size_t)4 * f.hidden, std::max<size_t>((size_t)4 * f.inter, (size_t)2 * c->ld.qkv_ld)) * sizeof(float));
+    ALLOC(c, c->pslab, (size_t)4 * std::min<size_t>(rows, 192) * f.hidden * sizeof(float));
     ALLOC(c, c->pqkv, rows * c->ld.qkv_ld * 2); ALLOC(c, c->pq, rows * f.hidden * 2);
     ALLOC(c, c->patt, rows * f.hidden * 2); ALLOC(c, c->pgu, rows * f.inter * 2);
     c->prefill_rows = rows;
@@ -157,45 +156,10 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
     // round 5: down_proj of a prompt of <= 128 rows (<= 4 row blocks: 160 rows measured 55.9 us against wstat_k 49.5; 64 rows 3.96 -> 3.69 ms per prefill) K-split over 4 workgroups per tile into fp32 slabs (xsplit32_k<.., BLK>), combined (+ residual) by the next
     // layer's RMSNorm -- after the last layer by one more norm launch whose packed output nobody reads
     int pend = 0;
-    // round 5: 65-192 rows -- the K = 4096 projections on row blocks of 64 x K halves (xprompt.hip): every weight fragment crosses the L2s ceil(M / 64) times instead
-    // of ceil(M / 32); the two fp32 partial slabs of a projection are finished by its consumer (RoPE kernel / next RMSNorm / SwiGLU combine)
-    bool xp = false;
-    if (ws && c->prompt_blk && M > 64 && M <= 192) {
-        auto pk = [&](GemmArgs a) { a.xpacked = 3; a.mtiles = mtl; return a; };
-        GemmArgs q = gargs(c->pxn, H, c->ll[0].wqkv, nullptr, c->pqkv, c->ld.qkv_ld, (int)M); q.N = c->ll[0].wqkv.Npad;
-        GemmArgs o = gargs(c->patt, H, c->ll[0].wo, nullptr, c->px, H, (int)M);
-        GemmArgs g = gargs(c->pxn, H, c->ll[0].wgu, nullptr, c->pgu, f.inter, (int)M);
-        static const bool on = !(getenv("RDX_XPROMPT") && atoi(getenv("RDX_XPROMPT")) == 0);       // RDX_XPROMPT=0: the 32-row blocks of xstat32_k<.., BLK> (A/B)
-        xp = on && H == 4096 && xprompt64_supported(pk(q)) && xprompt64_supported(pk(o)) && xprompt64_supported(pk(g)) && q.N == c->ld.qkv_ld;
-    }
     for (int l = 0; l < f.layers; ++l) {
         const LlamaLayer& L = c->ll[l];
         void* kc = kv_ptr(c, c->kcache, l);
         void* vc = kv_ptr(c, c->vcache, l);
-        if (xp) {
-            auto pk = [&](GemmArgs a) { a.xpacked = 3; a.mtiles = mtl; return a; };
-            if (pend) { launch_rmsnorm_packed_slab(dt, c->px, L.attn_norm, c->pxn, (int)M, mtl, f.rms_eps, c->pslab, pend, s); pend = 0; }
-            else launch_rmsnorm_packed(dt, c->px, L.attn_norm, c->pxn, (int)M, mtl, H, f.rms_eps, s);
-            { GemmArgs a = gargs(c->pxn, H, L.wqkv, nullptr, c->pqkv, c->ld.qkv_ld, (int)M); a.N = L.wqkv.Npad; launch_xprompt64(dt, pk(a), c->pslab, s); }
-            launch_rope_kv_prefill_slab(dt, c->ld, c->pslab, (long)mtl * 16, L.lora_bq, L.lora_bv, c->rope_cos, c->rope_sin, c->d_pos_ids, c->pq, kc, vc, B, T, keep, s);
-            AttnArgs at;
-            memset(&at, 0, sizeof(at));
-            at.Q = c->pq; at.q_bs = (long)T * H; at.q_ts = H; at.q_hs = 128;
-            at.K = kc; at.V = vc; at.k_bs = at.v_bs = (long)f.heads * f.max_len * 128; at.k_ts = at.v_ts = 128; at.k_hs = at.v_hs = (long)f.max_len * 128;
-            at.O = c->patt; at.o_bs = (long)T * H; at.o_ts = H; at.o_hs = 128;
-            at.B = B; at.H = f.heads; at.Tq = T; at.Tk = keep + T; at.causal = 1; at.k_perm = c->ld.k_perm; at.key_mask = c->key_mask; at.km_bs = f.max_len;
-            at.o_packed_mt = mtl; at.flash_min = c->flash_min;
-            launch_attention(dt, 128, at, s);
-            { GemmArgs a = gargs(c->patt, H, L.wo, nullptr, c->px, H, (int)M); launch_xprompt64(dt, pk(a), c->pslab, s); }
-            launch_rmsnorm_packed_slab(dt, c->px, L.mlp_norm, c->pxn, (int)M, mtl, f.rms_eps, c->pslab, 2, s);       // x += T(o_proj halves), then the norm
-            { GemmArgs a = gargs(c->pxn, H, L.wgu, nullptr, c->pgu, f.inter, (int)M); launch_xprompt64(dt, pk(a), c->pslab, s); }
-            launch_swiglu_slab(dt, c->pslab, c->pgu, (int)M, mtl, L.wgu.N, s);
-            { GemmArgs a = gargs(c->pgu, f.inter, L.wdown, nullptr, c->px, H, (int)M); a.resid = c->px; a.ldr = H;
-              GemmArgs b = pk(a);
-              if (M <= 128 && xsplit_blk_supported(b)) { launch_xsplit_blk(dt, b, c->pslab, s); pend = 4; }
-              else prompt_gemm(a, EPI_RESID, false); }
-            continue;
-        }
         if (ws && pend) { launch_rmsnorm_packed_slab(dt, c->px, L.attn_norm, c->pxn, (int)M, mtl, f.rms_eps, c->pslab, pend, s); pend = 0; }
         else if (ws) launch_rmsnorm_packed(dt, c->px, L.attn_norm, c->pxn, (int)M, mtl, H, f.rms_eps, s);
         else launch_rmsnorm(dt, c->px, L.attn_norm, c->pxn, (int)M, H, f.rms_eps, s);

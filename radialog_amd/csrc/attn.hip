@@ -255,15 +255,12 @@ void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s)
 // A workgroup handles `tpb` consecutive tokens of a prompt: a thread's LoRA-B rows (8 rows x 16 B for q and for v: 256 B per thread, 128 KiB per
 // workgroup) are read ONCE and stay in registers -- with one token per workgroup the batched prefill re-read them for each of its 5120 tokens
 // (655 MB through L2 per layer, 108 us against the 50 us its 250 MB of QKV / q / K / V traffic needs).
-// SLAB (round 5, xprompt.hip): the QKV projection arrives as two fp32 partial slabs [2][plane = rows_pad x qkv_ld] (the K halves of xprompt64_k); a value is
-// T(s0 + s1) -- the one rounding the GEMM epilogue would have done.
-template <typename T, bool SLAB = false>
+template <typename T>
 __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* __restrict__ qkv, const T* __restrict__ lbq,
                                                           const T* __restrict__ lbv, const T* __restrict__ cos_t,
                                                           const T* __restrict__ sin_t, const int* __restrict__ pos_ids,
                                                           T* __restrict__ qout, T* __restrict__ kcache,
-                                                          T* __restrict__ vcache, int B, int Tn, int slot0, int tpb,
-                                                          const float* __restrict__ slab = nullptr, long plane = 0) {
+                                                          T* __restrict__ vcache, int B, int Tn, int slot0, int tpb) {
     typedef typename Vec8<T>::type V8;
     constexpr int D = 128;
     const int b = blockIdx.y;
@@ -292,26 +289,15 @@ __global__ __launch_bounds__(1024) void rope_kv_prefill_k(LlamaDims d, const T* 
         }
         const size_t row = (size_t)b * Tn + t;
         const T* x = qkv + row * d.qkv_ld;
-        auto ld8 = [&](int col) -> V8 {                     // 8 consecutive columns of this row of the QKV output
-            if (!SLAB) return as_vec8<T>(ldg16(x + col));
-            const float* p0 = slab + row * d.qkv_ld + col;
-            const float* p1 = p0 + plane;
-            const float4 a0 = *reinterpret_cast<const float4*>(p0), a1 = *reinterpret_cast<const float4*>(p0 + 4);
-            const float4 b0 = *reinterpret_cast<const float4*>(p1), b1 = *reinterpret_cast<const float4*>(p1 + 4);
-            V8 o;
-            o[0] = fromf<T>(a0.x + b0.x); o[1] = fromf<T>(a0.y + b0.y); o[2] = fromf<T>(a0.z + b0.z); o[3] = fromf<T>(a0.w + b0.w);
-            o[4] = fromf<T>(a1.x + b1.x); o[5] = fromf<T>(a1.y + b1.y); o[6] = fromf<T>(a1.z + b1.z); o[7] = fromf<T>(a1.w + b1.w);
-            return o;
-        };
         float q8[8], k8[8], kp8[8];
         if (act) {
-            const V8 qv = ld8(n0), kv = ld8(H + n0), vv = ld8(2 * H + n0);
-            const V8 kpv = ld8(H + (lo ? n0 + D / 2 : n0 - D / 2));
+            const V8 qv = as_vec8<T>(ldg16(x + n0)), kv = as_vec8<T>(ldg16(x + H + n0)), vv = as_vec8<T>(ldg16(x + 2 * H + n0));
+            const V8 kpv = as_vec8<T>(ldg16(x + H + (lo ? n0 + D / 2 : n0 - D / 2)));
             float v8[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) { q8[e] = tof<T>(qv[e]); k8[e] = tof<T>(kv[e]); v8[e] = tof<T>(vv[e]); kp8[e] = tof<T>(kpv[e]); }
             if (lora) {
-                const V8 aq = ld8(3 * H), av = ld8(3 * H + 8);
+                const V8 aq = as_vec8<T>(ldg16(x + 3 * H)), av = as_vec8<T>(ldg16(x + 3 * H + 8));
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float sq = 0.f, sv = 0.f;
@@ -363,17 +349,6 @@ void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, cons
     dim3 grid((T_ + tpb - 1) / tpb, B), block(threads);
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rope_kv_prefill_k<T>), grid, block, 0, s, d, (const T*)qkv, (const T*)lora_bq, (const T*)lora_bv,
                                                 (const T*)cos_t, (const T*)sin_t, pos_ids, (T*)qout, (T*)kcache, (T*)vcache, B, T_, slot0, tpb));
-}
-
-// the same with the QKV projection taken from the two K-half slabs of xprompt64_k: slab [2][rows_pad][qkv_ld] fp32
-void launch_rope_kv_prefill_slab(int dtype, const LlamaDims& d, const float* slab, long rows_pad, const void* lora_bq, const void* lora_bv,
-                                 const void* cos_t, const void* sin_t, const int* pos_ids, void* qout, void* kcache, void* vcache, int B, int T_,
-                                 int slot0, hipStream_t s) {
-    const int threads = ((d.hidden / 8 + 63) / 64) * 64;
-    dim3 grid(T_, B), block(threads);                    // one prompt, <= 192 tokens: one token per workgroup
-    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rope_kv_prefill_k<T, true>), grid, block, 0, s, d, (const T*)nullptr, (const T*)lora_bq, (const T*)lora_bv,
-                                                (const T*)cos_t, (const T*)sin_t, pos_ids, (T*)qout, (T*)kcache, (T*)vcache, B, T_, slot0, 1, slab,
-                                                rows_pad * (long)d.qkv_ld));
 }
 
 // test introspection: the K cache of one layer back in [B][heads][max_len][128] row-major order

@@ -44,10 +44,6 @@ typedef __attribute__((address_space(1))) u4 g_u4;
 __device__ __forceinline__ u4 ldg16(const void* p) { return *(const g_u4*)p; }
 __device__ __forceinline__ u4 ldg16_nt(const void* p) { return __builtin_nontemporal_load((const g_u4*)p); }
 __device__ __forceinline__ void stg16(void* p, u4 v) { *(g_u4*)p = v; }
-// 16-byte load at a wave-UNIFORM global base + a per-lane 32-bit byte offset: the SGPR-base addressing form (one shared VGPR for the lane offset instead of a
-// 64-bit address pair per load -- 32 fragment loads issued together would otherwise hold 64 VGPRs of addresses)
-typedef __attribute__((address_space(1))) const char g_cchar;
-__device__ __forceinline__ u4 ldg16_u(const void* uniform_base, unsigned lane_byte_off) { return *(const g_u4*)((g_cchar*)uniform_base + lane_byte_off); }
 
 // ---- fp8 (OCP e4m3) -> model dtype, exact (every e4m3 value is representable in bf16 and f16) --------------------------------
 // two dwords = 8 fp8 bytes -> 8 model-dtype values in one 16-byte register quad (an MFMA A-operand chunk)

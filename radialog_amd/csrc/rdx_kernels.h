@@ -161,13 +161,6 @@ void launch_attention(int dtype, int head_dim, const AttnArgs& a, hipStream_t s)
 bool flash_prefill_supported(int head_dim, const AttnArgs& a);
 void launch_flash_prefill(int dtype, const AttnArgs& a, hipStream_t s);
 // prefill: LoRA add + RoPE + KV-cache write for T tokens of B rows; q -> qout [B*T][hidden]
-// one prompt's K = 4096 projections on row blocks of 64 x K halves (xprompt.hip): fp32 slabs [2][16 mtiles][N], finished by the consumers
-bool xprompt64_supported(const GemmArgs& a);
-void launch_xprompt64(int dtype, const GemmArgs& a, float* slab, hipStream_t s);
-void launch_swiglu_slab(int dtype, const float* slab, void* out, int M, int mtiles, int N, hipStream_t s);
-void launch_rope_kv_prefill_slab(int dtype, const LlamaDims& d, const float* slab, long rows_pad, const void* lora_bq, const void* lora_bv,
-                                 const void* cos_t, const void* sin_t, const int* pos_ids, void* qout, void* kcache, void* vcache, int B, int T_,
-                                 int slot0, hipStream_t s);
 void launch_rope_kv_prefill(int dtype, const LlamaDims& d, const void* qkv, const void* lora_bq, const void* lora_bv,
                             const void* cos_t, const void* sin_t, const int* pos_ids, void* qout, void* kcache,
                             void* vcache, int B, int T, int slot0, hipStream_t s);     // rows land at cache slots slot0 + t
