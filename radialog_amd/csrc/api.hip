@@ -68,7 +68,6 @@ extern "C" int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg) {
     }
     { const char* e = getenv("RDX_FLASH_MIN"); if (e) c->flash_min = atoi(e); }
     { const char* e = getenv("RDX_XS16"); if (e) c->xs16 = atoi(e) != 0; }
-    { const char* e = getenv("RDX_XS16_FUSE"); if (e) c->xs16_fuse = atoi(e) != 0; }
     { const char* e = getenv("RDX_PBLK"); if (e) c->prompt_blk = atoi(e) != 0; }
     { const char* e = getenv("RDX_PCONV_KSPLIT"); c->pconv_noks = e && atoi(e) == 0; }
     { const char* e = getenv("RDX_PCONV"); c->trunk_packed = !(e && atoi(e) == 0); }      // read once (A/B legs of the tests set it before rdx_create)
@@ -362,8 +361,8 @@ extern "C" int rdx_set_option(rdx_ctx* c, const char* name, int value) {
     if (!strcmp(name, "flash_min")) { c->flash_min = value; return 0; }
     if (!strcmp(name, "pconv")) { c->trunk_packed = value != 0; return 0; }
     if (!strcmp(name, "prompt_blk")) { c->prompt_blk = value != 0; return 0; }
-    if (!strcmp(name, "xs16") || !strcmp(name, "xs16_fuse")) {          // batch 3-16 decode family (xs16.hip) / its fused attention + o_proj launch on / off; a captured step graph of the other form is dropped
-        (name[4] ? c->xs16_fuse : c->xs16) = value != 0;
+    if (!strcmp(name, "xs16")) {          // batch 3-16 decode family (xs16.hip) on / off; a captured step graph of the other family is dropped
+        c->xs16 = value != 0;
         if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; c->gkey = GraphKey(); }
         return 0;
     }

@@ -48,7 +48,7 @@ static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, c
     launch_greedy_step(f.dtype, c->part_val, c->part_idx, c->n_vtiles, B, c->cur_eos, c->cur_pad, c->cur_max_new,
                        c->cur_tokens, c->d_unf, advance ? c->d_pos : nullptr, advance ? c->d_slot : nullptr, c->d_step,
                        c->embed, f.vocab, c->dx, f.hidden, c->d_pos, c->rope_cos, c->rope_sin, c->d_cur_rope,
-                       (c->fuse_attn_oproj || c->chain_mlp || c->xs16_fuse) ? c->d_ctr : nullptr,
+                       (c->fuse_attn_oproj || c->chain_mlp) ? c->d_ctr : nullptr,
                        f.layers * 256 + (c->chain_mlp ? (int)chain_ctr_ints(f.layers) : 0), c->stream);
 }
 
@@ -265,10 +265,8 @@ bool decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, long step
             at.pos = c->d_pos; at.slot_b = c->d_slot; at.key_mask = c->key_mask; at.cur_rope = c->d_cur_rope;
             at.kcache = kv_ptr(c, c->kcache, l); at.vcache = kv_ptr(c, c->vcache, l); at.out = c->datt;
             at.out_packed = 1;
-            GemmArgs ao = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B);
-            ao.resid = c->dx; ao.ldr = H; ao.xpacked = 1;
-            if (c->xs16_fuse && attn_orow16_supported(c->ld, ao, B)) launch_attn_orow16(dt, at, ao, B, c->d_ctr + (size_t)l * 256, c->d_err, s);
-            else { launch_decode_attention(dt, at, B, s); xs16_row(c, c->datt, L.wo, B); }
+            launch_decode_attention(dt, at, B, s);
+            xs16_row(c, c->datt, L.wo, B);
             { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; a.out_packed = 1;
               xs16_proj(c, a, EPI_SILU_MUL); }
             xs16_row(c, c->dgu, L.wdown, B);

@@ -46,10 +46,7 @@ template <> __device__ __forceinline__ float dot2<f16>(unsigned a, unsigned b, f
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(v2h, a), __builtin_bit_cast(v2h, b), c, false);
 }
 
-// OUT_WT (xs16.hip attn_orow16_k): the fragment-packed output goes out with write-through 8-byte stores, for consumer workgroups of the SAME launch.
-// HALVES 2: the workgroup is two independent WAVES-wave halves (one (row, head) each, own `dsm`); they share the three barriers, nothing else.
-template <typename T, int WAVES, bool DED = (WAVES == 8), typename WaitFn = NoWait, bool V_EARLY_ = !DED, int KG_ = 0, bool COH = false, bool OUT_WT = false,
-          int HALVES = 1>
+template <typename T, int WAVES, bool DED = (WAVES == 8), typename WaitFn = NoWait, bool V_EARLY_ = !DED, int KG_ = 0, bool COH = false>
 __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, const int h, const int b, float* dsm,
                                                       WaitFn wait_inputs = WaitFn()) {
     typedef typename Vec8<T>::type V8;
@@ -72,7 +69,7 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
     const T* cos_t = reinterpret_cast<const T*>(a.cos_t);
     const T* sin_t = reinterpret_cast<const T*>(a.sin_t);
 
-    const int tid = HALVES > 1 ? (int)(threadIdx.x & (WAVES * 64 - 1)) : (int)threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     float* part = dsm;                                   // [WAVES][D]
     T* qT = reinterpret_cast<T*>(dsm + WAVES * D);       // [D] rotated query, model dtype (MFMA B operand)
     float* S = dsm + WAVES * D + D;                      // [max_len]
@@ -353,20 +350,7 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
     }
     __syncthreads();
     ATT_T(6);
-    if (OUT_WT) {
-        if (tid < D / 4) {                                     // out_packed 1: 4 dims of one fragment row = 8 bytes, write-through
-            unsigned long long pk = 0ull;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = 0.f;
-#pragma unroll
-                for (int i = 0; i < WAVES; ++i) v += part[i * D + tid * 4 + e];
-                pk |= (unsigned long long)bits16<T>(fromf<T>(v)) << (16 * e);
-            }
-            const int k = h * D + tid * 4;
-            st8_agent(reinterpret_cast<T*>(a.out) + (((size_t)(((k >> 5) * a.out_mt + (b >> 4)) * 64 + ((k & 31) >> 3) * 16 + (b & 15)) << 3) + (k & 7)), pk);
-        }
-    } else if (!COH) {
+    if (!COH) {
         if (tid < D) {
             float v = 0.f;
 #pragma unroll

@@ -98,7 +98,6 @@ struct rdx_ctx {
                                      // launch, one workgroup per CU (chain.hip: decode_chain_k)
     bool xs16 = true;                // batch 3-16 decode on the one-row-tile family (xs16.hip: norm-prologue projections + un-split o_proj / down, 5 launches
                                      // per layer); RDX_XS16=0 at create / rdx_set_option("xs16", 0): the 32-row family of xstat32.hip (7 launches; A/B leg of the tests)
-    bool xs16_fuse = true;           // ... with attention + o_proj as ONE launch (attn_orow16_k: 4 per layer); RDX_XS16_FUSE=0 / rdx_set_option("xs16_fuse", 0): the two launches
     bool prompt_blk = true;          // one prompt's K = 4096 projections on xstat32_k<.., BLK> (RDX_PBLK=0 / rdx_set_option("prompt_blk", 0): wstat_k, the A/B leg)
     int chain_naps = 1;              // poll back-off of the chained launch (x s_sleep(8) between polls)
     GemmW cls_fc1, cls_fc2; const float *cls_fc1_b = nullptr, *cls_fc2_b = nullptr;   // findings classifier head

@@ -178,10 +178,6 @@ struct DecAttnArgs {
     int out_mt = 2;                  // row tiles of that packed block: 2 (the 32-row block), 3-4 for 33-128 rows ([k / 32][out_mt][lane][8], xpacked 3)
 };
 void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s);
-// decode attention + that o_proj as two roles of ONE launch (xs16.hip attn_orow16_k, batch 3-16): `at` as launch_decode_attention takes it (out = the packed block o_proj reads),
-// `g` as launch_xrow16 takes it; counter = 8 x 16 zeroed ints (handoff.h shards), err = the context's hand-off error flag
-bool attn_orow16_supported(const LlamaDims& d, const GemmArgs& g, int B);
-void launch_attn_orow16(int dtype, DecAttnArgs at, const GemmArgs& g, int B, int* counter, int* err, hipStream_t s);
 // Chained decode launches of the batch <= 2 step (chain.hip): units run as roles of one launch, chained by a fence-free counter
 // hand-off (handoff.h) instead of a kernel boundary.
 struct ChainLayer { const void *wqkv, *wdown, *attn_norm;

@@ -22,7 +22,6 @@
 #include "rdx_common.h"
 #include "rdx_kernels.h"
 #include "skinny_body.h"   // swiglu()
-#include "attn_body.h"     // decode_attention_body, handoff.h
 
 namespace rdx {
 
@@ -251,73 +250,6 @@ __global__ __launch_bounds__(XR_THREADS) void xrow16_k(GemmArgs a) {
     }
 }
 
-// ---- decode attention + o_proj (+ residual) in ONE launch ---------------------------------------------------------------------------------
-// The o_proj of batch 3-16 is a 33.5-MB weight stream behind a launch boundary: 7.5-9 us of which 5 are the fixed cost every weight-streaming
-// launch of this step pays, while the attention in front of it keeps HBM at 4 TB/s. Here both are roles of one launch of 8-wave
-// workgroups, two per CU. Workgroups [0, n_attn): attention -- PAIR: two heads of one row, one 4-wave half each (the stand-alone kernel's
-// body and register window, the halves share only the barriers and have the same context length), else one (row, head) on the 8-wave body
-// with the dedicated new-token wave (7 x 64 positions in registers: the latency form for few rows) -- output fragment-packed with write-through
-// 8-byte stores, then one arrival on the layer's sharded counter (handoff.h, the fence-free form of the batch 1-2 launches). Workgroups
-// [n_attn, +N / 16): one o_proj tile, wave w owns k in [512 w, +512): its WHOLE weight slice (16 fragments, 64 VGPRs, non-temporal) and the
-// residual are requested at entry and arrive while the attention runs; after the hand-off the activation fragments come through a ring of
-// agent-scope loads (they were written by other XCDs a moment ago), 16 MFMAs, the fixed-order LDS reduction and the residual epilogue of
-// xrow16_k. A consumer only waits on workgroups with smaller indices and every spin is bounded (handoff.h).
-constexpr int AO_WAVES = 8, AO_THREADS = AO_WAVES * 64, AO_CPW = 16, AO_XU = 8;
-
-template <typename T, bool PAIR>
-__global__ __launch_bounds__(AO_THREADS, 4) void attn_orow16_k(DecAttnArgs at, GemmArgs g, int n_attn, int* counter, int* err) {
-    extern __shared__ __attribute__((aligned(16))) float aosm[];
-    if ((int)blockIdx.x < n_attn) {
-        if (PAIR) {
-            const int hp = at.d.heads >> 1, half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);
-            const int b = blockIdx.x / hp, h = 2 * (blockIdx.x - b * hp) + half;
-            decode_attention_body<T, 4, false, NoWait, true, 0, false, true, 2>(at, h, b, aosm + (size_t)half * decode_attention_smem_floats(4, at.d.max_len));
-        } else {
-            const int b = blockIdx.x / at.d.heads, h = blockIdx.x - b * at.d.heads;
-            decode_attention_body<T, AO_WAVES, true, NoWait, false, 3, false, true>(at, h, b, aosm);
-        }
-        publish_sc1(counter, blockIdx.x);
-        return;
-    }
-    float* red = aosm;                                      // [8 waves][256]
-    const int lane = threadIdx.x & 63, wa = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 15, gq = lane >> 4;
-    const int tile = blockIdx.x - n_attn, c0 = wa * AO_CPW;
-    const u4* wp = reinterpret_cast<const u4*>(g.W) + ((size_t)tile * (AO_WAVES * AO_CPW) + c0) * 64 + lane;
-    u4 wr[AO_CPW], xr[AO_XU];
-#pragma unroll
-    for (int u = 0; u < AO_CPW; ++u) wr[u] = ldg16_nt(wp + (size_t)u * 64);
-    const int e_m = (threadIdx.x & 255) >> 4, e_nl = threadIdx.x & 15, n = tile * 16 + e_nl;
-    unsigned short res_bits = 0;
-    if (threadIdx.x < 256) res_bits = reinterpret_cast<const unsigned short*>(g.resid)[(size_t)min(e_m, g.M - 1) * g.ldr + n];
-    __builtin_amdgcn_sched_barrier(0);
-    WaitSharded{counter, n_attn, err, 2, nullptr}();
-    const T* X = reinterpret_cast<const T*>(g.X);
-    auto ldx = [&](int c) -> u4 {                           // fragment (c, row tile 0) of the packed block the attention role just wrote
-        const T* p = X + (size_t)(((c * 2) * 64 + lane) * 8);
-        const unsigned long long lo = ld8_agent(p), hi = ld8_agent(p + 4);
-        return (u4){(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
-    };
-#pragma unroll
-    for (int u = 0; u < AO_XU; ++u) xr[u] = ldx(c0 + u);
-    __builtin_amdgcn_sched_barrier(0);
-    v4f acc = (v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < AO_CPW; ++u) {
-        acc = mfma16(as_vec8<T>(wr[u]), as_vec8<T>(xr[u % AO_XU]), acc);
-        if (u + AO_XU < AO_CPW) xr[u % AO_XU] = ldx(c0 + u + AO_XU);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    *reinterpret_cast<float4*>(&red[wa * 256 + r * 16 + gq * 4]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    __syncthreads();
-    if (threadIdx.x < 256) {
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < AO_WAVES; ++i) v += red[i * 256 + threadIdx.x];
-        if (e_m < g.M) reinterpret_cast<T*>(g.out)[(size_t)e_m * g.ldo + n] = fromf<T>(tof<T>(from_bits16<T>(res_bits)) + rnd<T>(v));
-    }
-}
-
 // ---- host side ---------------------------------------------------------------------------------------------------------------------------
 bool xs16_rows_ok(int M) { return M >= 3 && M <= 16; }
 
@@ -353,29 +285,6 @@ bool xrow16_supported(const GemmArgs& a) {
 
 void launch_xrow16(int dtype, const GemmArgs& a, hipStream_t s) {
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((xrow16_k<T>), dim3(a.N / 16), dim3(XR_THREADS), 0, s, a));
-}
-
-// at: the stand-alone launch's arguments (out = the fragment-packed 32-row block, row tile 0 is used); g: o_proj as launch_xrow16 takes it
-static size_t attn_orow16_smem(const LlamaDims& d, int B) {
-    const size_t att = (d.heads * B > 256 ? 2 * decode_attention_smem_floats(4, d.max_len) : decode_attention_smem_floats(AO_WAVES, d.max_len)) * sizeof(float);
-    return std::max(att, (size_t)AO_WAVES * 256 * sizeof(float));
-}
-
-bool attn_orow16_supported(const LlamaDims& d, const GemmArgs& g, int B) {
-    return xrow16_supported(g) && d.head_dim == 128 && (d.heads & 1) == 0 && g.K == AO_WAVES * AO_CPW * 32 && g.K == d.heads * 128 && g.N / 16 <= 256 &&
-           attn_orow16_smem(d, B) <= (size_t)64 * 1024;
-}
-
-void launch_attn_orow16(int dtype, DecAttnArgs at, const GemmArgs& g, int B, int* counter, int* err, hipStream_t s) {
-    at.out_packed = 1; at.out_mt = 2;
-    const bool pair = at.d.heads * B > 256;             // more (row, head) pairs than CUs: two per workgroup on the 4-wave body
-    const int n_attn = pair ? B * (at.d.heads >> 1) : B * at.d.heads;
-    const size_t smem = attn_orow16_smem(at.d, B);
-    dim3 grid(n_attn + g.N / 16), block(AO_THREADS);
-    RDX_DISPATCH_T(dtype, T, {
-        if (pair) hipLaunchKernelGGL((attn_orow16_k<T, true>), grid, block, smem, s, at, g, n_attn, counter, err);
-        else hipLaunchKernelGGL((attn_orow16_k<T, false>), grid, block, smem, s, at, g, n_attn, counter, err);
-    });
 }
 
 }  // namespace rdx

@@ -2,7 +2,7 @@
 """Decode-step time per batch size (README's batch table, VERDICT r4 "next" 4): Vicuna-7B shapes, bf16 (or --dtype f16), prompt 160 tokens,
 (a) the hipGraph step replayed at context ~168 (rdx_time unit 0), (b) the mean step of a 256-token greedy decode (contexts 160 .. 415, what
 bench.py averages), with the HBM fraction (weights + KV of SURVEY 8d over 8 TB/s). `--ab` repeats every batch with the one-row-tile family
-off (rdx_set_option xs16 0: the 32-row kernels of xstat32.hip) and with xs16's fused attention + o_proj launch off (xs16_fuse 0). python tools/step_time.py [--batches 1,2,4,8,12,16,32] [--ab] [--fp8]"""
+off (rdx_set_option xs16 0: the 32-row kernels of xstat32.hip). python tools/step_time.py [--batches 1,2,4,8,12,16,32] [--ab] [--fp8]"""
 import argparse
 import os
 import sys
@@ -36,9 +36,8 @@ def main():
         eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
         ids = synth.synth_prompt_ids(B, T, vocab=lc.vocab, pad_rows=(B > 1), seed=7).to(eng.device)
         qf = synth.synth("t.qf_step", (B, 32, lc.qformer_dim), -1.0, 1.0).to(eng.device)
-        for fam, fuse in ([(1, 1), (1, 0), (0, 0)] if (a.ab and 3 <= B <= 16) else [(1, 1)]):
+        for fam in ([1, 0] if (a.ab and 3 <= B <= 16) else [1]):
             eng.set_option("xs16", fam)
-            eng.set_option("xs16_fuse", fuse)
             eng.generate(ids, qf, max_new=8, eos_id=-1, pad_id=0)
             step = eng.time_unit(0, 20)
             torch.cuda.synchronize()
@@ -56,7 +55,7 @@ def main():
             avg = ((time.perf_counter() - t0) / 2 - pre) / (N - 1) * 1e3
             kv = B * (T + N / 2.0) * 524288 + B * 524288
             frac = (wb + kv) / (avg * 1e-3) / 1e9 / bench.HBM_PEAK_GBS
-            name = (("xs16, attention + o_proj fused (4 launches / layer)" if fuse else "xs16 (5 launches / layer)") if (fam and 3 <= B <= 16) else "chained (3 / layer)" if B <= 2 else
+            name = ("xs16 (5 launches / layer)" if (fam and 3 <= B <= 16) else "chained (3 / layer)" if B <= 2 else
                     "row blocks (33-64 rows, 7 / layer)" if B > 32 else "xstat32 (7 launches / layer)")
             print(f"| {B} | {name} | {step:.3f} | {avg:.3f} | {frac * 100:.1f} % | {pre * 1e3:.1f} |", flush=True)
         eng.close()
