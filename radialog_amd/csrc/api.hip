@@ -266,11 +266,11 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         ALLOC(c, c->part_val, (size_t)B * c->n_vtiles * sizeof(float));
         ALLOC(c, c->part_idx, (size_t)B * c->n_vtiles * sizeof(int));
         // decode activations between kernels: from batch 3 whole fragment-packed blocks -- 32 rows (xstat32.hip / xs16.hip), or the row tiles of 33-128 rows
-        const int Bp = B > 2 ? std::max(32, (B + 15) / 16 * 16) : B;
+        const int Bp = B > 2 ? (B + 31) / 32 * 32 : B;            // whole 32-row blocks (the fp8 row-block kernels index their last block in full)
         ALLOC(c, c->dx, (size_t)B * H * 2); ALLOC(c, c->dxn, (size_t)Bp * H * 2);
         if (B > 2) ALLOC(c, c->kslab, (size_t)4 * Bp * H * sizeof(float));        // fp32 slabs of a K-split projection: [<= 4 groups][32, or the row tiles of 33-128 rows][H]
         ALLOC(c, c->dqkv, (size_t)B * c->ld.qkv_ld * 2);
-        ALLOC(c, c->dxs, 32 * sizeof(float));
+        ALLOC(c, c->dxs, (size_t)std::max(32, Bp) * sizeof(float));
         ALLOC(c, c->datt, (size_t)Bp * H * 2); ALLOC(c, c->dgu, (size_t)Bp * I * 2);
         ALLOC(c, c->pqe, (size_t)B * 32 * f.qformer_dim * 2); ALLOC(c, c->pimg, (size_t)B * 32 * H * 2);      // image splice rows
     }

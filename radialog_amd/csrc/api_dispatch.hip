@@ -104,11 +104,25 @@ void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split) {
 // the two block workgroups of a tile walker on one XCD (xstat32_k<.., BLK>: a weight fragment comes from HBM once, from that L2 once more); o_proj is
 // un-split (final rows: no slabs), down_proj (K = 11008) takes the prompt's weight-stationary kernel; the RMSNorms write the fragment-packed
 // [k / 32][row tiles][lane][8] the consumers read. Model-dtype weights only.
+bool blk64_fp8(rdx_ctx* c) { return !c->ll.empty() && fp8_weights(c->ll[0].wqkv); }
+
 bool blk64_ok(rdx_ctx* c, int B) {
     if (B <= 32 || B > RDX_MAX_ROWS || c->ll.empty()) return false;
     const rdx_config& f = c->cfg;
     const LlamaLayer& L = c->ll[0];
     const int mtl = (B + 15) / 16;
+    if (blk64_fp8(c)) {
+        // fp8 x fp8 (round 5): the 32-row fp8 kernels per row block -- e4m3 blocks + xscale for QKV / gate-up / lm_head, o_proj and down_proj K-split with
+        // the workgroup's own quantisation of its K range (xsplit32_k<.., A8, BLK>), slabs combined by the next RMSNorm
+        auto p8 = [&](GemmArgs a, int xp, int outp) { a.xpacked = xp; a.mtiles = mtl; a.out_packed = outp; a.xscale = c->dxs; a.xgroups = 1; return a; };
+        GemmArgs q = gargs(c->dxn, f.hidden, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); q.N = L.wqkv.Npad;
+        GemmArgs o = gargs(c->datt, f.hidden, L.wo, nullptr, c->dx, f.hidden, B);
+        GemmArgs gu = gargs(c->dxn, f.hidden, L.wgu, nullptr, c->dgu, f.inter, B);
+        GemmArgs d = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, f.hidden, B);
+        GemmArgs lm = gargs(c->dxn, f.hidden, c->lm_head, nullptr, nullptr, f.vocab, B); lm.N = c->lm_head.Npad;
+        return f.hidden == 4096 && c->kslab && c->dxs && xstat_blk8_supported(p8(q, 4, 0), EPI_NONE) && xsplit_blk8_groups(p8(o, 2, 0)) == 2 &&
+               xstat_blk8_supported(p8(gu, 4, 2), EPI_SILU_MUL) && xsplit_blk8_groups(p8(d, 2, 0)) == 4 && xstat_blk8_supported(p8(lm, 4, 0), EPI_LOGITS);
+    }
     auto pk = [&](GemmArgs a, int outp) { a.xpacked = 3; a.mtiles = mtl; a.out_packed = outp; return a; };
     GemmArgs q = gargs(c->dxn, f.hidden, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); q.N = L.wqkv.Npad;
     GemmArgs o = gargs(c->datt, f.hidden, L.wo, nullptr, c->dx, f.hidden, B); o.resid = c->dx; o.ldr = f.hidden;

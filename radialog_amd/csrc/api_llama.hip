@@ -38,10 +38,18 @@ static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, c
         if (!blk64_ok(c, B)) { c->unsupported = "more than 32 decoder rows need model-dtype weights at hidden 4096 / inter 11008 (the row-block family)"; return; }
         const int mtl = (B + 15) / 16;
         const int pend = (x == c->dx) ? c->pend_groups : 0;       // the last layer's K-split down_proj left its slabs (and the residual add) to this norm
-        if (pend) { c->pend_groups = 0; launch_rmsnorm_packed_slab(f.dtype, c->dx, c->final_norm, c->dxn, B, mtl, f.rms_eps, c->kslab, pend, c->stream); }
+        if (blk64_fp8(c)) {
+            if (pend) c->pend_groups = 0;
+            launch_rmsnorm_blk_fp8(f.dtype, const_cast<void*>(x), c->final_norm, c->dxn, c->dxs, B, mtl, f.rms_eps, pend ? c->kslab : nullptr, pend, c->stream);
+            a.X = c->dxn; a.norm_w = nullptr; a.xpacked = 4; a.mtiles = mtl; a.xscale = c->dxs; a.xgroups = 1;
+            launch_xstat_blk8(f.dtype, a, EPI_LOGITS, c->stream);
+        }
+        else if (pend) { c->pend_groups = 0; launch_rmsnorm_packed_slab(f.dtype, c->dx, c->final_norm, c->dxn, B, mtl, f.rms_eps, c->kslab, pend, c->stream); }
         else launch_rmsnorm_packed(f.dtype, x, c->final_norm, c->dxn, B, mtl, f.hidden, f.rms_eps, c->stream);
-        a.X = c->dxn; a.norm_w = nullptr; a.xpacked = 3; a.mtiles = mtl;
-        launch_xstat_blk(f.dtype, a, EPI_LOGITS, c->stream);
+        if (!blk64_fp8(c)) {
+            a.X = c->dxn; a.norm_w = nullptr; a.xpacked = 3; a.mtiles = mtl;
+            launch_xstat_blk(f.dtype, a, EPI_LOGITS, c->stream);
+        }
     }
     else if (x == c->dx && xs16_ok(c, B)) xs16_proj(c, a, EPI_LOGITS);        // batch 3-16 decode: the final RMSNorm is the kernel's prologue
     else skinny(c, a, EPI_LOGITS);
@@ -228,6 +236,28 @@ bool decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, long step
         // 33-128 rows: the row-block family (api_dispatch.hip blk64_ok): 7 launches per layer, no K-split slabs
         if (!blk64_ok(c, B)) { c->unsupported = "more than 32 decoder rows need model-dtype weights at hidden 4096 / inter 11008 (the row-block family)"; return false; }
         const int mtl = (B + 15) / 16;
+        if (blk64_fp8(c)) {
+            // fp8 x fp8: the 32-row fp8 kernels per row block (api_dispatch.hip blk64_ok); both residual projections K-split, their slabs + residual left to the next RMSNorm
+            auto p8 = [&](GemmArgs a, int xp, int outp) { a.xpacked = xp; a.mtiles = mtl; a.out_packed = outp; a.xscale = c->dxs; a.xgroups = 1; return a; };
+            for (int l = 0; l < f.layers; ++l) {
+                const LlamaLayer& L = c->ll[l];
+                { const int pend = c->pend_groups; c->pend_groups = 0;
+                  launch_rmsnorm_blk_fp8(dt, c->dx, L.attn_norm, c->dxn, c->dxs, B, mtl, f.rms_eps, pend ? c->kslab : nullptr, pend, s); }
+                { GemmArgs a = gargs(c->dxn, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; launch_xstat_blk8(dt, p8(a, 4, 0), EPI_NONE, s); }
+                DecAttnArgs at;
+                at.d = c->ld; at.qkv = c->dqkv; at.lbq = L.lora_bq; at.lbv = L.lora_bv; at.cos_t = c->rope_cos; at.sin_t = c->rope_sin;
+                at.pos = c->d_pos; at.slot_b = c->d_slot; at.key_mask = c->key_mask; at.cur_rope = c->d_cur_rope;
+                at.kcache = kv_ptr(c, c->kcache, l); at.vcache = kv_ptr(c, c->vcache, l); at.out = c->datt;
+                at.out_packed = 2;                       // the 64-deep order, one 32-row block per 32 rows
+                launch_decode_attention(dt, at, B, s);
+                { GemmArgs a = gargs(c->datt, H, L.wo, nullptr, c->dx, H, B); launch_xsplit_blk8(dt, p8(a, 2, 0), c->kslab, s); }
+                launch_rmsnorm_blk_fp8(dt, c->dx, L.mlp_norm, c->dxn, c->dxs, B, mtl, f.rms_eps, c->kslab, 2, s);
+                { GemmArgs a = gargs(c->dxn, H, L.wgu, nullptr, c->dgu, f.inter, B); launch_xstat_blk8(dt, p8(a, 4, 2), EPI_SILU_MUL, s); }
+                { GemmArgs a = gargs(c->dgu, f.inter, L.wdown, nullptr, c->dx, H, B); launch_xsplit_blk8(dt, p8(a, 2, 0), c->kslab, s); c->pend_groups = 4; }
+            }
+            lm_head_and_greedy(c, c->dx, B, logits, out_step, step_stride, /*advance=*/1);
+            return false;
+        }
         auto pk = [&](GemmArgs a, int outp) { a.xpacked = 3; a.mtiles = mtl; a.out_packed = outp; return a; };
         for (int l = 0; l < f.layers; ++l) {
             const LlamaLayer& L = c->ll[l];

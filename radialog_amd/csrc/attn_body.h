@@ -359,7 +359,9 @@ __device__ __forceinline__ void decode_attention_body(const DecAttnArgs& a, cons
             // out_packed: the 32-row fragment-packed block the K-split o_proj reads (xsplit32_k): [k / 32][b / 16][(k % 32) / 8][b % 16][8]
             // (out_packed 2: the fp8 consumer's 64-deep order, fragment 2 (k / 64) + (k % 16) / 8, g = (k % 64) / 16)
             const int pf = a.out_packed == 2 ? 2 * (k >> 6) + ((k & 15) >> 3) : (k >> 5), pg = a.out_packed == 2 ? ((k & 63) >> 4) : ((k & 31) >> 3);
-            const size_t o = a.out_packed ? ((size_t)((pf * a.out_mt + (b >> 4)) * 64 + pg * 16 + (b & 15)) << 3) + (k & 7) : (size_t)b * H + k;
+            // (out_packed 2 beyond 32 rows: one such 32-row block per 32 rows, at a block stride of 32 H elements)
+            const size_t o = a.out_packed == 2 ? (size_t)(b >> 5) * (32 * H) + (((size_t)((pf * 2 + ((b >> 4) & 1)) * 64 + pg * 16 + (b & 15)) << 3) + (k & 7))
+                           : a.out_packed ? ((size_t)((pf * a.out_mt + (b >> 4)) * 64 + pg * 16 + (b & 15)) << 3) + (k & 7) : (size_t)b * H + k;
             reinterpret_cast<T*>(a.out)[o] = fromf<T>(v);
         }
     } else if (tid < D / 4) {                                  // write-through 8-byte stores (4 dims per lane)

@@ -142,6 +142,7 @@ template <typename T, int PACK>
 __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __restrict__ w, T* __restrict__ out, float eps, int n_rows,
                                                      const float* __restrict__ slab, int groups, T* xw, float* __restrict__ xscale = nullptr, int mtl = 0) {
     // PACK 6 (round 5, 33-128 decoder rows): the PACK 3 order over `mtl` row tiles WITH the pending K-split slabs [groups][16 mtl][H] folded in first
+    // PACK 4 with mtl > 0 (fp8 at 33-128 rows): ceil(mtl / 2) blocks of 32 rows, block b = the PACK 4 e4m3 block at byte offset 32 H b; slabs [groups][32 blocks][H]
     typedef typename Vec8<T>::type V8;
     constexpr int H = 4096;
     __shared__ float red[32];
@@ -152,10 +153,11 @@ __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __rest
         return out + ((size_t)((f * (PACK == 3 ? groups : PACK == 6 ? mtl : 2) + (int)(row >> 4)) * 64 + g * 16 + (int)(row & 15)) << 3);
     };
     const int i0 = threadIdx.x * 8, i1 = i0 + 2048;
+    const size_t row8 = PACK == 4 ? (row & 31) : row;          // PACK 4: the row inside its 32-row e4m3 block ...
+    unsigned char* const o8 = reinterpret_cast<unsigned char*>(out) + (PACK == 4 ? (row >> 5) * (size_t)(32 * H) : (size_t)0);      // ... and the block
     if ((PACK == 4 || PACK == 5) && (int)row >= n_rows) {
-        unsigned char* o8 = reinterpret_cast<unsigned char*>(out);
-        *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row, i0, H)) = (u2){0u, 0u};
-        *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row, i1, H)) = (u2){0u, 0u};
+        *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row8, i0, H)) = (u2){0u, 0u};
+        *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row8, i1, H)) = (u2){0u, 0u};
         if (threadIdx.x == 0) xscale[row] = 1.0f;
         return;
     }
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __rest
         for (int gq = 0; gq < 4; ++gq)
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const float* p = slab + ((size_t)min(gq, groups - 1) * (PACK == 6 ? 16 * mtl : 32) + row) * H + (k ? i1 : i0);
+                const float* p = slab + ((size_t)min(gq, groups - 1) * (PACK == 6 ? 16 * mtl : (PACK == 4 && mtl) ? 32 * ((mtl + 1) >> 1) : 32) + row) * H + (k ? i1 : i0);
                 sp[gq][k][0] = *reinterpret_cast<const float4*>(p);
                 sp[gq][k][1] = *reinterpret_cast<const float4*>(p + 4);
             }
@@ -208,9 +210,8 @@ __global__ __launch_bounds__(256) void rmsnorm4096_k(const T* x, const T* __rest
         float sc, inv;
         fp8_scale(am, sc, inv);
         if (threadIdx.x == 0) xscale[row] = sc;
-        unsigned char* o8 = reinterpret_cast<unsigned char*>(out);
-        *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row, i0, H)) = quant8<T>(o[0], inv);
-        *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row, i1, H)) = quant8<T>(o[1], inv);
+        *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row8, i0, H)) = quant8<T>(o[0], inv);
+        *reinterpret_cast<u2*>(dst8<PACK == 4 ? 4 : 5>(o8, row8, i1, H)) = quant8<T>(o[1], inv);
         return;
     }
     stg16(dst(i0), as_u4<T>(o[0]));
@@ -266,6 +267,12 @@ void launch_rmsnorm_packed32_fp8(int dtype, void* x, const void* w, void* out8, 
     }
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm_k<T, 4>), dim3(32), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out8, H, eps, rows, slab,
                                                 groups, (T*)x, xscale));
+}
+
+// ... and fp8 at 33-128 rows: ceil(mtiles / 2) such 32-row e4m3 blocks at a block stride of 32 H bytes, xscale[32 blocks], slabs [groups][32 blocks][H]. H = 4096.
+void launch_rmsnorm_blk_fp8(int dtype, void* x, const void* w, void* out8, float* xscale, int rows, int mtiles, float eps, const float* slab, int groups, hipStream_t s) {
+    RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((rmsnorm4096_k<T, 4>), dim3(32 * ((mtiles + 1) / 2)), dim3(256), 0, s, (const T*)x, (const T*)w, (T*)out8, eps, rows, slab,
+                                                groups, (T*)x, xscale, mtiles));
 }
 
 void launch_rmsnorm_packed32(int dtype, void* x, const void* w, void* out, int rows, int H, float eps, int pack, const float* slab,

@@ -80,7 +80,7 @@ struct rdx_ctx {
     float* part_val = nullptr; int* part_idx = nullptr; int n_vtiles = 0;
     // decode-step activations ([max_batch] rows) and prefill activations (grown on demand)
     void *dx = nullptr, *dxn = nullptr, *dqkv = nullptr, *datt = nullptr, *dgu = nullptr;
-    float* dxs = nullptr;            // fp8 path, batch 3-32 decode: xscale[32] of the e4m3 activation block in dxn (rmsnorm4096_k<T, 4>)
+    float* dxs = nullptr;            // fp8 path, batch 3-128 decode: xscale[rows in 32-row blocks] of the e4m3 activation block(s) in dxn (rmsnorm4096_k<T, 4>)
     void* pxq = nullptr; float* pxs = nullptr;   // fp8 path, prefill: e4m3 activations [rows][max(hidden, inter)] and their scales [rows][4]
     std::string unsupported;         // set by the dispatch when a shape has no kernel in the current mode (fp8 weights); reported by the entry points
     float* kslab = nullptr;          // batch 3-32 decode: fp32 partial slabs [<= 4 groups][32][hidden] of a K-split projection
@@ -171,7 +171,8 @@ bool down_split_ok(rdx_ctx* c, const LlamaLayer& L, int B);
 void launch_ksplit(rdx_ctx* c, const GemmArgs& a);
 void launch_down(rdx_ctx* c, const LlamaLayer& L, int B, bool split);
 // batch 3-16, model-dtype weights, hidden 4096: the decode step's projections on xs16.hip (no stand-alone RMSNorm, no K-split slabs)
-bool blk64_ok(rdx_ctx* c, int B);      // 33-128 rows: the row-block decode family
+bool blk64_ok(rdx_ctx* c, int B);      // 33-128 rows: the row-block decode family (model-dtype weights, or fp8 x fp8: blk64_fp8)
+bool blk64_fp8(rdx_ctx* c);            // ... its fp8 x fp8 form is the one in use (e4m3 decoder weights)
 bool xs16_ok(rdx_ctx* c, int B);
 void xs16_proj(rdx_ctx* c, GemmArgs a, int epi);          // a.norm_w set, a.X = the row-major residual stream
 void xs16_row(rdx_ctx* c, const void* xpacked, const GemmW& W, int B);     // dx += T(xpacked . W^T), in place

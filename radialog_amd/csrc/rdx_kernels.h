@@ -135,6 +135,13 @@ void launch_rmsnorm_packed_slab(int dtype, void* x, const void* w, void* out, in
 // K-split down_proj / o_proj over 33-128 rows (xsplit32_k<.., BLK>): X xpacked 3 over a.mtiles row tiles, slabs [groups][16 mtiles][N]
 bool xsplit_blk_supported(const GemmArgs& a);
 void launch_xsplit_blk(int dtype, const GemmArgs& a, float* slab, hipStream_t s);
+// ... and with fp8 weights (fp8 x fp8): every 32-row block keeps the layouts of the 32-row fp8 kernels at a block stride -- xstat: X = e4m3 blocks (xpacked 4, 32 K bytes
+// apart) + xscale[rows]; xsplit: X = model-dtype 64-deep blocks (xpacked 2, 32 K elements apart), slabs [groups][32 blocks][N], groups = 2 (K = 4096) or 4 (K = 11008)
+bool xstat_blk8_supported(const GemmArgs& a, int epi);
+void launch_xstat_blk8(int dtype, const GemmArgs& a, int epi, hipStream_t s);
+int xsplit_blk8_groups(const GemmArgs& a);
+void launch_xsplit_blk8(int dtype, const GemmArgs& a, float* slab, hipStream_t s);
+void launch_rmsnorm_blk_fp8(int dtype, void* x, const void* w, void* out8, float* xscale, int rows, int mtiles, float eps, const float* slab, int groups, hipStream_t s);
 bool wsgemm_supported(const GemmArgs& a, const ConvGeom& cg, int epi);
 void launch_wsgemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, const void* zero16, hipStream_t s);
 

@@ -40,7 +40,9 @@ __device__ __forceinline__ v4f xs_mfma8(const u4& a, const u4& b, v4f c) {
 template <typename T, int EPI, bool W8, bool A8 = false, bool BLK = false>
 __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
     static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
-    static_assert(!BLK || !W8, "the row-block mode is model-dtype only");
+    static_assert(!BLK || !W8 || A8, "row blocks with fp8 weights: fp8 x fp8 only");
+    // (BLK with fp8, round 5: every 32-row block keeps the 32-row e4m3 / 64-deep layouts of the fp8 kernels, block b at a block stride -- xscale, the
+    //  row-major outputs and the slabs are indexed by the global row)
     constexpr int TPI = W8 ? 2 : 1;                   // tiles per trip
     constexpr int LPT = W8 ? XS_CPW / 2 : XS_CPW;     // 16-byte weight loads per wave per tile
     constexpr int RING = TPI * LPT;                   // 16
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
     for (int mt = 0; mt < 2; ++mt) {
         if (A8) {
             // e4m3 block [chunk j][mt][lane][16]: this wave's chunks j = (XS_CPW / 2) wa .. + XS_CPW / 2
-            const u4* x8 = reinterpret_cast<const u4*>(a.X) + (size_t)((wa * (XS_CPW / 2)) * 2 + mt) * 64 + lane;
+            const u4* x8 = reinterpret_cast<const u4*>(a.X) + (BLK ? (size_t)mb * (32 * XS_K / 16) : (size_t)0) + (size_t)((wa * (XS_CPW / 2)) * 2 + mt) * 64 + lane;
 #pragma unroll
             for (int c = 0; c < NXF; ++c) xf[mt][c] = ldg16(x8 + (size_t)c * 128);
         } else if (BLK) {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
             } else if (EPI == EPI_SILU_MUL) {
                 // rows 0-7 of a tile are gate, 8-15 the matching up rows: the partner sits 8 lanes away in the same DPP row
                 const float u = dpp_mov<DPP_ROR8>(v);
-                if (BLK && a.out_packed) {
+                if (BLK && a.out_packed == 3) {
                     // the prompt's fragment-packed [k / 32][mtiles][lane][8] (out_packed 3: what wstat_k / this kernel's BLK mode read)
                     const int mtg = 2 * mb + e_mt;
                     if (e_nl < 8 && t_o < ntiles && mtg < a.mtiles)
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
                     // (out_packed 2, fp8 consumer: the 64-deep order -- piece t_o is fragment 2 (t_o / 8) + (t_o & 1), g = (t_o & 7) / 2)
                     const int pf = a.out_packed == 2 ? 2 * (t_o >> 3) + (t_o & 1) : (t_o >> 2), pg = a.out_packed == 2 ? ((t_o & 7) >> 1) : (t_o & 3);
                     if (e_nl < 8 && t_o < ntiles)
-                        out[((size_t)((pf * 2 + e_mt) * 64 + pg * 16 + (e_idx >> 4)) << 3) + e_nl] =
+                        out[(BLK ? (size_t)mb * 32 * (ntiles * 8) : (size_t)0) + ((size_t)((pf * 2 + e_mt) * 64 + pg * 16 + (e_idx >> 4)) << 3) + e_nl] =
                             e_m < a.M ? fromf<T>(swiglu<T>(v, u)) : fromf<T>(0.f);
                 } else if (e_nl < 8 && ok) out[(size_t)e_m * a.ldo + t_o * 8 + e_nl] = fromf<T>(swiglu<T>(v, u));
             } else if (EPI == EPI_LOGITS) {
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
 template <typename T, int KC, int KGN, bool W8, int TPI, bool A8 = false, bool BLK = false>
 __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __restrict__ slab) {
     static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
-    static_assert(!BLK || !W8, "the row-block mode is model-dtype only");
+    static_assert(!BLK || !W8 || A8, "row blocks with fp8 weights: fp8 x fp8 only");
     constexpr int SLOTS = XS_WAVES * KGN, CPW = (KC + SLOTS - 1) / SLOTS, FPL = W8 ? 2 : 1;   // fragments (MFMAs per row tile) per load
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
     float* red = reinterpret_cast<float*>(smx);       // [2 bufs][TPI][8 waves][2 mt][256]
@@ -308,14 +310,15 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 #pragma unroll
         for (int j = 0; j < CPW * FPL; ++j) {
             const int f = (c0 + min(j / FPL, cnt - 1)) * FPL + (j % FPL);          // packed fragment index (32-deep, or 2 per 64-deep chunk)
-            const u4 v = BLK ? ldg16(X + ((size_t)((f * a.mtiles + min(2 * mb + mt, a.mtiles - 1)) * 64 + lane) << 3))
-                             : ldg16(X + ((size_t)((f * 2 + mt) * 64 + lane) << 3));
+            // BLK: the row-tile order of the model-dtype path (xpacked 3), or -- fp8 -- block mb's own 32-row block in the 64-deep order (xpacked 2)
+            const u4 v = (BLK && !W8) ? ldg16(X + ((size_t)((f * a.mtiles + min(2 * mb + mt, a.mtiles - 1)) * 64 + lane) << 3))
+                                      : ldg16(X + (BLK ? (size_t)mb * 32 * a.K : (size_t)0) + ((size_t)((f * 2 + mt) * 64 + lane) << 3));
             xf[mt][j] = (j / FPL) < cnt ? v : (u4){0u, 0u, 0u, 0u};
         }
     __builtin_amdgcn_sched_barrier(0);
 
     const int e_mt = threadIdx.x >> 8, e_idx = threadIdx.x & 255, e_m = (BLK ? 32 * mb : 0) + e_mt * 16 + (e_idx >> 4), e_nl = e_idx & 15;
-    float* sl = slab + ((size_t)kg * (BLK ? 16 * a.mtiles : 32) + e_m) * a.N;
+    float* sl = slab + ((size_t)kg * (BLK ? (W8 ? 32 * ((a.mtiles + 1) >> 1) : 16 * a.mtiles) : 32) + e_m) * a.N;       // slab plane: the padded row count
     u4 xq[2][A8 ? CPW : 1];
     float e_xs = 1.f;
     if (A8) {
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
         {
             float am = 0.f;
 #pragma unroll
-            for (int i = 0; i < XS_WAVES; ++i) am = fmaxf(am, rowmax[i * 32 + e_m]);
+            for (int i = 0; i < XS_WAVES; ++i) am = fmaxf(am, rowmax[i * 32 + e_mt * 16 + (e_idx >> 4)]);       // this thread's row WITHIN the block
             float inv;
             fp8_scale(am, e_xs, inv);
         }
@@ -449,6 +452,35 @@ void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
             if (w8) hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2, true>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
             else hipLaunchKernelGGL((xsplit32_k<T, 128, 2, false, 1>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
         }
+    });
+}
+
+// fp8 x fp8 on row blocks (33-128 rows, round 5): X = per-block 32-row layouts at a block stride -- xstat: e4m3 blocks (xpacked 4) + xscale[rows];
+// xsplit: model-dtype 64-deep blocks (xpacked 2), each K-group workgroup quantises its range; slabs [groups][32 NB][N]
+bool xstat_blk8_supported(const GemmArgs& a, int epi) {
+    return a.xpacked == 4 && a.xscale && a.mtiles >= 3 && a.mtiles <= 8 && a.M <= a.mtiles * 16 && a.K == XS_K && a.W8 && a.wscale && !a.norm_w && !a.bias &&
+           (epi == EPI_NONE || epi == EPI_SILU_MUL || epi == EPI_LOGITS) && (a.out_packed == 0 || (a.out_packed == 2 && epi == EPI_SILU_MUL)) && (a.N + 15) / 16 >= 128;
+}
+
+void launch_xstat_blk8(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
+    const size_t smem = (size_t)2 * 2 * XS_WAVES * 2 * 256 * 4;
+    RDX_DISPATCH_T(dtype, T, {
+        if (epi == EPI_NONE) hipLaunchKernelGGL((xstat32_k<T, EPI_NONE, true, true, true>), dim3(256), dim3(XS_THREADS), smem, s, a);
+        else if (epi == EPI_SILU_MUL) hipLaunchKernelGGL((xstat32_k<T, EPI_SILU_MUL, true, true, true>), dim3(256), dim3(XS_THREADS), smem, s, a);
+        else if (epi == EPI_LOGITS) hipLaunchKernelGGL((xstat32_k<T, EPI_LOGITS, true, true, true>), dim3(256), dim3(XS_THREADS), smem, s, a);
+    });
+}
+
+int xsplit_blk8_groups(const GemmArgs& a) {
+    if (a.xpacked != 2 || !a.W8 || !a.wscale || a.mtiles < 3 || a.mtiles > 8 || a.M > a.mtiles * 16 || a.norm_w || a.bias || (a.N + 15) / 16 < 128 || (a.N + 15) / 16 > 512) return 0;
+    return a.K == 11008 ? 4 : a.K == 4096 ? 2 : 0;
+}
+
+void launch_xsplit_blk8(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
+    const size_t smem = (size_t)2 * 2 * XS_WAVES * 2 * 256 * 4;
+    RDX_DISPATCH_T(dtype, T, {
+        if (a.K == 11008) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2, true, true>), dim3(256), dim3(XS_THREADS), smem, s, a, slab);
+        else hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2, true, true>), dim3(256), dim3(XS_THREADS), smem, s, a, slab);
     });
 }
 
