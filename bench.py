@@ -26,6 +26,7 @@ Rank 0 prints ONE JSON line. `value` = reports/s of the whole job with inputs re
                TFLOP/s over the 2.5 PFLOP/s dense bf16 peak).
   b32          (batch-1 runs) BASELINE configs[2] / [3] timed in the same process at every world size: per-GPU batch 32, hipGraph step.
   fp8_b32      (batch-1 runs) BASELINE configs[4]: e4m3 decoder weights AND activations on the fp8 MFMA, per-GPU batch 32.
+  b64 / b128 / fp8_b128   (batch-1 runs, one rank) 64 and 128 reports per GPU on the row-block decode family (33-128 rows), the last with fp8 weights.
   token_check  the first 8 greedy tokens of row 0 of every timed configuration against tests/golden/bench_tokens.json (exit 3 on a miss).
   cpu_baseline the CPU oracle (oracle/ref_cpu.py, kind "port") running BASELINE configs[0] for real on the host cores: one
                448 px image through the full-size encoder, the 160-token prefill and 32 greedy tokens through all 32 layers.
@@ -780,6 +781,9 @@ def main():
         # 288 GB of HBM buy when the 13.2 GB weight stream of a decode step is amortised over twice the reports
         subs["b64"] = (timed_run(64, False, 2, 1), f"per-GPU batch 64 (global {64 * world}): beyond BASELINE configs[2]/[3]'s 32 per GPU, same pipeline, hipGraph step")
         subs["b128"] = (timed_run(128, False, 2, 1), f"per-GPU batch 128 (global {128 * world}), the most one context holds (RDX_MAX_ROWS): four 32-row blocks per tile walker")
+        if not args.no_fp8:
+            subs["fp8_b128"] = (timed_run(128, True, 2, 1), f"per-GPU batch 128 (global {128 * world}) with the configs[4] weight path: fp8 x fp8 kernels per 32-row block "
+                                                            "(row by row the arithmetic of fp8_b32: tests/test_gpu_parity.py::test_fp8_row_blocks_equal_the_32_row_kernels_row_by_row)")
     f16_r = None
     if B == 1 and not args.fp8 and args.dtype != "f16" and world == 1 and not args.no_f16 and not STUB:
         # the reference's dtype, in which token identity with the CPU path actually holds (parity_f16): the same configs[1] workload timed in fp16

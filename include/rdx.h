@@ -46,8 +46,8 @@ typedef struct rdx_config {
     int v_img, v_stem, v_planes[4], v_blocks[4], v_b2v, v_proj;
     float v_ln_eps;
     /* capacities */
-    int max_batch;                                 /* decode rows held in the KV cache: 1 .. 128 in the model dtype (round 5: rows 33-128 decode in
-                                                    * 32-row blocks that share an XCD's L2), 1 .. 32 usable with fp8 weights (RDX_W_GEMM_FP8)          */
+    int max_batch;                                 /* decode rows held in the KV cache: 1 .. 128 (round 5: rows 33-128 decode in 32-row blocks that
+                                                    * share an XCD's L2 -- model dtype, or the fp8 x fp8 kernels with fp8 weights, RDX_W_GEMM_FP8)    */
     int max_len;                                   /* KV slots per row (prompt + generated), multiple of 32        */
     int enable_vision, enable_llama;               /* build only one half if 0                                     */
     /* findings classifier (findings_classifier/chexpert_model.py:7-21): the same trunk + projector (v_*) followed by

@@ -35,7 +35,7 @@ static void lm_head_and_greedy(rdx_ctx* c, const void* x, int B, void* logits, c
     a.out_step = out_step; a.out_step_stride = step_stride;
     if (B > 32) {
         // 33-128 rows: final RMSNorm into the fragment-packed row tiles, lm_head in two row blocks (xstat32_k<EPI_LOGITS, BLK>)
-        if (!blk64_ok(c, B)) { c->unsupported = "more than 32 decoder rows need model-dtype weights at hidden 4096 / inter 11008 (the row-block family)"; return; }
+        if (!blk64_ok(c, B)) { c->unsupported = "more than 32 decoder rows need hidden 4096 / inter 11008 (the row-block family)"; return; }
         const int mtl = (B + 15) / 16;
         const int pend = (x == c->dx) ? c->pend_groups : 0;       // the last layer's K-split down_proj left its slabs (and the residual add) to this norm
         if (blk64_fp8(c)) {
@@ -104,7 +104,7 @@ int prefill_impl(rdx_ctx* c, const int32_t* ids, const int32_t* mask, int B, int
     launch_embed_splice(dt, ids, c->d_img_pos, c->embed, f.vocab, c->pimg, 32, c->px, B, T, H, qformer_embs ? 1 : 0, s);
 
     const bool fp8 = fp8_weights(c->ll[0].wqkv);
-    if (B > 32 && !blk64_ok(c, B)) return fail(c, -8, "rdx_prefill: more than 32 rows per context need model-dtype weights at the Vicuna-7B widths (the 33-64 row decode family)");
+    if (B > 32 && !blk64_ok(c, B)) return fail(c, -8, "rdx_prefill: more than 32 rows per context need the Vicuna-7B widths (hidden 4096, inter 11008: the row-block decode family)");
     if (fp8) {
         // fp8 weights (BASELINE configs[4]): every projection of the prompt is an fp8 x fp8 MFMA GEMM (gemm8.hip) over e4m3 activations with one
         // scale per row and K group -- 1 group behind an RMSNorm (quantised in its epilogue), 2 for o_proj, 4 for down_proj (quant_rows_k on the
@@ -234,7 +234,7 @@ bool decode_step_launch(rdx_ctx* c, void* logits, const int* out_step, long step
     }
     if (B > 32) {
         // 33-128 rows: the row-block family (api_dispatch.hip blk64_ok): 7 launches per layer, no K-split slabs
-        if (!blk64_ok(c, B)) { c->unsupported = "more than 32 decoder rows need model-dtype weights at hidden 4096 / inter 11008 (the row-block family)"; return false; }
+        if (!blk64_ok(c, B)) { c->unsupported = "more than 32 decoder rows need hidden 4096 / inter 11008 (the row-block family)"; return false; }
         const int mtl = (B + 15) / 16;
         if (blk64_fp8(c)) {
             // fp8 x fp8: the 32-row fp8 kernels per row block (api_dispatch.hip blk64_ok); both residual projections K-split, their slabs + residual left to the next RMSNorm

@@ -19,7 +19,7 @@
 using namespace rdx;
 
 // decoder rows per context: batch 1-2 chained launches, 3-16 xs16.hip, 3-32 xstat32.hip, 33-128 the row-block family (NB = ceil(rows / 32) row blocks per
-// tile walker sharing an XCD's L2: xstat32_k / xsplit32_k<.., BLK>; model-dtype weights only). 128 rows x 512 slots of KV = 68 GB of the 288.
+// tile walker sharing an XCD's L2: xstat32_k / xsplit32_k<.., BLK>; fp8 weights: the 32-row fp8 x fp8 kernels per block). 128 rows x 512 slots of KV = 68 GB of the 288.
 constexpr int RDX_MAX_ROWS = 128;
 
 struct GemmW { void* w = nullptr; int N = 0, K = 0, Npad = 0; void* w8 = nullptr; float* scale = nullptr; };   // w8/scale: fp8 copy

@@ -24,13 +24,13 @@ from radialog_amd.tokenizer import load_tokenizer                          # noq
 
 
 ENGINE_ROWS = 128     # librdx holds up to 128 decoder rows per context in the model dtype (rdx_ctx.h RDX_MAX_ROWS; round 5: the row-block decode family) ...
-ENGINE_ROWS_FP8 = 32  # ... and 32 with fp8 weights (the fp8 x fp8 decode kernels are the 32-row family)
+ENGINE_ROWS_FP8 = 128  # ... and with fp8 weights (round 5: the 32-row fp8 x fp8 decode kernels per row block)
 
 
 def engine_rows(batch_size, num_beams, bin_qa=False, all_qa=False, fp8=False):
     """Rows the engine must hold at once -> (max_batch, report-loop batch size, findings-QA batch size): the report loop runs batch_size
     prompts x num_beams beam rows -- the reference's 12 x 3 = 36 (test.py:267,:279) in ONE pass since round 5 (chunked only when that exceeds the
-    engine's rows: 128, 32 with fp8 weights); the binary QA pass is greedy (14 questions per study, test.py:548-590); the findings QA runs
+    engine's rows: 128); the binary QA pass is greedy (14 questions per study, test.py:548-590); the findings QA runs
     batches of 5 with beams (test.py:610-650)."""
     rows = ENGINE_ROWS_FP8 if fp8 else ENGINE_ROWS
     beams = max(num_beams, 1)

@@ -425,6 +425,29 @@ def test_batch_3_16_decode_families_agree_and_match_oracle(B):
         eng.close()
 
 
+def test_fp8_row_blocks_equal_the_32_row_kernels_row_by_row():
+    """fp8 x fp8 at 33-128 rows runs the 32-row fp8 kernels once per 32-row block (xstat32_k / xsplit32_k <.., A8, BLK>, rmsnorm4096_k<4> over blocks): a row's
+    arithmetic -- its own e4m3 scales, the K groups of o_proj / down_proj, every accumulation order -- is what the 32-row family computes for that row.
+    So 40 rows in one pass (a full block + a ragged one) must reproduce, BIT FOR BIT, the tokens and logits of rows 0-31 and rows 32-39 run as two
+    32-row-family calls on the same engine (production width, two layers, hipGraph step)."""
+    from radialog_amd.engine import RdxEngine, synth_getter
+    cfg, _ = _production_width_weights(2)
+    B, T, N = 40, 96, 6
+    ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, pad_rows=True, seed=31)
+    qf = synth.synth("t.qf8blk", (B, 32, cfg.llama.qformer_dim), -1.0, 1.0)
+    eng = RdxEngine(cfg, dtype="bf16", device=0, max_batch=B, max_len=128, lora=True, vision=False, weights_fp8=True)
+    eng.load_weights(synth_getter(cfg, eng.device, lora=True), vision=False)
+    toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
+    toks, scores = toks.cpu(), scores[:n].float().cpu()
+    assert not torch.isnan(scores).any()
+    for lo, hi in ((0, 32), (32, 40)):
+        t2, s2, n2 = eng.generate(ids[lo:hi], qf[lo:hi], max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
+        assert n2 == n and torch.equal(t2.cpu(), toks[lo:hi]), f"rows {lo}..{hi - 1}: tokens differ between the row-block pass and the 32-row family"
+        d = float((s2[:n2].float().cpu() - scores[:, lo:hi]).abs().max())
+        assert d == 0.0, f"rows {lo}..{hi - 1}: logits differ by {d} between the row-block pass and the 32-row family"
+    eng.close()
+
+
 def test_unplanted_lm_head_teacher_forced_margin_rule(cfg, cpu_w):
     """The identity legs above run on synth.py's planted lm_head (64 decisive rows, so that identical tokens can be DEMANDED). This leg
     uses an ordinary random-init head -- every row std 0.02 like transformers' `_init_weights` (modeling_llama_imgemb.py:349-358), top-2

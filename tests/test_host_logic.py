@@ -168,11 +168,11 @@ def test_test_py_sizes_the_engine_for_beams_and_downstream_passes():
         size(1, 9)
     assert size(12, 1) == (12, 12, 5)
     assert size(12, 3) == (36, 12, 5)                       # round 5: the reference's 12 prompts x 3 beams in one pass (33-128 rows: the row-block family)
-    assert size(12, 3, fp8=True) == (30, 10, 5)             # fp8 weights: 32 rows -> chunks of 10 prompts x 3 beams
-    assert size(12, 3, bin_qa=True, fp8=True) == (30, 10, 5)    # the greedy binary QA needs 14 rows, not 14 x 3
+    assert size(12, 3, fp8=True) == (36, 12, 5)             # fp8 weights: the same 128 rows since round 5 (the fp8 x fp8 row blocks)
+    assert size(12, 3, bin_qa=True, fp8=True) == (36, 12, 5)    # the greedy binary QA needs 14 rows, not 14 x 3
     assert size(2, 1, bin_qa=True) == (14, 2, 5)
     assert size(1, 8, all_qa=True) == (40, 1, 5)            # findings QA: 5 prompts x 8 beams
-    assert size(1, 8, all_qa=True, fp8=True) == (32, 1, 4)
+    assert size(1, 8, all_qa=True, fp8=True) == (40, 1, 5)
     assert size(64, 3) == (126, 42, 5)                      # 192 rows would not fit: chunks of 42 prompts x 3 beams
     for args_ in ((12, 1), (12, 3, True, True), (32, 2), (5, 8, True, True)):
-        assert size(*args_)[0] <= 128 and size(*args_, fp8=True)[0] <= 32
+        assert size(*args_)[0] <= 128 and size(*args_, fp8=True)[0] <= 128
