@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Regenerate tests/golden/bench_tokens.json on an MI355X: the first 8 greedy tokens of row 0 of every configuration bench.py times
-(batch 1, batch 32, fp8 weights at batch 32), taken from the `token_check` objects of one bench line. Run after any kernel change that
+(batch 1, 32, 64, 128; fp8 weights at batch 32 and 128; fp16 at batch 1), taken from the `token_check` objects of one bench line. Run after any kernel change that
 re-orders an accumulation (`python tools/make_bench_fixture.py`, ~1.5 min); the batch-1 line is additionally checked against the
 full-depth CPU oracle by every default bench run (cpu_baseline.parity), so a wrong fixture cannot hide a wrong kernel."""
 import json
@@ -21,7 +21,7 @@ def main():
             sys.stderr.write(p.stderr[-4000:])
             raise SystemExit("bench.py printed no JSON line")
         d = json.loads(line[-1])
-        for obj in [d] + [d[k] for k in ("b32", "fp8_b32") if k in d]:
+        for obj in [d] + [d[k] for k in ("b32", "fp8_b32", "b64", "b128", "fp8_b128", "f16_b1") if k in d]:
             tc = obj["token_check"]
             out[tc["key"]] = tc["tokens"]
     path = os.path.join(REPO, "tests", "golden", "bench_tokens.json")
