@@ -371,21 +371,30 @@ constexpr int DA_WAVES = 16;       // latency variant: few (head, row) pairs, ea
 constexpr int DA_WAVES_TP = 4;     // throughput variant: > 256 pairs, 4 workgroups per CU share the KV stream (8 waves with a 256-position
                                    // register window measured 5 % slower at batch 32)
 
+constexpr int DA_WAVES_MID = 8;    // 9-16 rows (257-512 pairs): two 8-wave workgroups per CU, a 336-position register window each (the 4-wave form leaves a CU 8 waves).
+                                   // Dedicated new-token wave, 3 K groups per wave, V behind the scores; measured against all 8 waves owning rows with a 256-position
+                                   // window and V early (+0.05 ms per step at 12 / 16 rows) and the dedicated wave with a 224-position window and V early (+0.03)
+
 template <typename T, int WAVES>
-__global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 4 : 1)) void decode_attention_k(DecAttnArgs a) {
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 16 ? 1 : 4)) void decode_attention_k(DecAttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float dsm[];
     // latency variant: wave 0 is dedicated to the new token (its operand loads are first in its queue), 15 waves own the cache
     if (WAVES == 16) decode_attention_body<T, WAVES, true, NoWait, true>(a, blockIdx.x, blockIdx.y, dsm);
+    else if (WAVES == 8) decode_attention_body<T, WAVES, true, NoWait, false, 3>(a, blockIdx.x, blockIdx.y, dsm);
     else decode_attention_body<T, WAVES, false>(a, blockIdx.x, blockIdx.y, dsm);
 }
 
 void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s) {
     dim3 grid(a.d.heads, B);
-    const char* tp_env = getenv("RDX_ATT_TP");                       // tests: force the throughput variant
+    const char* tp_env = getenv("RDX_ATT_TP");                       // tests: 1 forces the throughput variant, 2 the 8-wave one
     const int force_tp = tp_env ? atoi(tp_env) : 0;
     if (a.d.heads * B <= 256 && !force_tp) {
         const size_t smem = decode_attention_smem_floats(DA_WAVES, a.d.max_len) * sizeof(float);
         RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T, DA_WAVES>), grid, dim3(DA_WAVES * 64), smem, s, a));
+    } else if (force_tp == 2 || (a.d.heads * B <= 512 && !force_tp && !(getenv("RDX_ATT_MID") && atoi(getenv("RDX_ATT_MID")) == 0))) {
+        // 9-16 rows at 32 heads (round 5; RDX_ATT_MID=0: the 4-wave form, the A/B leg; RDX_ATT_TP=2: forced, tests): batch 12 3.162 -> 3.098 ms per step, 16: 3.222 -> 3.178
+        const size_t smem = decode_attention_smem_floats(DA_WAVES_MID, a.d.max_len) * sizeof(float);
+        RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T, DA_WAVES_MID>), grid, dim3(DA_WAVES_MID * 64), smem, s, a));
     } else {
         const size_t smem = decode_attention_smem_floats(DA_WAVES_TP, a.d.max_len) * sizeof(float);
         RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T, DA_WAVES_TP>), grid, dim3(DA_WAVES_TP * 64), smem, s, a));

@@ -209,7 +209,10 @@ __global__ __launch_bounds__(XR_THREADS) void xrow16_k(GemmArgs a) {
     const int clast = c1 - 1;
     const u4* wp = reinterpret_cast<const u4*>(a.W) + (size_t)tile * KC * 64 + lane;
     const T* X = reinterpret_cast<const T*>(a.X);
-    auto xaddr = [&](int c) { return X + (size_t)(((c * 2) * 64 + lane) * 8); };      // fragment (c, mt = 0) of the packed block
+    // fragment (c, mt = 0) of the packed block. At <= 8 (<= 4) rows the lanes of the padding rows re-read row r - 8 (r & 3): their MFMA columns are never stored, and
+    // the fragment's second 128-byte line per lane group (half of each line) is not fetched at all -- at K = 11008 the activations are as many L2 -> CU bytes as the weights
+    const int xlane = a.M <= 4 ? (lane & ~12) : a.M <= 8 ? (lane & ~8) : (a.M <= 12 && (lane & 12) == 12) ? lane - 4 : lane;      // (9-12 rows: rows 12-15 re-read 8-11 -- half a line)
+    auto xaddr = [&](int c) { return X + (size_t)(((c * 2) * 64 + xlane) * 8); };
 
     u4 wr[XR_U], xr[XR_U];
 #pragma unroll

@@ -506,14 +506,14 @@ def test_production_width_decode_over_the_bench_positions_teacher_forced(B, N, d
         assert same >= MIN_COVER[dtype] * total, f"B={B} {dtype}: only {same}/{total} steps chose the oracle's token"
 
 
-@pytest.mark.parametrize("B,tp", [(1, 0), (3, 0), (3, 1)])
+@pytest.mark.parametrize("B,tp", [(1, 0), (3, 0), (3, 1), (3, 2)])
 def test_long_context_decode_streams_past_the_register_window(cfg, cpu_w, B, tp, monkeypatch):
     """Multi-turn prompts (test.py:440-674: report + follow-up question, 400-700 tokens) put the context beyond the 480
     positions decode attention holds in registers; the rest streams through the MFMA / dot2 tail loops. T = 600 here.
-    tp = 1 forces the 4-wave throughput variant that batch-32 decode uses (128-position window)."""
+    tp = 1 forces the 4-wave throughput variant that batch-32 decode uses (128-position window), tp = 2 the 8-wave variant of 9-16 rows (336)."""
     from oracle import ref_cpu
     if tp:
-        monkeypatch.setenv("RDX_ATT_TP", "1")
+        monkeypatch.setenv("RDX_ATT_TP", str(tp))
     from radialog_amd.engine import RdxEngine, synth_getter
     T, N = 600, 6
     ids = synth.synth_prompt_ids(B, T, vocab=cfg.llama.vocab, img_offset=6, pad_rows=False, seed=11)
@@ -530,15 +530,16 @@ def test_long_context_decode_streams_past_the_register_window(cfg, cpu_w, B, tp,
 
 
 @pytest.mark.parametrize("tp,lens", [(1, (47, 48, 49, 64, 65, 96, 97, 112, 113, 128, 129)),
-                                     (0, (60, 61, 120, 121, 240, 241, 300, 301, 420, 421, 480, 481))])
+                                     (0, (60, 61, 120, 121, 240, 241, 300, 301, 420, 421, 480, 481)),
+                                     (2, (47, 56, 57, 84, 85, 112, 113, 223, 224, 225, 335, 336, 337, 400))])      # 8 waves: 7 cache waves x 3 groups x 16 (lower part 224), V rows 28 apart
 def test_decode_attention_context_lengths_around_the_register_window_edges(cfg, cpu_w, tp, lens, monkeypatch):
     """Context lengths on either side of every boundary of the register window: the halves (loaded unconditionally / once
     `slot` is known), the V row pairs P.V consumes together (16 positions apart in the 4-wave variant, 60 in the 16-wave
     one -- an unloaded odd row of a pair once produced NaN x 0), the window end where the tail loops take over. Three
-    decode steps from each prompt length, both attention variants, logits and tokens against the oracle."""
+    decode steps from each prompt length, all three attention variants, logits and tokens against the oracle."""
     from oracle import ref_cpu
     if tp:
-        monkeypatch.setenv("RDX_ATT_TP", "1")
+        monkeypatch.setenv("RDX_ATT_TP", str(tp))
     from radialog_amd.engine import RdxEngine, synth_getter
     B, N = 2, 4
     for dtype in ("f16", "bf16"):
