@@ -337,11 +337,11 @@ def _prefix_err(scores, ref_scores, tok_a, tok_b, N):
 
 @pytest.mark.parametrize("B,fp8,layers,dtypes", [
     (32, False, 1, ("f16", "bf16")), (32, True, 1, ("bf16",)), (32, False, 2, ("f16",)),        # BASELINE configs[2] / [4] per-GPU batch
-    (20, False, 1, ("f16", "bf16")), (20, True, 1, ("bf16",)), (8, False, 1, ("bf16",)), (16, True, 1, ("bf16",)),
+    (20, False, 1, ("bf16",)), (20, True, 1, ("bf16",)), (8, False, 1, ("bf16",)), (16, True, 1, ("bf16",)),
     (5, False, 1, ("bf16",)), (3, False, 1, ("f16",)), (4, True, 1, ("bf16",)), (1, False, 1, ("f16", "bf16")),
     (2, False, 1, ("f16",)), (1, True, 1, ("bf16",)), (20, False, 2, ("bf16",)), (1, False, 2, ("f16",)),
     (12, False, 1, ("f16", "bf16")), (16, False, 2, ("f16",)),       # round 5: the reference's eval batch (test.py:279,:344) and a full row tile on xs16.hip
-    (64, False, 1, ("f16", "bf16")), (40, False, 2, ("bf16",)),       # round 5: 33-128 rows, the row-block family (ragged last block at 40),
+    (64, False, 1, ("bf16",)), (40, False, 2, ("bf16",)),       # round 5: 33-128 rows, the row-block family (ragged last block at 40),
     (88, False, 1, ("bf16",)), (128, False, 1, ("f16",)),                                       # three (one workgroup slot in four idle) and four row blocks per tile walker
     (40, True, 1, ("bf16",)), (96, True, 1, ("bf16",)), (128, True, 1, ("bf16",))])               # ... and its fp8 x fp8 form (the 32-row fp8 kernels per row block)
 def test_production_width_layers_match_oracle(B, fp8, layers, dtypes):
