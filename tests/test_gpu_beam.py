@@ -89,6 +89,33 @@ def test_beam_search_at_the_references_eval_batch_36_rows_in_one_pass():
     lm._engine.close()
 
 
+def test_fp8_beam_search_at_36_rows_equals_two_chunked_passes():
+    """With fp8 weights rounds 1-4 (and test.py's sizing until round 5) chunked 12 prompts x 3 beams at the 32 rows of the fp8 decode family; the fp8 x fp8 row
+    blocks take the 36 rows in one pass. Row by row they compute what the 32-row fp8 kernels compute (tests/test_gpu_parity.py::
+    test_fp8_row_blocks_equal_the_32_row_kernels_row_by_row), and beam search is a deterministic function of the logits: the one-pass hypotheses and scores
+    must EQUAL those of the same 12 prompts run as two 6-prompt calls (18 rows each: the 32-row family, the same decode-attention variant) on the same engine.
+    Production width, one layer; covers _reorder_cache and the log-softmax scoring above 32 rows on the fp8 path."""
+    from radialog_amd.config import LlamaCfg
+    from radialog_amd.modeling_llama_imgemb import LlamaForCausalLM
+    lcfg = LlamaCfg(layers=1, qformer_dim=192)
+    B, k, T, N = 12, 3, 96, 6
+    lm = LlamaForCausalLM.from_pretrained(None, torch_dtype=torch.bfloat16, cfg=lcfg, max_batch=B * k, max_len=128, synthetic=True, weights_fp8=True).eval()
+    ids = synth.synth_prompt_ids(B, T, vocab=lcfg.vocab, img_offset=6, pad_rows=True, seed=78)
+    qf = synth.synth("t.qfb36f8", (B, 32, lcfg.qformer_dim), -1.0, 1.0)
+
+    def run(lo, hi):
+        return lm.generate(input_ids=ids[lo:hi], qformer_embs=qf[lo:hi], num_beams=k, max_new_tokens=N, eos_token_id=-1, pad_token_id=0,
+                           return_dict_in_generate=True, output_scores=True)
+    one = run(0, B)
+    assert one.sequences.shape == (B, T + N) and one.scores[0].shape == (B * k, lcfg.vocab) and not torch.isnan(one.scores[0].float()).any()
+    for lo, hi in ((0, 6), (6, 12)):
+        part = run(lo, hi)
+        assert torch.equal(part.sequences.cpu(), one.sequences[lo:hi].cpu()), f"prompts {lo}..{hi - 1}: hypotheses differ between one 36-row pass and an 18-row pass"
+        assert torch.equal(part.sequences_scores.cpu(), one.sequences_scores[lo:hi].cpu())
+        assert torch.equal(part.scores[0].cpu(), one.scores[0][lo * k:hi * k].cpu())
+    lm._engine.close()
+
+
 def test_beam_reorder_moves_only_the_diverging_suffix_and_changes_nothing(monkeypatch):
     """_reorder_cache (modeling_llama_imgemb.py:838-843) is `past[:, beam_idx]`; rdx_beam_search moves, per re-parented row, only the cache
     positions from the first token at which the row's old history and its new parent's differ (rounded down to the 16-position group) --
