@@ -33,6 +33,7 @@ struct GemmArgs {
     int xpacked;                     // xstat32_k: X is the fragment-packed 32-row block written by launch_rmsnorm_packed32 (1 / 2);
                                      // 3 (wstat_k): fragment-packed [k / 32][mtiles][lane][8] over `mtiles` row tiles of 16 (out_packed 3 alike)
     int mtiles;
+    int xdup_off;                    // experiments (RDX_XDUP=0): padding rows of a 32-row block load their own (zero / stale) lines instead of re-reading real rows
     // fp8 activations (W8A8: gemm8.hip, xstat32_k<.., A8>): X holds e4m3 bytes, xscale[row][xgroups] their absmax / 448 scales over `xgroups`
     // equal K ranges (1 behind an RMSNorm, 2 o_proj, 4 down_proj); xpacked 4 = the 32-row block in the 64-deep fragment order
     const float* xscale; int xgroups;

@@ -37,6 +37,17 @@ __device__ __forceinline__ v4f xs_mfma8(const u4& a, const u4& b, v4f c) {
 // its own -- the NB row-block workgroups of a walker sit on the SAME XCD (workgroup ids are dealt round-robin over the 8 XCDs: id % 8) and walk the
 // same tile sequence, so a weight fragment comes from HBM once and from that XCD's L2 NB - 1 times. X is the prompt's fragment-packed
 // [k / 32][mtiles][lane][8] (xpacked 3, what rmsnorm_k<T, 3> / attention_k / the SwiGLU epilogue write); row block mb reads row tiles 2 mb, 2 mb + 1.
+// Where a fragment load of row tile `mt` reads when only `m` of the block's 32 rows are real (round 5): a fragment is 16 rows x 16 bytes per lane group, i.e. two 128-byte lines
+// of 8 rows each -- a lane whose row lies past the last line with a real row reads row `row % (8 ceil(m / 8))` instead (its MFMA column is never stored), so the lines of
+// padding rows are never requested: at 12 rows half of every activation block (the 256 workgroups of a launch pull 32-64 MB of them through the L2s), at 40 rows 3/4 of
+// the second row block. Returns the source lane (same lane group), sets the source row tile.
+__device__ __forceinline__ int xs_src_lane(int m, int mt, int lane, int& mt_s) {
+    const int m8 = (m + 7) & ~7, row = 16 * mt + (lane & 15);
+    const int src = (m8 >= 32 || m8 <= 0) ? row : row % m8;
+    mt_s = src >> 4;
+    return (lane & 48) | (src & 15);
+}
+
 template <typename T, int EPI, bool W8, bool A8 = false, bool BLK = false>
 __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
     static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
@@ -91,19 +102,22 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
     constexpr int NXF = A8 ? XS_CPW / 2 : XS_CPW;
     u4 xf[2][NXF];
     const bool xp = a.xpacked != 0;          // fragment-packed by rmsnorm_k<T, PACK>: fragment (f, mt) is one contiguous KiB
+    const int m_real = a.xdup_off ? 32 : min(32, a.M - 32 * mb);       // real rows of this 32-row block
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+        int mts;
+        const int ls = xs_src_lane(m_real, mt, lane, mts);              // padding rows re-read real ones (xs_src_lane)
         if (A8) {
             // e4m3 block [chunk j][mt][lane][16]: this wave's chunks j = (XS_CPW / 2) wa .. + XS_CPW / 2
-            const u4* x8 = reinterpret_cast<const u4*>(a.X) + (BLK ? (size_t)mb * (32 * XS_K / 16) : (size_t)0) + (size_t)((wa * (XS_CPW / 2)) * 2 + mt) * 64 + lane;
+            const u4* x8 = reinterpret_cast<const u4*>(a.X) + (BLK ? (size_t)mb * (32 * XS_K / 16) : (size_t)0) + (size_t)((wa * (XS_CPW / 2)) * 2 + mts) * 64 + ls;
 #pragma unroll
             for (int c = 0; c < NXF; ++c) xf[mt][c] = ldg16(x8 + (size_t)c * 128);
         } else if (BLK) {
-            const int mtg = min(2 * mb + mt, a.mtiles - 1);             // a ragged last block re-reads the last row tile (its rows are never stored)
+            const int mtg = min(2 * mb + mts, a.mtiles - 1);
 #pragma unroll
-            for (int c = 0; c < NXF; ++c) xf[mt][c] = ldg16(X + ((size_t)(((wa * XS_CPW + c) * a.mtiles + mtg) * 64 + lane) << 3));
+            for (int c = 0; c < NXF; ++c) xf[mt][c] = ldg16(X + ((size_t)(((wa * XS_CPW + c) * a.mtiles + mtg) * 64 + ls) << 3));
         } else {
-            const T* xr = xp ? X + (size_t)(((wa * XS_CPW) * 2 + mt) * 64 + lane) * 8
+            const T* xr = xp ? X + (size_t)(((wa * XS_CPW) * 2 + mts) * 64 + ls) * 8
                              : X + (size_t)min(mt * 16 + r, a.M - 1) * a.ldx + wa * (XS_CPW * 32);
 #pragma unroll
             for (int c = 0; c < NXF; ++c) {
@@ -305,16 +319,20 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
     }
     const T* X = reinterpret_cast<const T*>(a.X);
     u4 xf[2][CPW * FPL];
+    const int m_real = a.xdup_off ? 32 : min(32, a.M - 32 * mb);       // real rows of this 32-row block: padding rows re-read real ones (xs_src_lane)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt) {
+        int mts;
+        const int ls = xs_src_lane(m_real, mt, lane, mts);
 #pragma unroll
         for (int j = 0; j < CPW * FPL; ++j) {
             const int f = (c0 + min(j / FPL, cnt - 1)) * FPL + (j % FPL);          // packed fragment index (32-deep, or 2 per 64-deep chunk)
             // BLK: the row-tile order of the model-dtype path (xpacked 3), or -- fp8 -- block mb's own 32-row block in the 64-deep order (xpacked 2)
-            const u4 v = (BLK && !W8) ? ldg16(X + ((size_t)((f * a.mtiles + min(2 * mb + mt, a.mtiles - 1)) * 64 + lane) << 3))
-                                      : ldg16(X + (BLK ? (size_t)mb * 32 * a.K : (size_t)0) + ((size_t)((f * 2 + mt) * 64 + lane) << 3));
+            const u4 v = (BLK && !W8) ? ldg16(X + ((size_t)((f * a.mtiles + min(2 * mb + mts, a.mtiles - 1)) * 64 + ls) << 3))
+                                      : ldg16(X + (BLK ? (size_t)mb * 32 * a.K : (size_t)0) + ((size_t)((f * 2 + mts) * 64 + ls) << 3));
             xf[mt][j] = (j / FPL) < cnt ? v : (u4){0u, 0u, 0u, 0u};
         }
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     const int e_mt = threadIdx.x >> 8, e_idx = threadIdx.x & 255, e_m = (BLK ? 32 * mb : 0) + e_mt * 16 + (e_idx >> 4), e_nl = e_idx & 15;
@@ -420,6 +438,13 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 #undef XS_T
 }
 
+// RDX_XDUP=0 (A/B leg): the padding rows of a 32-row block load their own lines
+static GemmArgs xs_env(GemmArgs a) {
+    static const bool off = getenv("RDX_XDUP") && atoi(getenv("RDX_XDUP")) == 0;
+    a.xdup_off = off ? 1 : 0;
+    return a;
+}
+
 // smallest row count (batch) that takes the activation-stationary / K-split kernels; below it the GEMV family of skinny_body.h
 // (whose LDS stage holds up to 4 rows of 4096). Measured step times, default GEMV path -> these kernels: batch 5 3.31 -> 3.25 ms,
 // batch 8 3.53 -> 3.29, batch 16 4.23 -> 3.53 (rows beyond the batch ride along as zero columns of the 32-row block); batch 3 and
@@ -437,7 +462,8 @@ int xsplit32_groups(const GemmArgs& a) {
     return 0;
 }
 
-void launch_xsplit32(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
+void launch_xsplit32(int dtype, const GemmArgs& a_in, float* slab, hipStream_t s) {
+    const GemmArgs a = xs_env(a_in);
     const int kgn = xsplit32_groups(a);
     const int nt = (a.N + 15) / 16;
     const bool w8 = a.W8 && a.wscale;                        // fp8 weights: fp8 x fp8, every K-group workgroup quantises its range of the activations
@@ -462,7 +488,8 @@ bool xstat_blk8_supported(const GemmArgs& a, int epi) {
            (epi == EPI_NONE || epi == EPI_SILU_MUL || epi == EPI_LOGITS) && (a.out_packed == 0 || (a.out_packed == 2 && epi == EPI_SILU_MUL)) && (a.N + 15) / 16 >= 128;
 }
 
-void launch_xstat_blk8(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
+void launch_xstat_blk8(int dtype, const GemmArgs& a_in, int epi, hipStream_t s) {
+    const GemmArgs a = xs_env(a_in);
     const size_t smem = (size_t)2 * 2 * XS_WAVES * 2 * 256 * 4;
     RDX_DISPATCH_T(dtype, T, {
         if (epi == EPI_NONE) hipLaunchKernelGGL((xstat32_k<T, EPI_NONE, true, true, true>), dim3(256), dim3(XS_THREADS), smem, s, a);
@@ -476,7 +503,8 @@ int xsplit_blk8_groups(const GemmArgs& a) {
     return a.K == 11008 ? 4 : a.K == 4096 ? 2 : 0;
 }
 
-void launch_xsplit_blk8(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
+void launch_xsplit_blk8(int dtype, const GemmArgs& a_in, float* slab, hipStream_t s) {
+    const GemmArgs a = xs_env(a_in);
     const size_t smem = (size_t)2 * 2 * XS_WAVES * 2 * 256 * 4;
     RDX_DISPATCH_T(dtype, T, {
         if (a.K == 11008) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2, true, true>), dim3(256), dim3(XS_THREADS), smem, s, a, slab);
@@ -489,7 +517,8 @@ bool xsplit_blk_supported(const GemmArgs& a) {
            (a.N + 15) / 16 >= 128 && (a.N + 15) / 16 <= 512;
 }
 
-void launch_xsplit_blk(int dtype, const GemmArgs& a, float* slab, hipStream_t s) {
+void launch_xsplit_blk(int dtype, const GemmArgs& a_in, float* slab, hipStream_t s) {
+    const GemmArgs a = xs_env(a_in);
     const size_t smem = (size_t)2 * XS_WAVES * 2 * 256 * 4;
     RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((xsplit32_k<T, 344, 4, false, 1, false, true>), dim3(256), dim3(XS_THREADS), smem, s, a, slab));
 }
@@ -529,7 +558,8 @@ bool xstat_blk_supported(const GemmArgs& a, int epi) {
            (a.N + 15) / 16 >= 128;
 }
 
-void launch_xstat_blk(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
+void launch_xstat_blk(int dtype, const GemmArgs& a_in, int epi, hipStream_t s) {
+    const GemmArgs a = xs_env(a_in);
     const size_t smem = (size_t)2 * XS_WAVES * 2 * 256 * 4;
     RDX_DISPATCH_T(dtype, T, {
         if (epi == EPI_NONE) hipLaunchKernelGGL((xstat32_k<T, EPI_NONE, false, false, true>), dim3(256), dim3(XS_THREADS), smem, s, a);
@@ -539,7 +569,8 @@ void launch_xstat_blk(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
     });
 }
 
-void launch_xstat32(int dtype, const GemmArgs& a, int epi, hipStream_t s) {
+void launch_xstat32(int dtype, const GemmArgs& a_in, int epi, hipStream_t s) {
+    const GemmArgs a = xs_env(a_in);
     const bool w8 = a.W8 && a.wscale;        // fp8 weights: the activations are the e4m3 block of rmsnorm4096_k<T, 4> (xpacked 4; launch_skinny_gemm checks)
     RDX_DISPATCH_T(dtype, T, {
         if (w8) launch_xstat32_t<T, true, true>(a, epi, s);
