@@ -55,7 +55,7 @@ def main():
             avg = ((time.perf_counter() - t0) / 2 - pre) / (N - 1) * 1e3
             kv = B * (T + N / 2.0) * 524288 + B * 524288
             frac = (wb + kv) / (avg * 1e-3) / 1e9 / bench.HBM_PEAK_GBS
-            name = ("xs16 (5 launches / layer)" if (fam and 3 <= B <= 16) else "chained (3 / layer)" if B <= 2 else
+            name = ("fp8 x fp8: " if a.fp8 else "") + ("xs16 (5 launches / layer)" if (fam and not a.fp8 and 3 <= B <= 16) else "chained (3 / layer)" if B <= 2 else
                     "row blocks (33-128 rows, 7 / layer)" if B > 32 else "xstat32 (7 launches / layer)")
             print(f"| {B} | {name} | {step:.3f} | {avg:.3f} | {frac * 100:.1f} % | {pre * 1e3:.1f} |", flush=True)
         eng.close()
