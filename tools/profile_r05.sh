@@ -2,6 +2,7 @@
 # Round-5 profiling passes (run on the GPU box from the repo root); text summaries only -> gpurun_out/prof/.
 #   bash tools/profile_r05.sh decode     kernel tables of a 256-token decode at batch 16 (xs16 on / off) and batch 32
 #   bash tools/profile_r05.sh bench      kernel table of the default bench command
+#   bash tools/profile_r05.sh final      kernel tables of the final tree: batch 12 / 16 decode, fp8 x fp8 row blocks at 64 / 128 rows
 #   bash tools/profile_r05.sh pmc        FETCH_SIZE / WRITE_SIZE passes of bench.py at batch 1 / 32 / 32 fp8 (one counter per pass; tools/pmc_to_json.py r05)
 set -u
 ROOT=$PWD
@@ -52,4 +53,10 @@ if [ $what = prefill64 ]; then
 fi
 if [ $what = dec64 ]; then
   trace dec_b64 0 python $ROOT/tools/decode_only.py 64 256 1
+fi
+if [ $what = final ]; then      # the final round-5 tree: batch 12 / 16 on xs16 with the 8-wave attention, fp8 x fp8 row blocks at 64 and 128 rows
+  trace dec_b12_final 0 python $ROOT/tools/decode_only.py 12 256 1
+  trace dec_b16_final 0 python $ROOT/tools/decode_only.py 16 256 1
+  trace dec_fp8_b64 0 python $ROOT/tools/decode_only.py 64 256 1 1
+  trace dec_fp8_b128 0 python $ROOT/tools/decode_only.py 128 256 1 1
 fi
