@@ -60,3 +60,7 @@ if [ $what = final ]; then      # the final round-5 tree: batch 12 / 16 on xs16 
   trace dec_fp8_b64 0 python $ROOT/tools/decode_only.py 64 256 1 1
   trace dec_fp8_b128 0 python $ROOT/tools/decode_only.py 128 256 1 1
 fi
+if [ $what = pmc_extra ]; then   # FETCH_SIZE of the round-5 additions: batch 12 (xs16 + the 8-wave attention), fp8 x fp8 row blocks at 64 rows (mean context 288)
+  pmc1 b12 FETCH_SIZE --batch 12 --steps 1 --warmup 0 --prompt-len 280 --new-tokens 8 --no-cpu-baseline --no-graph
+  pmc1 b64fp8 FETCH_SIZE --batch 64 --fp8 --steps 1 --warmup 0 --prompt-len 280 --new-tokens 8 --no-cpu-baseline --no-graph
+fi
