@@ -776,7 +776,7 @@ def main():
                            f"batch 32 (global {32 * world}); no reference fp8 path exists -- its oracle is the reference math on the "
                            "same fake-quantised operands (cpu_baseline.parity_fp8 / tests/test_gpu_parity.py), i.e. unpinnable against the reference itself; "
                            "cpu_baseline.fp8_vs_unquantised says what it costs against the un-quantised oracle")
-    if B == 1 and not args.fp8 and not args.no_b64 and not STUB:
+    if B == 1 and not args.fp8 and not args.no_b64 and not STUB and world == 1:        # one rank only: the N > 1 run stays lean (its per-GPU loads are b32 / fp8_b32)
         # round 5: 64 reports per GPU (33-64 decoder rows: the row-block family) -- not a BASELINE configuration (those stop at 32 per GPU): what the
         # 288 GB of HBM buy when the 13.2 GB weight stream of a decode step is amortised over twice the reports
         subs["b64"] = (timed_run(64, False, 2, 1), f"per-GPU batch 64 (global {64 * world}): beyond BASELINE configs[2]/[3]'s 32 per GPU, same pipeline, hipGraph step")
