@@ -16,6 +16,8 @@ Pinned here:
              with torch ops exactly as blip2_qformer.py:469 writes them)
   rope/rms   LlamaRotaryEmbedding tables, LlamaRMSNorm rows
   downstream downstream_tasks/automated_correction.py + chexpert_classification_downstream.py prompt builders (strings)
+  llama_real_layer   ONE LlamaDecoderLayer at the production shape (4096 / 11008 / 32 x 128): prefill T = 8 + 2 decode steps, three dtypes
+  qformer_real       BertLMHeadModel(...).bert at the production shape (768 x 12, 32 queries x 196 x 1408), B = 1
   vit_pooler biovil_t/transformer.py VisionTransformerPooler (Block, MultiHeadAttentionLayer, SinePositionEmbedding are the
              reference's own code) in eval mode, two-image call. Its three timm==0.4.12 imports are shimmed in-process: DropPath
              (identity in eval), trunc_normal_ (init only, overwritten by our weights) and Mlp, restated as timm 0.4.12 defines
@@ -186,6 +188,118 @@ def make_qformer():
     print("qformer_small:", o.last_hidden_state.shape, float(o.last_hidden_state.abs().mean()))
 
 
+def _qformer_ref():
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    for nm in ("apply_chunking_to_forward", "prune_linear_layer"):
+        if not hasattr(mu, nm):
+            setattr(mu, nm, getattr(pu, nm))
+    if not hasattr(mu, "find_pruneable_heads_and_indices"):
+        mu.find_pruneable_heads_and_indices = lambda *a, **k: (set(), torch.zeros(0))
+    mu.PreTrainedModel.get_head_mask = lambda self, m, n, *a, **k: [None] * n
+    ref = _load("model/lavis/models/blip2_models/Qformer.py", "ref_qformer")
+    if hasattr(ref.BertPreTrainedModel, "init_weights"):
+        ref.BertPreTrainedModel.init_weights = lambda self: None
+    return ref
+
+
+def _u16(t):
+    """fp16 / bf16 values as their 16 bits (halves the fixture)."""
+    return t.contiguous().view(torch.int16).numpy()
+
+
+REAL_LAYER_T, REAL_LAYER_PAD, REAL_LAYER_STEPS = 8, 3, 2
+REAL_LAYER_HEADS = (0, 13, 31)           # K / V heads kept in the fixture (all of hidden_states is kept)
+
+
+def real_layer_inputs(c):
+    """Inputs of the real-shape decoder-layer fixture (regenerated by the test, not stored): B = 2, row 1 left-padded by 3."""
+    T, S = REAL_LAYER_T, REAL_LAYER_STEPS
+    xs = [synth.synth("golden.real_layer.x0", (2, T, c.hidden), -1.0, 1.0)]
+    xs += [synth.synth(f"golden.real_layer.x{s + 1}", (2, 1, c.hidden), -1.0, 1.0) for s in range(S)]
+    am = torch.ones(2, T, dtype=torch.long)
+    am[1, :REAL_LAYER_PAD] = 0
+    return xs, am
+
+
+def make_llama_real_layer():
+    """ONE real-shape LlamaDecoderLayer (hidden 4096, inter 11008, 32 heads x 128) of the reference
+    (modeling_llama_imgemb.py:253-318, attention :187-250), prefill T = 8 + 2 decode steps, fp32 / fp16 / bf16, with the masks the
+    reference's own _make_causal_mask / _expand_mask build (:44-73, :475-496) and prepare_inputs' position rule. Stores OUTPUTS only;
+    inputs and weights are regenerated from radialog_amd.synth by the test."""
+    from transformers import LlamaConfig
+    c = LlamaCfg(layers=1)
+    work = tempfile.mkdtemp()
+    os.makedirs(os.path.join(work, "pretraining", "embs"))
+    with open(os.path.join(work, "pretraining/embs/stage1_pt_instruct_blip_origlr_img448_embeddings_test.pkl"), "wb") as f:
+        pickle.dump({}, f)
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        ref = _load("model/lavis/models/blip2_models/modeling_llama_imgemb.py", "ref_llama_real")
+    finally:
+        os.chdir(cwd)
+    hcfg = LlamaConfig(vocab_size=c.vocab, hidden_size=c.hidden, intermediate_size=c.inter, num_hidden_layers=1,
+                       num_attention_heads=c.heads, max_position_embeddings=c.max_pos, rms_norm_eps=c.rms_eps, pad_token_id=0, hidden_act="silu")
+    specs = {k: v for k, v in synth.llama_specs(c, lora=False).items() if k.startswith("model.layers.0.")}
+    W = synth.make_weights(specs)
+    xs, am = real_layer_inputs(c)
+    out = {}
+    for tag, dt in (("f32", torch.float32), ("f16", torch.float16), ("bf16", torch.bfloat16)):
+        layer = ref.LlamaDecoderLayer(hcfg)
+        missing, unexpected = layer.load_state_dict({k[len("model.layers.0."):]: v for k, v in W.items()}, strict=False)
+        assert not unexpected and all("inv_freq" in k for k in missing), (missing, unexpected)
+        layer = layer.eval().to(dt)          # rounds the parameters and the cached rope tables (demo.py:234)
+        keep = (lambda t: t.numpy()) if dt == torch.float32 else _u16
+        with torch.no_grad():
+            mask_now, past = am.clone(), None
+            for s, x in enumerate(xs):
+                x = x.to(dt)
+                T = x.shape[1]
+                pl = 0 if past is None else past[0].shape[2]
+                # LlamaModel._prepare_decoder_attention_mask uses no state of the model (:475-496)
+                m4 = ref.LlamaModel._prepare_decoder_attention_mask(None, mask_now, (2, T), x, pl)
+                pos = mask_now.long().cumsum(-1) - 1               # prepare_inputs_for_generation :805-810
+                pos.masked_fill_(mask_now == 0, 1)
+                pos = pos[:, -T:]
+                o = layer(x, attention_mask=m4, position_ids=pos, past_key_value=past, use_cache=True)
+                out[f"h{s}_{tag}"] = keep(o[0])
+                past = o[1]
+                mask_now = torch.cat([mask_now, mask_now.new_ones(2, 1)], -1)
+            out[f"k_{tag}"] = keep(past[0][:, list(REAL_LAYER_HEADS)])
+            out[f"v_{tag}"] = keep(past[1][:, list(REAL_LAYER_HEADS)])
+        del layer
+    np.savez_compressed(os.path.join(OUT, "llama_real_layer.npz"), **out)
+    print("llama_real_layer:", {k: v.shape for k, v in out.items()})
+
+
+def make_qformer_real():
+    """the reference's BertLMHeadModel(...).bert at its REAL shape (768 x 12 layers x 12 heads, 32 queries, cross-attention
+    to 196 x 1408 every 2nd layer; Qformer.py:804-965), B = 1. Output only; input and weights regenerated by the test."""
+    ref = _qformer_ref()
+    q = QFormerCfg()
+    bc = ref.BertConfig(vocab_size=30523, hidden_size=q.hidden, num_hidden_layers=q.layers, num_attention_heads=q.heads,
+                        intermediate_size=q.inter, layer_norm_eps=q.ln_eps, hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+    bc.encoder_width = q.enc_width
+    bc.add_cross_attention = True
+    bc.cross_attention_freq = q.cross_freq
+    bc.query_length = q.n_query
+    model = ref.BertLMHeadModel(bc)
+    W = synth.make_weights(synth.qformer_specs(q))
+    sd = {k[len("Qformer."):]: v for k, v in W.items() if k.startswith("Qformer.")}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected
+    for mk in missing:
+        assert any(s in mk for s in ("word_embeddings", "position_embeddings", "position_ids", ".intermediate.dense", ".output.dense", ".output.LayerNorm", "cls.")), mk
+    model.eval()
+    img = synth.synth("golden.qf_real_img", (1, 196, q.enc_width), -2.0, 2.0)
+    with torch.no_grad():
+        o = model.bert(query_embeds=W["query_tokens"].expand(1, -1, -1), encoder_hidden_states=img,
+                       encoder_attention_mask=torch.ones(1, 196, dtype=torch.long), return_dict=True)
+    np.savez_compressed(os.path.join(OUT, "qformer_real.npz"), out=o.last_hidden_state.numpy())
+    print("qformer_real:", o.last_hidden_state.shape, float(o.last_hidden_state.abs().mean()))
+
+
 def make_projector():
     ref = _load("biovil_t/modules.py", "ref_modules")
     v = VisionCfg(img=128, stem=32, planes=(32, 64, 128, 256), blocks=(1, 2, 2, 1), b2v=64, proj=352)
@@ -318,7 +432,7 @@ def make_prompter():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["llama", "qformer", "projector", "prompter", "vit_pooler", "downstream"]
+    which = sys.argv[1:] or ["llama", "qformer", "projector", "prompter", "vit_pooler", "downstream", "llama_real_layer", "qformer_real"]
     if "llama" in which:
         make_llama()
     if "qformer" in which:
@@ -331,3 +445,7 @@ if __name__ == "__main__":
         make_vit_pooler()
     if "downstream" in which:
         make_downstream()
+    if "llama_real_layer" in which:
+        make_llama_real_layer()
+    if "qformer_real" in which:
+        make_qformer_real()

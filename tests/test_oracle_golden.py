@@ -110,3 +110,58 @@ def test_vit_pooler_matches_reference_module(golden_dir):
     with torch.no_grad():
         out = ref_cpu.vit_pooler(torch.from_numpy(g["cur"]), torch.from_numpy(g["prev"]), W, v)
     np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# SURVEY.md 8c real-shape fixtures (round 6): the oracle at the PRODUCTION widths against the reference's own modules
+# ----------------------------------------------------------------------------------------------------------------------
+def _from_u16(a, dt):
+    return torch.from_numpy(a.copy()).view(dt)
+
+
+@pytest.mark.parametrize("tag", ["f32", "f16", "bf16"])
+def test_real_shape_decoder_layer_matches_reference(golden_dir, tag):
+    """ONE LlamaDecoderLayer at hidden 4096 / inter 11008 / 32 heads x 128 (modeling_llama_imgemb.py:253-318 over :187-250, :85-93, :96-142,
+    masks :44-73): prefill T = 8 (row 1 left-padded by 3) + 2 decode steps. Every production-width GPU leg rests on the oracle at exactly this
+    configuration (head_dim 128, 32 heads); llama_tiny.npz pins head_dim 32 / 4 heads only. Weights and inputs are regenerated here."""
+    from oracle.make_golden import real_layer_inputs, REAL_LAYER_HEADS
+    from radialog_amd.config import LlamaCfg
+    g = np.load(os.path.join(golden_dir, "llama_real_layer.npz"))
+    c = LlamaCfg(layers=1)
+    dt = DT[tag]
+    specs = {k: v for k, v in synth.llama_specs(c, lora=False).items() if k.startswith("model.layers.0.")}
+    W = synth.make_weights(specs)
+    orc = ref_cpu.LlamaOracle(W, c, dt, lora=False)
+    xs, am = real_layer_inputs(c)
+    load = (lambda k: torch.from_numpy(g[k])) if tag == "f32" else (lambda k: _from_u16(g[k], dt))
+    # same torch ops in the same order: bit-exact on the machine that wrote the fixture; another host's BLAS blocking may move the last
+    # bit of a 4096- / 11008-deep fp32 accumulation, so the bar is a few ulps of the output magnitude (|h| <= ~4), not equality
+    atol = {"f32": 2e-5, "f16": 4e-3, "bf16": 3.2e-2}[tag]
+    past, mask_now, exact = None, am.clone(), True
+    with torch.no_grad():
+        for s, x in enumerate(xs):
+            x = x.to(dt)
+            T = x.shape[1]
+            pl = 0 if past is None else past[0].shape[2]
+            pos = ref_cpu.positions_from_mask(mask_now)[:, -T:]
+            h, past = orc.layer(0, x, orc._mask(mask_now, T, pl), pos, past)
+            want = load(f"h{s}_{tag}")
+            exact = exact and torch.equal(h, want)
+            np.testing.assert_allclose(h.float().numpy(), want.float().numpy(), rtol=0, atol=atol, err_msg=f"hidden_states of pass {s}")
+            mask_now = torch.cat([mask_now, mask_now.new_ones(2, 1)], -1)
+    hs = list(REAL_LAYER_HEADS)
+    np.testing.assert_allclose(past[0][:, hs].float().numpy(), load(f"k_{tag}").float().numpy(), rtol=0, atol=atol)
+    np.testing.assert_allclose(past[1][:, hs].float().numpy(), load(f"v_{tag}").float().numpy(), rtol=0, atol=atol)
+    print(f"real-shape layer {tag}: bit-exact = {exact}")
+
+
+def test_real_shape_qformer_matches_reference(golden_dir):
+    """BertLMHeadModel(...).bert at 768 x 12 layers x 12 heads, 32 queries, cross-attention to 196 x 1408 (Qformer.py:804-965), B = 1."""
+    from radialog_amd.config import QFormerCfg
+    g = np.load(os.path.join(golden_dir, "qformer_real.npz"))
+    q = QFormerCfg()
+    W = synth.make_weights(synth.qformer_specs(q))
+    img = synth.synth("golden.qf_real_img", (1, 196, q.enc_width), -2.0, 2.0)
+    with torch.no_grad():
+        out = ref_cpu.qformer(img, W, q)
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=5e-6)
