@@ -58,6 +58,9 @@ typedef struct rdx_config {
 /* lifecycle -- replaces model construction (demo.py:149-153 init_blip, :221-236 init_vicuna) */
 int rdx_create(rdx_ctx** out, int device_id, const rdx_config* cfg);
 void rdx_destroy(rdx_ctx* ctx);
+/* 16 hex digits: radialog_amd/build.py source_hash() over the kernel / ABI sources this binary was compiled from ("unstamped" when built
+ * without the build script). The Python loader compares it with the hash of the sources next to it and refuses a mismatch. */
+const char* rdx_build_hash(void);
 const char* rdx_last_error(rdx_ctx* ctx);          /* ctx may be NULL: last error of a failed rdx_create           */
 int rdx_sync(rdx_ctx* ctx);
 void* rdx_stream(rdx_ctx* ctx);                    /* hipStream_t of the context                                   */

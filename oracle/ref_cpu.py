@@ -259,13 +259,19 @@ def fake_quant_e4m3(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
 
 
 class LlamaOracle:
-    def __init__(self, W: Dict[str, torch.Tensor], cfg, dtype=torch.float16, lora: bool = True, exact: bool = False, fp8: bool = False):
+    def __init__(self, W: Dict[str, torch.Tensor], cfg, dtype=torch.float16, lora: bool = True, exact: bool = False, fp8: bool = False,
+                 device="cpu"):
         """W: fp32 (or already-rounded) tensors keyed by reference state_dict names; cast to `dtype` here
         the way `.half()` does for every floating parameter/buffer (demo.py:234).
         exact=True: the same op sequence and the same rounding points, but every contraction (linear layers, Q.K^T, P.V)
         is accumulated in fp64 before its single rounding to `dtype` -- the order-independent value both torch's CPU
         kernels (fp32 accumulation in their blocking order) and the HIP kernels (fp32 MFMA accumulation in theirs)
         approximate. Used by the parity tests to bound each side's accumulation-order noise.
+        device: where the torch ops run. The ORACLE proper is always the CPU one (device "cpu", the default: the restatement every parity bar
+        refers to and bench.py's cpu_baseline). Round 6: the EXACT ARBITER may be placed on the test's GPU (exact=True, device="cuda"): its
+        contractions are fp64 -- order-independent to 1e-16 wherever they run -- and with the fp64 copies of the weights cached in HBM (53 GB for
+        Vicuna-7B) a full-depth step costs milliseconds instead of the minute torch-CPU needs to widen 6.6 G parameters per step, so that it can
+        arbitrate a whole 64-step horizon instead of 3 steps. In exact mode the RMSNorm variance is an fp64 mean too (rounded to fp32 once).
         fp8=True: the reference math on the engine's fp8 weight path (RdxEngine(weights_fp8=True), BASELINE configs[4]; the reference itself
         has no fp8 mode -- this is the fake-quantised restatement its parity is defined against): the seven decoder projections
         (+ LoRA-A, fused into QKV by the engine) and lm_head use e4m3 weights with one scale per output row; their INPUT activations are
@@ -273,7 +279,10 @@ class LlamaOracle:
         fp8 x fp8: every projection of a prefill, and decode / lm_head at batch >= 3 (batch <= 2 expands the weights in registers and keeps
         model-dtype activations). Products of the quantised values are accumulated in fp32 and rounded once to `dtype`."""
         self.cfg, self.dtype, self.exact, self.fp8 = cfg, dtype, exact, fp8
-        self.W = {k: v.to(dtype) for k, v in W.items()}
+        self.dev = torch.device(device)
+        self.W = {k: v.to(device=self.dev, dtype=dtype) for k, v in W.items()}
+        # exact mode away from the CPU: fp64 copies of the matrices, made once (keyed by the storage they widen)
+        self._dbl = {v.data_ptr(): v.double() for v in self.W.values() if v.dim() == 2} if (exact and self.dev.type != "cpu") else {}
         self.W8 = {}
         if fp8:
             for k, v in W.items():
@@ -285,12 +294,23 @@ class LlamaOracle:
                                                # run restated at batch 1 (activation scales are per row: rows do not interact; bench.py)
         self.lora = lora and any("lora_A" in k for k in W)
         self.cos, self.sin = rope_tables(cfg.head_dim, cfg.max_pos, cfg.rope_base, dtype)
+        self.cos, self.sin = self.cos.to(self.dev), self.sin.to(self.dev)
 
     # -- pieces ---------------------------------------------------------------------------------------
     def _linear(self, x, w, b=None):
         if not self.exact:
             return F.linear(x, w, b)
-        return F.linear(x.double(), w.double(), None if b is None else b.double()).to(x.dtype)
+        wd = self._dbl.get(w.data_ptr())
+        return F.linear(x.double(), w.double() if wd is None else wd, None if b is None else b.double()).to(x.dtype)
+
+    def _rms(self, x, w):
+        if not self.exact:
+            return rmsnorm(x, w, self.cfg.rms_eps)
+        var = x.double().pow(2).mean(-1, keepdim=True).to(torch.float32)          # the order-independent value of the fp32 mean
+        h = x * torch.rsqrt(var + self.cfg.rms_eps)
+        if w.dtype in (torch.float16, torch.bfloat16):
+            h = h.to(w.dtype)
+        return w * h
 
     def _mm(self, a, b):
         if not self.exact:
@@ -320,10 +340,11 @@ class LlamaOracle:
         """embed_tokens + img_proj_layer + splice (:571-594). qformer_embs [B,32,768] float or None."""
         W = self.W
         E = W["model.embed_tokens.weight"]
+        ids = ids.to(self.dev)
         if qformer_embs is None:
             return F.embedding(ids.clamp(max=E.shape[0] - 1), E)
-        img = self._linear(qformer_embs.to(self.dtype), W["model.img_proj_layer.weight"], W["model.img_proj_layer.bias"])
-        pos = split_positions(ids)
+        img = self._linear(qformer_embs.to(device=self.dev, dtype=self.dtype), W["model.img_proj_layer.weight"], W["model.img_proj_layer.bias"])
+        pos = split_positions(ids.cpu())
         rows = []
         for b in range(ids.shape[0]):
             p = int(pos[b])
@@ -334,16 +355,17 @@ class LlamaOracle:
         """_prepare_decoder_attention_mask (:475-496): causal(finfo.min) + padding(finfo.min)."""
         dt = self.dtype
         mn = torch.finfo(dt).min
+        key_mask = key_mask.to(self.dev)
         B, Tk = key_mask.shape
         inv = 1.0 - key_mask[:, None, None, :].expand(B, 1, Tq, Tk).to(dt)
         m = inv.masked_fill(inv.to(torch.bool), mn)
         if Tq > 1:
-            c = torch.full((Tq, Tq), mn)
-            idx = torch.arange(Tq)
+            c = torch.full((Tq, Tq), mn, device=self.dev)
+            idx = torch.arange(Tq, device=self.dev)
             c.masked_fill_(idx < (idx + 1).view(Tq, 1), 0)
             c = c.to(dt)
             if past:
-                c = torch.cat([torch.zeros(Tq, past, dtype=dt), c], dim=-1)
+                c = torch.cat([torch.zeros(Tq, past, dtype=dt, device=self.dev), c], dim=-1)
             m = m + c[None, None]
         return m
 
@@ -352,10 +374,11 @@ class LlamaOracle:
         L = f"model.layers.{l}."
         B, T, H = x.shape
         nh, d = c.heads, c.head_dim
-        h = rmsnorm(x, W[L + "input_layernorm.weight"], c.rms_eps)
+        h = self._rms(x, W[L + "input_layernorm.weight"])
         q = self._proj(h, L, "q_proj").view(B, T, nh, d).transpose(1, 2)
         k = self._proj(h, L, "k_proj").view(B, T, nh, d).transpose(1, 2)
         v = self._proj(h, L, "v_proj").view(B, T, nh, d).transpose(1, 2)
+        pos_ids = pos_ids.to(self.dev)
         cos = self.cos[pos_ids][:, None]                     # [B,1,T,d]
         sin = self.sin[pos_ids][:, None]
         q = (q * cos) + (_rot_half(q) * sin)
@@ -365,11 +388,11 @@ class LlamaOracle:
             v = torch.cat([past[1], v], dim=2)
         s = self._mm(q, k.transpose(2, 3)) / math.sqrt(d)
         s = s + mask
-        s = torch.max(s, torch.tensor(torch.finfo(s.dtype).min))
+        s = torch.max(s, torch.tensor(torch.finfo(s.dtype).min, device=s.device))
         p = F.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
         o = self._mm(p, v).transpose(1, 2).reshape(B, T, H)
         x = x + self._lin(o, L + "self_attn.o_proj.weight", groups=2)
-        h = rmsnorm(x, W[L + "post_attention_layernorm.weight"], c.rms_eps)
+        h = self._rms(x, W[L + "post_attention_layernorm.weight"])
         g = F.silu(self._lin(h, L + "mlp.gate_proj.weight")) * self._lin(h, L + "mlp.up_proj.weight")
         x = x + self._lin(g, L + "mlp.down_proj.weight", groups=4)
         return x, (k, v)
@@ -388,11 +411,26 @@ class LlamaOracle:
             x, kv = self.layer(l, x, mask, pos_ids, None if past is None else past[l])
             new_past.append(kv)
         self.last_hidden = x                                   # decoder output before the final norm (diagnostics)
-        h = rmsnorm(x, self.W["model.norm.weight"], self.cfg.rms_eps)
+        h = self._rms(x, self.W["model.norm.weight"])
         hl = h if all_logits else h[:, -1:]
         # lm_head runs on the [B][H] last-position rows in prefill and decode alike: fp8 x fp8 from batch 3
         logits = self._lin(hl, "lm_head.weight", a8=self.fp8 and (x.shape[0] >= 3 or self.force_a8))
         return logits, new_past, h
+
+    def forced_logits(self, ids: torch.Tensor, qformer_embs: Optional[torch.Tensor], tokens: torch.Tensor, pad_id: int = 0) -> List[torch.Tensor]:
+        """Teacher-forced pass: prefill, then one decode step per column of `tokens` [B, n] except the last -- the logits rows [B, V] (model
+        dtype, on the CPU) of steps 0 .. n-1, every step fed the GIVEN token instead of its own argmax (what the parity tests feed the engine
+        through rdx_decode_step_ids), so that several evaluations can be compared on identical inputs over a whole horizon."""
+        key_mask = ids.ne(pad_id).long()
+        logits, past, _ = self.forward(self.embed(ids, qformer_embs), key_mask, positions_from_mask(key_mask))
+        E = self.W["model.embed_tokens.weight"]
+        rows = [logits[:, -1, :].cpu()]
+        for s in range(tokens.shape[1] - 1):
+            key_mask = torch.cat([key_mask, key_mask.new_ones(key_mask.shape[0], 1)], dim=-1)
+            x = F.embedding(tokens[:, s:s + 1].to(self.dev).clamp(max=E.shape[0] - 1), E)
+            logits, past, _ = self.forward(x, key_mask, positions_from_mask(key_mask)[:, -1:], past)
+            rows.append(logits[:, -1, :].cpu())
+        return rows
 
     # -- greedy loop (transformers==4.28.1 GenerationMixin.greedy_search, restated) --------------------
     def generate_greedy(self, ids: torch.Tensor, qformer_embs: Optional[torch.Tensor], max_new: int,
@@ -409,7 +447,7 @@ class LlamaOracle:
         toks, scores, margins = [], [], []
         E = self.W["model.embed_tokens.weight"]
         for step in range(max_new):
-            row = logits[:, -1, :]
+            row = logits[:, -1, :].cpu()
             scores.append(row.clone())
             top2 = row.float().topk(2, dim=-1).values
             margins.append(top2[:, 0] - top2[:, 1])
@@ -423,7 +461,7 @@ class LlamaOracle:
             if (eos_id >= 0 and unfinished.max() == 0) or step == max_new - 1:
                 break
             pos = positions_from_mask(key_mask)[:, -1:]
-            x = F.embedding(nxt[:, None].clamp(max=E.shape[0] - 1), E)
+            x = F.embedding(nxt[:, None].to(self.dev).clamp(max=E.shape[0] - 1), E)
             logits, past, _ = self.forward(x, key_mask, pos, past)
         return {"tokens": torch.stack(toks, dim=1), "scores": scores, "margins": torch.stack(margins, 0)}
 

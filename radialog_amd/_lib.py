@@ -55,6 +55,7 @@ SYMBOLS = {
     "rdx_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(RdxConfig)]),
     "rdx_destroy": (None, [_P]),
     "rdx_last_error": (C.c_char_p, [_P]),
+    "rdx_build_hash": (C.c_char_p, []),
     "rdx_sync": (C.c_int, [_P]),
     "rdx_stream": (_P, [_P]),
     "rdx_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.c_int64, C.c_int]),
@@ -119,6 +120,11 @@ def load_hooks(lib):
         return
     src = lib
     if not hasattr(lib, next(iter(HOOK_SYMBOLS))):
+        if os.environ.get("RDX_LIB_PATH") and os.path.realpath(LIB_PATH) != os.path.realpath(os.path.join(HERE, "librdx.so")):
+            # librdx_hooks.so NEEDs "librdx.so" and finds the in-tree one through $ORIGIN: next to an RDX_LIB_PATH build that does not link the
+            # hooks in, that would be a SECOND copy of the library with its own contexts
+            raise RdxLibraryError(f"RDX_DEBUG_HOOKS is set, but RDX_LIB_PATH={LIB_PATH} does not link the hooks in and {HOOKS_PATH} would load a "
+                                  "second librdx.so next to it: build the alternative library with api_debug.hip (tools/sanitize_host.sh does)")
         if not os.path.exists(HOOKS_PATH):
             raise RdxLibraryError(f"RDX_DEBUG_HOOKS is set but {HOOKS_PATH} is missing: build it with `python -m radialog_amd.build`")
         try:
@@ -147,7 +153,9 @@ def load():
             f"{LIB_PATH} not found: build it with `python -m radialog_amd.build` (hipcc, gfx950). "
             "There is no CPU fallback for the RaDialog hot path.")
     try:
-        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)      # RTLD_GLOBAL: librdx_hooks.so resolves the context / launcher symbols against it
+        # RTLD_GLOBAL only when the hooks will be loaded: librdx_hooks.so resolves the context / launcher symbols against this handle. The
+        # product configuration keeps the library's C++ helpers (fail, gargs, run_gemm, ...) out of the process's global namespace.
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL if hooks_enabled() else C.RTLD_LOCAL)
     except OSError as e:
         raise RdxLibraryError(f"cannot load {LIB_PATH}: {e}") from e
     for name, (res, args) in SYMBOLS.items():
@@ -157,9 +165,35 @@ def load():
             raise RdxLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
+    check_build_hash(lib)
     load_hooks(lib)
     _lib = lib
     return lib
+
+
+def build_hash() -> str:
+    """The source hash compiled into the loaded library (rdx_build_hash)."""
+    return load().rdx_build_hash().decode()
+
+
+def check_build_hash(lib):
+    """Binary <-> source correspondence (round 6): the .so files are git-ignored and travel to the GPU box as built, so the library says which
+    sources it was compiled from and the loader compares that with the sources lying next to it. A mismatch is an error (rebuild:
+    `python -m radialog_amd.build`); RDX_ALLOW_STALE_LIB=1 turns it into a warning for bisecting with an old binary."""
+    from . import build as _b
+    try:
+        want = _b.source_hash()
+    except OSError:
+        return                      # a deployment without csrc/ next to the library: nothing to compare with
+    got = lib.rdx_build_hash().decode()
+    if got != want:
+        msg = (f"{LIB_PATH} was built from sources with hash {got}, the tree's radialog_amd/csrc hashes to {want}: the library is stale -- "
+               "rebuild it with `python -m radialog_amd.build`")
+        if os.environ.get("RDX_ALLOW_STALE_LIB", "0") not in ("", "0"):
+            import warnings
+            warnings.warn(msg)
+        else:
+            raise RdxLibraryError(msg)
 
 
 def check(ctx, rc: int, what: str):

@@ -29,27 +29,48 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+HASH_FILE = os.path.join(CSRC, ".build_hash")      # the source hash the in-tree objects / libraries were built from (git-ignored, travels with gpurun)
+
+
+def built_hash():
+    try:
+        with open(HASH_FILE) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
 def _stale():
+    """The libraries are stale when they are missing or when the hash compiled into them (rdx_build_hash(), mirrored in csrc/.build_hash)
+    is not the hash of the sources in the tree -- content, not mtimes (round 6: a checkout or a copy can leave an old .so newer than the
+    sources it no longer matches)."""
     if not os.path.exists(OUT) or not os.path.exists(OUT_HOOKS):
         return True
-    t = min(os.path.getmtime(OUT), os.path.getmtime(OUT_HOOKS))
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HOOK_SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return built_hash() != source_hash()
+
+
+def _obj_stale(src, obj, hdr_mtime):
+    return (not os.path.exists(obj)) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_mtime)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    h = source_hash()
     objs, hook_objs = [], []
     procs = []
+    hdr_mtime = max(os.path.getmtime(os.path.join(CSRC, x)) for x in HEADERS + [os.path.abspath(__file__)] if os.path.exists(os.path.join(CSRC, x)))
     for s in SOURCES + HOOK_SOURCES:
-        o = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        src, o = os.path.join(CSRC, s), os.path.join(CSRC, s.replace(".hip", ".o"))
+        (hook_objs if s in HOOK_SOURCES else objs).append(o)
+        # api.hip carries the hash (rdx_build_hash): recompiled on every rebuild; the other units only when they or a header changed
+        if not force and s != "api.hip" and not _obj_stale(src, o, hdr_mtime):
+            continue
+        cmd = [hipcc] + FLAGS + ([f'-DRDX_BUILD_HASH="{h}"'] if s == "api.hip" else []) + ["-c", src, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
-        (hook_objs if s in HOOK_SOURCES else objs).append(o)
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
@@ -62,6 +83,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(HASH_FILE, "w") as f:
+        f.write(h + "\n")
     return OUT
 
 

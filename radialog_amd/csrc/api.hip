@@ -94,6 +94,13 @@ extern "C" void rdx_destroy(rdx_ctx* c) {
 
 extern "C" const char* rdx_last_error(rdx_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
+// radialog_amd/build.py source_hash() of the kernel / ABI sources this library was compiled from (round 6: _lib.load() refuses a library whose
+// hash is not the tree's -- a stale .so cannot be tested or benchmarked silently)
+#ifndef RDX_BUILD_HASH
+#define RDX_BUILD_HASH "unstamped"
+#endif
+extern "C" const char* rdx_build_hash(void) { return RDX_BUILD_HASH; }
+
 extern "C" int rdx_sync(rdx_ctx* c) {
     if (!c) return -1;
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -273,6 +280,11 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
         ALLOC(c, c->dxs, (size_t)std::max(32, Bp) * sizeof(float));
         ALLOC(c, c->datt, (size_t)Bp * H * 2); ALLOC(c, c->dgu, (size_t)Bp * I * 2);
         ALLOC(c, c->pqe, (size_t)B * 32 * f.qformer_dim * 2); ALLOC(c, c->pimg, (size_t)B * 32 * H * 2);      // image splice rows
+        // rows 33-128 decode on the row-block family, which exists for the Vicuna-7B widths only (api_dispatch.hip blk64_ok): say so HERE, not at the
+        // first prefill of a context that already holds a 128-row KV cache
+        if (B > 32 && !blk64_ok(c, B))
+            return fail(c, -1, "rdx_finalize_weights: max_batch %d > 32 needs the Vicuna-7B widths (hidden 4096, inter 11008: the row-block decode family, model-dtype "
+                               "or fp8 weights); this model (hidden %d, inter %d) holds at most 32 rows per context", B, H, I);
     }
     if (f.enable_vision) {
         const int H = f.q_hidden, I = f.q_inter;
@@ -355,7 +367,8 @@ extern "C" int rdx_finalize_weights(rdx_ctx* c) {
 }
 
 // Test / experiment switches of one context (read from the environment once, at rdx_create): "flash_min" = workgroups from which the batched
-// prefill attention takes flash_prefill_k (0 = never, 1 = always; RDX_FLASH_MIN), "pconv" = the encoder on fragment-packed activations (RDX_PCONV).
+// prefill attention takes flash_prefill_k (0 = never, 1 = always; RDX_FLASH_MIN), "pconv" = the encoder on fragment-packed activations (RDX_PCONV),
+// "xs16" = batch 3-16 decode on the one-row-tile family (RDX_XS16), "prompt_blk" = one prompt's K = 4096 projections on 32-row blocks (RDX_PBLK).
 extern "C" int rdx_set_option(rdx_ctx* c, const char* name, int value) {
     if (!c || !name) return -1;
     if (!strcmp(name, "flash_min")) { c->flash_min = value; return 0; }

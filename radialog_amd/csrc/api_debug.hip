@@ -146,7 +146,7 @@ extern "C" int rdx_conv_test(rdx_ctx* c, const void* X, const float* W, const fl
         if (!c->zero16 || !pconv_supported(pa, ksize * ksize, stride, epi)) { hipFree(buf); return fail(c, -1, "rdx_conv_test: shape not supported by pconv"); }
     }
     auto once = [&]() {
-        if (path) launch_pconv(dt, pa, ksize * ksize, stride, epi, path == 2, c->stream);
+        if (path && !launch_pconv(dt, pa, ksize * ksize, stride, epi, path == 2, c->stream)) { hipFree(buf); return fail(c, -1, "rdx_conv_test: pconv refused the tiling"); }
         else conv_gemm(c, X, w, bias, need_res ? resid : nullptr, out, B, H, H, Cin, ksize, ksize, stride, ksize / 2, Ho, Ho, epi);
     };
     once();

@@ -83,7 +83,7 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
         PConvArgs a; memset(&a, 0, sizeof(a));
         a.X = X; a.W = W.w; a.bias = bias; a.resid = resid; a.out = out; a.zero16 = c->zero16;
         a.Hin = a.Win = a.Hout = a.Wout = 1; a.Cin = K; a.N = W.N; a.M = rows; a.mt_in = a.mt_out = mtiles(rows); a.ldo = W.N; a.no_ksplit = c->pconv_noks;
-        launch_pconv(dt, a, 1, 1, epi, rowout, s);
+        if (!launch_pconv(dt, a, 1, 1, epi, rowout, s)) c->unsupported = "pconv: a 1 x 1 stride-1 convolution whose input and output row tilings differ";
     };
     if (stem_pool_supported(f.v_stem)) {
         // conv1 + bn1 + relu + maxpool in one launch: the 224^2 x 64 stem output never goes to HBM (stem.hip)
@@ -109,7 +109,7 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
         a.X = X; a.W = W.w; a.bias = bias; a.resid = resid; a.out = out; a.zero16 = c->zero16;
         a.Hin = Hin; a.Win = Hin; a.Cin = Cin; a.Hout = Hout; a.Wout = Hout; a.N = W.N;
         a.M = B * Hout * Hout; a.mt_in = mtiles((long)B * Hin * Hin); a.mt_out = mtiles(a.M); a.ldo = W.N; a.no_ksplit = c->pconv_noks;
-        launch_pconv(dt, a, taps, stride, epi, rowout, s);
+        if (!launch_pconv(dt, a, taps, stride, epi, rowout, s)) c->unsupported = "pconv: a 1 x 1 stride-1 convolution whose input and output row tilings differ";
     };
     for (const VBlock& vb : c->vb) {
         const int Ho = (Hc - 1) / vb.stride + 1;      // 3x3 pad 1 and the 1x1 downsample agree (odd sizes: 61 -> 31)
@@ -183,7 +183,7 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
         launch_to_f32(dt, c->cls_out, cls_logits, (size_t)Bimg * f.cls_classes, s);
         HIPCHK(c, hipStreamSynchronize(s));
         HIPCHK(c, hipGetLastError());
-        return 0;
+        return take_unsupported(c);
     }
     // a5: NCHW reshape scramble + ln_vision
     launch_scramble_layernorm(dt, t3, c->v_ln_g, c->v_ln_b, c->v_imgemb, image_embeds, Bimg, P, f.v_proj, f.v_ln_eps, s);
@@ -203,7 +203,7 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
             PConvArgs a; memset(&a, 0, sizeof(a));
             a.X = X; a.W = W.w; a.bias = bias; a.resid = resid; a.out = out; a.zero16 = c->zero16;
             a.Hin = a.Win = a.Hout = a.Wout = 1; a.Cin = K; a.N = W.N; a.M = M; a.mt_in = mt; a.mt_out = mt; a.ldo = W.N; a.no_ksplit = c->pconv_noks;
-            launch_pconv(dt, a, 1, 1, epi, rowout, s);
+            if (!launch_pconv(dt, a, 1, 1, epi, rowout, s)) c->unsupported = "pconv: a 1 x 1 stride-1 convolution whose input and output row tilings differ";
         };
         auto attn = [&](const void* Q, long q_ts, const void* K_, const void* V_, long kv_bs, long kv_ts, int Tk) {
             AttnArgs at;
@@ -233,7 +233,7 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
             launch_layernorm_packed(dt, c->qt, L.f_g, L.f_b, last ? nullptr : c->qx, last ? qformer_out : nullptr, M, H, f.q_ln_eps, s);
         }
         HIPCHK(c, hipGetLastError());
-        return 0;
+        return take_unsupported(c);
     }
     launch_broadcast_rows(dt, c->q_query_ln, c->qx, NQ, H, B, s);
     for (const QLayer& L : c->ql) {
@@ -265,7 +265,7 @@ static int encode_impl(rdx_ctx* c, const float* image, const float* previous, in
         launch_layernorm(dt, c->qt, L.f_g, L.f_b, c->qx, last ? qformer_out : nullptr, M, H, f.q_ln_eps, s);
     }
     HIPCHK(c, hipGetLastError());
-    return 0;
+    return take_unsupported(c);
 }
 
 extern "C" int rdx_encode_image(rdx_ctx* c, const float* image, int B, float* qformer_out, float* image_embeds) {

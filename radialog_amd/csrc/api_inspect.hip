@@ -89,6 +89,33 @@ extern "C" int rdx_time(rdx_ctx* c, int what, int iters, float* ms_host) {
             if (xpk > 0) { a.X = c->dxn; a.ldx = a.K; a.norm_w = nullptr; a.xpacked = xpk - 1; a.xscale = pn.xscale; a.xgroups = pn.xgroups; }
             return a;
         };
+        // batch 3-16 decodes on xs16.hip (norm-prologue xstat16_k, un-split xrow16_k): time THOSE kernels, not the 32-row family the step never launches there
+        const bool x16 = what >= 1 && what <= 5 && xs16_ok(c, B);
+        if (x16) {
+            HIPCHK(c, hipEventRecord(e0, c->stream));
+            for (int i = 0; i < iters; ++i) {
+                for (int l = 0; l < (what == 5 ? 1 : f.layers); ++l) {
+                    const LlamaLayer& L = c->ll[same_layer ? 0 : l];
+                    if (what == 1) { GemmArgs a = gargs(c->dx, H, L.wgu, nullptr, c->dgu, f.inter, B); a.norm_w = L.mlp_norm; a.eps = f.rms_eps; a.out_packed = 1; xs16_proj(c, a, EPI_SILU_MUL); }
+                    else if (what == 2) { GemmArgs a = gargs(c->dx, H, L.wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = L.wqkv.Npad; a.norm_w = L.attn_norm; a.eps = f.rms_eps; xs16_proj(c, a, EPI_NONE); }
+                    else if (what == 5) { GemmArgs a = gargs(c->dx, H, c->lm_head, nullptr, nullptr, f.vocab, B); a.N = c->lm_head.Npad; a.n_valid = f.vocab; a.norm_w = c->final_norm; a.eps = f.rms_eps;
+                                          a.part_val = c->part_val; a.part_idx = c->part_idx; xs16_proj(c, a, EPI_LOGITS); }
+                    else {      // 3: o_proj, 4: down_proj -- xrow16_k with the residual epilogue, written to a scratch buffer so that repeated launches do not grow dx
+                        const GemmW& W = what == 3 ? L.wo : L.wdown;
+                        GemmArgs a = gargs(what == 3 ? c->datt : c->dgu, W.K, W, nullptr, c->dqkv, H, B); a.resid = c->dx; a.ldr = H; a.xpacked = 1;
+                        launch_xrow16(f.dtype, a, c->stream);
+                    }
+                    ++launches;
+                }
+            }
+            HIPCHK(c, hipEventRecord(e1, c->stream));
+            HIPCHK(c, hipEventSynchronize(e1));
+            float ms16 = 0.f;
+            HIPCHK(c, hipEventElapsedTime(&ms16, e0, e1));
+            hipEventDestroy(e0); hipEventDestroy(e1);
+            *ms_host = ms16 / (float)launches;
+            return take_unsupported(c);
+        }
         if (what == 1) { GemmArgs a = gargs(c->dx, H, c->ll[0].wgu, nullptr, c->dgu, f.inter, B); a.norm_w = c->ll[0].mlp_norm; a.eps = f.rms_eps; pre(a, EPI_SILU_MUL); }
         if (what == 2) { GemmArgs a = gargs(c->dx, H, c->ll[0].wqkv, nullptr, c->dqkv, c->ld.qkv_ld, B); a.N = c->ll[0].wqkv.Npad; a.norm_w = c->ll[0].attn_norm; a.eps = f.rms_eps; pre(a, EPI_NONE); }
         if (what == 5) { GemmArgs a = gargs(c->dx, H, c->lm_head, nullptr, nullptr, f.vocab, B); a.N = c->lm_head.Npad; a.n_valid = f.vocab; a.norm_w = c->final_norm; a.eps = f.rms_eps; pre(a, EPI_LOGITS); }

@@ -386,12 +386,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 16 ? 1 : 4)) void decode_atte
 
 void launch_decode_attention(int dtype, const DecAttnArgs& a, int B, hipStream_t s) {
     dim3 grid(a.d.heads, B);
-    const char* tp_env = getenv("RDX_ATT_TP");                       // tests: 1 forces the throughput variant, 2 the 8-wave one
+    const char* tp_env = getenv("RDX_ATT_TP");                       // tests: 1 forces the throughput variant, 2 the 8-wave one (re-read per launch: the tests flip it between engines)
     const int force_tp = tp_env ? atoi(tp_env) : 0;
+    static const bool att_mid = !(getenv("RDX_ATT_MID") && atoi(getenv("RDX_ATT_MID")) == 0);      // A/B switch, read once
     if (a.d.heads * B <= 256 && !force_tp) {
         const size_t smem = decode_attention_smem_floats(DA_WAVES, a.d.max_len) * sizeof(float);
         RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T, DA_WAVES>), grid, dim3(DA_WAVES * 64), smem, s, a));
-    } else if (force_tp == 2 || (a.d.heads * B <= 512 && !force_tp && !(getenv("RDX_ATT_MID") && atoi(getenv("RDX_ATT_MID")) == 0))) {
+    } else if (force_tp == 2 || (a.d.heads * B <= 512 && !force_tp && att_mid)) {
         // 9-16 rows at 32 heads (round 5; RDX_ATT_MID=0: the 4-wave form, the A/B leg; RDX_ATT_TP=2: forced, tests): batch 12 3.162 -> 3.098 ms per step, 16: 3.222 -> 3.178
         const size_t smem = decode_attention_smem_floats(DA_WAVES_MID, a.d.max_len) * sizeof(float);
         RDX_DISPATCH_T(dtype, T, hipLaunchKernelGGL((decode_attention_k<T, DA_WAVES_MID>), grid, dim3(DA_WAVES_MID * 64), smem, s, a));

@@ -449,9 +449,10 @@ static void launch_pc1(const PConvArgs& a, int taps, int stride, bool rowout, in
     }
 }
 
-void launch_pconv(int dtype, PConvArgs a, int taps, int stride, int epi, bool rowout, hipStream_t s) {
-    // a 1 x 1 stride-1 convolution reads input tile mt for output tile mt (no gather): the two tensors must have the same tiling
-    if (taps == 1 && stride == 1 && a.mt_in != a.mt_out) { fprintf(stderr, "launch_pconv: mt_in %d != mt_out %d for a 1 x 1 stride-1 convolution\n", a.mt_in, a.mt_out); abort(); }
+bool launch_pconv(int dtype, PConvArgs a, int taps, int stride, int epi, bool rowout, hipStream_t s) {
+    // a 1 x 1 stride-1 convolution reads input tile mt for output tile mt (no gather): the two tensors must have the same tiling. Nothing is
+    // launched otherwise and the caller reports through the ABI's error path (rdx_ctx::unsupported -> -8): the library never aborts its host process
+    if (taps == 1 && stride == 1 && a.mt_in != a.mt_out) return false;
     a.clog = ilog2(a.Cin / 32);
     int mtw = 1, ntw = 2, ks = 1;
     pconv_pick(a, taps, &mtw, &ntw, &ks);
@@ -462,6 +463,7 @@ void launch_pconv(int dtype, PConvArgs a, int taps, int stride, int epi, bool ro
         else if (epi == EPI_RESID) launch_pc1<T, EPI_RESID>(a, taps, stride, rowout, mtw, ntw, ks, s);
         else launch_pc1<T, EPI_NONE>(a, taps, stride, rowout, mtw, ntw, ks, s);
     });
+    return true;
 }
 
 }  // namespace rdx

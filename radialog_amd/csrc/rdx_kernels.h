@@ -148,7 +148,7 @@ void launch_wsgemm(int dtype, const GemmArgs& a, const ConvGeom& cg, int epi, co
 
 // fragment-packed convolution (pconv.hip): taps 1 | 9 (3 x 3 pad 1), stride 1 | 2, epilogues NONE / RELU / RESID_RELU; rowout = row-major output
 bool pconv_supported(const PConvArgs& a, int taps, int stride, int epi);
-void launch_pconv(int dtype, PConvArgs a, int taps, int stride, int epi, bool rowout, hipStream_t s);
+bool launch_pconv(int dtype, PConvArgs a, int taps, int stride, int epi, bool rowout, hipStream_t s);      // false: refused (1 x 1 stride-1 with mt_in != mt_out), nothing launched
 // LayerNorm / broadcast on packed tensors (the Q-Former on packed activations)
 bool layernorm_packed_supported(int H);
 void launch_layernorm_packed(int dtype, const void* x, const float* gamma, const float* beta, void* out, float* out_f32, int M, int H, float eps, hipStream_t s);

@@ -47,7 +47,7 @@ def check_greedy(toks, scores, ref, tol, min_cover=0.9, label="", margin_rule_to
     return compared, total, worst
 
 
-def teacher_forced(eng, ref, ids, qf, N, tol, label, rows=None):
+def teacher_forced(eng, ref, ids, qf, N, tol, label, rows=None, collect=None):
     """Decode N steps feeding the ORACLE's tokens (rdx_decode_step_ids), so that every step's inputs are the oracle's and every
     (row, step) pair is compared -- a free-running comparison ends a row at its first near-tie flip, long before position 416.
     Per (row, step): the largest of the 32 001 logit differences must be below tol for >= 99 % of the pairs and below 1.5 x tol for all of
@@ -55,7 +55,8 @@ def teacher_forced(eng, ref, ids, qf, N, tol, label, rows=None):
     |logit| in [4, 8), where five-step legs see 6-9e-3; the oracle itself sits 5e-3 from the exactly-accumulated value); the engine's own
     argmax equals the oracle's token unless the oracle's margin is <= 2 x the measured logit error of that step.
     rows: the engine's rows the oracle was run on (ref holds len(rows) rows, in that order) -- the other rows of the batch ride along on their own
-    argmax tokens (rows are independent; they load the kernels like any row) and are only checked for NaN. Returns (identical, total, worst error)."""
+    argmax tokens (rows are independent; they load the kernels like any row) and are only checked for NaN. collect: a list that receives the fp32
+    logit rows [len(rows) or B, V] of every step (for a second comparison, e.g. against the exact evaluation). Returns (identical, total, worst error)."""
     rt = ref["tokens"]
     B = rt.shape[0]
     toks, lg = eng.prefill(ids, qf, max_new=N, eos_id=-1)
@@ -72,6 +73,8 @@ def teacher_forced(eng, ref, ids, qf, N, tol, label, rows=None):
         prev_am = lgc.argmax(dim=1)
         if rows is not None:
             lgc = lgc[rows]
+        if collect is not None:
+            collect.append(lgc.clone())
         err = (lgc - ref["scores"][s].float()).abs().amax(dim=1)
         worst = max(worst, float(err.max()))
         over += int((err >= tol).sum())

@@ -26,3 +26,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(REPO, "tests", "golden")
+
+
+def pytest_report_header(config):
+    """Which binary is under test (round 6): the source hash compiled into librdx.so and the tree's -- _lib.load() refuses a mismatch."""
+    try:
+        from radialog_amd import _lib, build
+        return f"librdx: build hash {_lib.build_hash()} (tree {build.source_hash()}), {_lib.LIB_PATH}"
+    except Exception as e:          # no library yet: the tests that need it fail loudly themselves
+        return f"librdx: not loaded ({type(e).__name__}: {e})"

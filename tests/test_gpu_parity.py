@@ -369,7 +369,8 @@ prefill (gemm8.hip) and from batch 3 in decode (xstat32.hip); the oracle runs th
             ref = ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True, fp8=fp8).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
             # the exactly-accumulated evaluation costs as much again: on the legs that span the kernel families (batch 1, 20, 32)
             with_exact = (not fp8) and layers == 1 and B in (1, 12, 20, 32)
-            truth = (ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True, exact=True).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
+            # (round 6: the fp64 arbiter runs on this GPU -- oracle/ref_cpu.py LlamaOracle(device=...): fp64 contractions are order-independent wherever they run)
+            truth = (ref_cpu.LlamaOracle(cpu_w, cfg.llama, DT[dtype], lora=True, exact=True, device=eng.device).generate_greedy(ids, qf, max_new=N, eos_id=-1, pad_id=0)
                      if with_exact else None)
         toks, scores, n = eng.generate(ids, qf, max_new=N, eos_id=-1, pad_id=0, output_scores=True, use_graph=True)
         tol = PROD_TOL[dtype] * layers ** 0.5        # accumulation-order noise adds up layer by layer (two layers: 1.4e-2 in fp16)

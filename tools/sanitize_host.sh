@@ -18,9 +18,10 @@ from radialog_amd import build
 print(" ".join(build.SOURCES + build.HOOK_SOURCES))     # one library: the hooks linked in (_lib.load_hooks takes them from RDX_LIB_PATH when it exports them)
 PY
 )
+  HASH=$(python -c "import sys; sys.path.insert(0, '$ROOT'); from radialog_amd import build; print(build.source_hash())")
   pids=""
   for s in $SRCS; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -g -std=c++17 -fPIC -fsanitize=undefined,bounds,integer-divide-by-zero -fno-sanitize=vptr -fno-omit-frame-pointer \
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -DRDX_BUILD_HASH="\"$HASH\"" -O3 -g -std=c++17 -fPIC -fsanitize=undefined,bounds,integer-divide-by-zero -fno-sanitize=vptr -fno-omit-frame-pointer \
       -Wno-unused-value -Wno-option-ignored -c $CSRC/$s -o /tmp/rdx_asan/${s%.hip}.o & pids="$pids $!"
   done
   rc=0; for p in $pids; do wait $p || rc=1; done
