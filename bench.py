@@ -16,7 +16,9 @@ under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-ad
 and fails loudly when fewer than N GPUs are visible. Launched by torch.distributed.run directly (the driver's form) it reads
 RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment; WORLD_SIZE must equal --gpus.
 
-Rank 0 prints ONE JSON line. `value` = reports/s of the whole job with inputs resident in HBM. Added objects:
+Rank 0 prints ONE JSON line of < 4 KB (round 6: compact_line() -- the contract's fields, `roofline` / `cpu_baseline` with scalars only, every sub-run as
+`<key>_value` / `_decode_ms` / `_frac` scalars, every parity leg as {ok, same, n, worst, bar}) and writes the full record described below to
+bench_detail.json beside this script (RDX_BENCH_DETAIL overrides the path). `value` = reports/s of the whole job with inputs resident in HBM. The full record:
   roofline     bound "hbm": the kernel rocprofv3 ranks first in the decode loop -- at batch <= 2 the chained down(l) -> QKV(l+1)
                launch `decode_chain_k` (profiles/r03_bench_b1_kernel_stats.md), at batch 3-32 the gate/up SwiGLU `xstat32_k`:
                algorithmic bytes per launch / its average launch duration measured live with HIP events on the library's stream
@@ -109,7 +111,7 @@ def prefill_flops(lc, T, B):
     return B * (per_tok * T + attn + 2.0 * lc.vocab * H + 2.0 * 32 * lc.qformer_dim * H)
 
 
-PMC_FILES = ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json")
+PMC_FILES = ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json")
 
 
 def pmc_traffic(kernel_key):
@@ -454,7 +456,8 @@ def measure_detail(eng, cfg, args, B, T, N, img, ids, out_q, elapsed_per_step_ms
         ms = eng.time_unit(1, 10)
         wb = wbytes(2 * I_, H_)
         nb = 2 * I_ * H_ * wb + B * H_ * wb + H_ * 2 + B * I_ * 2
-        nm = (f"xstat32_k<{args.dtype},EPI_SILU_MUL{',W8,A8 (fp8 x fp8 MFMA)' if wb == 1 else ''}> (gate/up SwiGLU, activation-stationary batch 3-32 GEMM)" if B > 2 else
+        nm = (f"xstat16_k<{args.dtype},EPI_SILU_MUL,NORM> (gate/up SwiGLU with the RMSNorm prologue, one-row-tile family of batch 3-16)" if (3 <= B <= 16 and wb == 2) else
+              f"xstat32_k<{args.dtype},EPI_SILU_MUL{',W8,A8 (fp8 x fp8 MFMA)' if wb == 1 else ''}> (gate/up SwiGLU, activation-stationary batch 3-32 GEMM)" if B > 2 else
               f"skinny_gemm_k<{args.dtype},MT,EPI_SILU_MUL,NORM{',W8' if wb == 1 else ''}> (gate/up SwiGLU GEMV)")
         dom = (nm, ms, nb, f"gate_up B={B} {args.dtype}{' fp8' if args.fp8 else ''}")
         if B > 2:
@@ -550,7 +553,7 @@ def fixture_check(dtype, B, fp8, tokens_row0):
 def cpu_baseline_pointer():
     """N > 1 lines: the CPU oracle is timed on rank 0 at N = 1 only (contract); multi-rank lines carry the committed N = 1 figure of this
     build so that SCALE records are self-contained."""
-    for name in ("r05_bench.json", "r04_bench.json", "r03_bench.json"):
+    for name in ("r06_bench.json", "r05_bench.json", "r04_bench.json", "r03_bench.json"):
         try:
             with open(os.path.join(REPO, "profiles", name)) as f:
                 cb = json.loads(f.read().strip().splitlines()[-1])["cpu_baseline"]
@@ -611,6 +614,83 @@ def gather_clock(dist, elapsed, world, device):
     dist.all_gather(allt, te)
     dist.all_reduce(te, op=dist.ReduceOp.MAX)
     return float(te.item()), [float(t.item()) for t in allt]
+
+
+def _sig(x, n=5):
+    """Floats of the compact line at n significant digits (the line has to stay under 4 KB; the full figures are in the detail file)."""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}")
+    if isinstance(x, list):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def _parity_brief(p):
+    return {"ok": bool(p.get("ok")), "same": p.get("tokens_identical"), "n": p.get("tokens_compared"), "worst": _sig(p.get("worst_logit_err"), 3),
+            "bar": _sig(p.get("abs_bar"), 3)}
+
+
+def compact_line(res, detail_name):
+    """The ONE JSON line of stdout, under 4 KB (round 6, VERDICT r5 "weak" 10: the round-5 line was 15 KB, the driver keeps 8 KB of stdout, so the
+    configs[2] / configs[4] sub-runs never reached its record): the contract's fields in full, `roofline` and `cpu_baseline` with scalars only, every
+    sub-run as `<key>_value` / `_ms_per_step` / `_decode_ms` / `_frac` scalars, every parity leg as {ok, same, n, worst, bar}. Everything else -- kernel
+    names, prose, per-phase tables, token fixtures, divergence notes -- is in the detail file written beside it (`detail`)."""
+    roof = res["roofline"]
+    out = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                               "dtype", "data")}
+    cfg = res["config"]
+    out["config"] = {"workload": cfg["workload"][:150], "per_gpu_batch": cfg["per_gpu_batch"], "global_batch": cfg["global_batch"],
+                     "prompt_len": cfg["prompt_len"], "new_tokens": cfg["new_tokens"], "parallelism": cfg["parallelism"]}
+    r = {"bound": roof["bound"], "kernel": roof["kernel"].split(" (")[0], "achieved": _sig(roof["achieved"]), "peak": roof["peak"], "unit": roof["unit"],
+         "frac": _sig(roof["frac"]), "traffic": roof["traffic"], "bytes_per_launch": roof["bytes_per_launch"], "us_per_launch": _sig(roof["us_per_launch"]),
+         "decode_avg_step_ms": _sig(roof["decode_avg_step_ms"]), "decode_avg_frac": _sig(roof["decode_avg_frac"]), "prefill_ms": _sig(roof["prefill_ms"]),
+         "mfma_encode_frac": _sig(roof["mfma"]["encode_frac"]), "mfma_prefill_frac": _sig(roof["mfma"]["prefill_frac"])}
+    ts = roof.get("traffic_source") or {}
+    r["traffic_stale"] = ts.get("stale")
+    out["encoder_ms_per_img"] = _sig(res["encoder_ms_per_img"])
+    out["tokens_per_s"] = _sig(res["tokens_per_s"])
+    out["rccl_ranks"] = res["rccl_ranks"]
+    out["per_rank_ms_per_step"] = _sig(res["per_rank_ms_per_step"], 12)
+    out["collective"] = (res.get("collective") or "")[:70]
+    for key in ("b32", "fp8_b32", "b64", "b128", "fp8_b128", "f16_b1"):
+        sub = res.get(key)
+        if not sub:
+            continue
+        out[f"{key}_value"] = _sig(sub["value"])
+        out[f"{key}_ms_per_step"] = _sig(sub["ms_per_step"])
+        out[f"{key}_decode_ms"] = _sig(sub["decode_avg_step_ms"])
+        out[f"{key}_frac"] = _sig(sub["decode_avg_frac"])
+        out[f"{key}_prefill_ms"] = _sig(sub["prefill_ms"])
+        out[f"{key}_tokens_ok"] = bool(sub["token_check"]["ok"])
+        r[f"{key}_decode_avg_frac"] = _sig(sub["decode_avg_frac"])              # (also inside `roofline`: the driver's record keeps that object's scalars)
+        if key in ("b32", "fp8_b32"):
+            out[f"{key}_global_batch"] = sub["global_batch"]
+            out[f"{key}_prefill_mfma_frac"] = r[f"{key}_prefill_mfma_frac"] = _sig(sub["mfma"]["prefill_frac"])
+            out[f"{key}_enc_ms"] = _sig(sub["encoder_ms_per_img"])
+    if "value_f16" in res:
+        out["value_f16"] = _sig(res["value_f16"])
+    e = res.get("enc_b256")
+    if e and "encoder_ms_per_img" in e:
+        out["enc_b256_ms"] = _sig(e["encoder_ms_per_img"])
+        out["enc_b256_frac"] = r["enc_b256_mfma_frac"] = _sig(e["encode_frac"])
+    out["roofline"] = r
+    cb = res.get("cpu_baseline") or {}
+    out["cpu_baseline"] = {k: (_sig(cb[k]) if k != "sample" else cb[k][:230]) for k in
+                           ("value", "unit", "cores", "host_cpus", "kind", "sample", "s_per_token", "s_encode", "s_prefill", "source") if k in cb}
+    par = {k[len("parity"):].lstrip("_") or res["dtype"]: _parity_brief(v) for k, v in cb.items() if k.startswith("parity")}
+    if par:
+        out["parity"] = par
+    for k, v in cb.items():
+        if k.startswith("fp8_vs_unquantised"):
+            out[k] = {"same": v["tokens_identical"], "n": v["tokens_compared"], "median_err": _sig(v["median_logit_err"], 3), "worst": _sig(v["worst_logit_err"], 3),
+                      "median_margin": _sig(v["median_oracle_margin"], 3)}
+    for k in ("token_check",):
+        out["tokens_ok"] = bool(res[k]["ok"])
+    for k in ("oracle_checked", "fixtures_match", "results_verified", "max_batch_per_gpu", "build_hash"):
+        if k in res:
+            out[k] = res[k]
+    out["detail"] = detail_name
+    return out
 
 
 def main():
@@ -875,8 +955,23 @@ def main():
         res["oracle_legs"] = {k: bool(cb[k].get("ok")) for k in parity_keys}
         res["fixtures_match"] = all(c.get("ok", True) for c in fixtures)
         res["results_verified"] = (oracle_checked and oracle_ok) or (not oracle_checked and res["fixtures_match"] and not STUB)
+        try:
+            from radialog_amd import _lib as _l
+            res["build_hash"] = "stub" if STUB else _l.build_hash()
+        except Exception:
+            res["build_hash"] = None
+        # the full record (kernel names, prose, per-phase tables, divergence notes) beside the script; the ONE stdout line is its < 4 KB extract
+        detail_path = os.environ.get("RDX_BENCH_DETAIL") or os.path.join(REPO, "bench_detail.json")
+        try:
+            with open(detail_path, "w") as f:
+                json.dump(res, f, indent=1)
+        except OSError as e:
+            print(f"bench.py: could not write {detail_path}: {e}", file=sys.stderr)
+        line = json.dumps(compact_line(res, os.path.basename(detail_path)), separators=(",", ":"))
+        if len(line) > 4096:
+            print(f"bench.py: WARNING: the result line is {len(line)} bytes (> 4096)", file=sys.stderr)
         sys.stdout.flush()
-        os.write(out_fd, (json.dumps(res) + "\n").encode())
+        os.write(out_fd, (line + "\n").encode())
         rc = 0 if (STUB or (oracle_ok and (oracle_checked or res["fixtures_match"]))) else 3
         if not res["fixtures_match"]:
             print("bench.py: WARNING: a timed configuration's first tokens differ from tests/golden/bench_tokens.json (token_check)", file=sys.stderr)

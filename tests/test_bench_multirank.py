@@ -38,8 +38,13 @@ def test_bench_gpus2_emits_one_line_with_the_multi_rank_fields():
     assert "source" in d["cpu_baseline"] or d["cpu_baseline"]["value"] is None
     assert d["cpu_baseline"]["kind"] == "port" and "N = 1" in d["cpu_baseline"]["sample"]
     assert d["oracle_checked"] is False
-    # both sub-runs ride the same line, labelled as the 8-GPU configurations' per-GPU loads
-    b32, f8 = d["b32"], d["fp8_b32"]
+    # both sub-runs ride the same line as scalars (round 6: the line stays under 4 KB; the nested records are in the detail file beside bench.py)
+    assert len(json.dumps(d)) < 4096
+    assert d["b32_global_batch"] == 64 and d["fp8_b32_global_batch"] == 64 and d["b32_value"] > 0 and d["fp8_b32_value"] > 0
+    assert d["roofline"]["b32_decode_avg_frac"] == d["b32_frac"]
+    with open(os.path.join(REPO, d["detail"])) as f:
+        full = json.load(f)
+    b32, f8 = full["b32"], full["fp8_b32"]
     assert b32["workload"].startswith("configs[3]") and "RCCL all-gather" in b32["workload"]
     assert b32["n_gpus"] == 2 and b32["per_gpu_batch"] == 32 and b32["global_batch"] == 64 and len(b32["per_rank_ms_per_step"]) == 2
     assert f8["workload"].startswith("configs[4]") and f8["global_batch"] == 64 and f8["dtype"].endswith("+fp8w")
@@ -56,4 +61,4 @@ def test_bench_stub_single_rank_under_the_launcher():
                        env=env, capture_output=True, text=True, timeout=600, cwd=REPO)
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
-    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and len(d["per_rank_ms_per_step"]) == 1 and "b32" not in d
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and len(d["per_rank_ms_per_step"]) == 1 and "b32_value" not in d
