@@ -684,6 +684,9 @@ def compact_line(res, detail_name):
         if k.startswith("fp8_vs_unquantised"):
             out[k] = {"same": v["tokens_identical"], "n": v["tokens_compared"], "median_err": _sig(v["median_logit_err"], 3), "worst": _sig(v["worst_logit_err"], 3),
                       "median_margin": _sig(v["median_oracle_margin"], 3)}
+    if "fp8_b32" in res:
+        out["fp8_statement"] = ("no e4m3 variant keeps the un-quantised model's tokens on random-init weights: W8A8 27/96, W8A8+bf16 LoRA-A 31/96, "
+                                "W8A16 decode 34/96, W8A16 40/96 (profiles/r06_fp8_variants.md); pinned by its definition: quantiser codes bit-exact")
     for k in ("token_check",):
         out["tokens_ok"] = bool(res[k]["ok"])
     for k in ("oracle_checked", "fixtures_match", "results_verified", "max_batch_per_gpu", "build_hash"):

@@ -11,6 +11,10 @@ extern "C" {
 
 /* debug: 8 timestamps (100 MHz ticks) of workgroup (0,0) of the stand-alone decode-attention kernel of `layer` */
 int rdx_attn_trace(rdx_ctx* ctx, int layer, long long* host);
+/* the fp8 path's activation quantisers on caller data (round 6: their e4m3 CODES and scales are compared with the oracle's fake quantisation, bit for bit).
+ * X [M][K] model dtype (device), K % 128 == 0. mode 0: quant_rows_k -- out8 [M][K] e4m3 bytes, scales [M][groups] (groups 1..4: 128-deep blocks
+ * [NB q / G, NB (q + 1) / G)); mode 1: RMSNorm(norm_w [K], eps) -> e4m3 -- out8 [M][K], scales [M]. */
+int rdx_quant_test(rdx_ctx* ctx, const void* X, int M, int K, int groups, int mode, const void* norm_w, float eps, void* out8, float* scales);
 /* debug: per-workgroup timestamps of one stand-alone decode GEMV (what: 1 gate/up, 2 qkv, 4 down), host[tile*8 + 0..5]; the
  * persistent batch >= 3 kernels (xstat32.hip) write one record per WORKGROUP: entry, first trip's K loop done, first trip done, last
  * trip begins, its K loop done, end, [6] = trips, [7] = XCC id (tools/xs_trace.py) */

@@ -258,9 +258,28 @@ def fake_quant_e4m3(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
     return out
 
 
+def quant_e4m3_codes(x: torch.Tensor, groups: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The e4m3 CODES (uint8 [.., K]) and fp32 scales ([.., groups]) behind fake_quant_e4m3: what librdx's quant_rows_k / rmsnorm -> fp8 must produce
+    bit for bit on the same inputs (tests/test_gpu_gemm.py, rdx_quant_test)."""
+    xf = x.float()
+    K = xf.shape[-1]
+    NB = K // 128
+    codes = torch.empty(xf.shape, dtype=torch.uint8)
+    scales = torch.empty(xf.shape[:-1] + (groups,), dtype=torch.float32)
+    for q in range(groups):
+        a = (NB * q // groups) * 128
+        b = K if q == groups - 1 else (NB * (q + 1) // groups) * 128
+        seg = xf[..., a:b]
+        am = seg.abs().amax(dim=-1, keepdim=True)
+        inv = torch.where(am > 0, 448.0 / am, torch.ones_like(am))
+        scales[..., q] = torch.where(am > 0, am / 448.0, torch.ones_like(am))[..., 0]
+        codes[..., a:b] = (seg * inv).to(torch.float8_e4m3fn).view(torch.uint8)
+    return codes, scales
+
+
 class LlamaOracle:
     def __init__(self, W: Dict[str, torch.Tensor], cfg, dtype=torch.float16, lora: bool = True, exact: bool = False, fp8: bool = False,
-                 device="cpu"):
+                 device="cpu", fp8_lora_a: bool = True, a8_mode: str = "engine"):
         """W: fp32 (or already-rounded) tensors keyed by reference state_dict names; cast to `dtype` here
         the way `.half()` does for every floating parameter/buffer (demo.py:234).
         exact=True: the same op sequence and the same rounding points, but every contraction (linear layers, Q.K^T, P.V)
@@ -277,7 +296,10 @@ class LlamaOracle:
         (+ LoRA-A, fused into QKV by the engine) and lm_head use e4m3 weights with one scale per output row; their INPUT activations are
         e4m3 too -- one scale per row and K group (1 group behind an RMSNorm, 2 for o_proj, 4 for down_proj) -- wherever the engine multiplies
         fp8 x fp8: every projection of a prefill, and decode / lm_head at batch >= 3 (batch <= 2 expands the weights in registers and keeps
-        model-dtype activations). Products of the quantised values are accumulated in fp32 and rounded once to `dtype`."""
+        model-dtype activations). Products of the quantised values are accumulated in fp32 and rounded once to `dtype`.
+        Variants for the accuracy study of the fp8 configuration (tools/fp8_variants.py, round 6; the engine implements "engine" with fp8_lora_a = True):
+        a8_mode "engine" = the rule above, "always" = every pass fp8 x fp8 (= force_a8), "never" = W8A16 everywhere (e4m3 weights, model-dtype
+        activations), "prefill" = fp8 x fp8 in the prefill only, every decode step W8A16; fp8_lora_a False keeps the LoRA-A matrices in the model dtype."""
         self.cfg, self.dtype, self.exact, self.fp8 = cfg, dtype, exact, fp8
         self.dev = torch.device(device)
         self.W = {k: v.to(device=self.dev, dtype=dtype) for k, v in W.items()}
@@ -287,8 +309,9 @@ class LlamaOracle:
         if fp8:
             for k, v in W.items():
                 if k == "lm_head.weight" or (k.startswith("model.layers.") and v.dim() == 2 and
-                                             (k.endswith("_proj.weight") or k.endswith("lora_A.weight"))):
-                    self.W8[k] = fake_quant_e4m3(v)
+                                             (k.endswith("_proj.weight") or (fp8_lora_a and k.endswith("lora_A.weight")))):
+                    self.W8[k] = fake_quant_e4m3(v.to(self.dev))
+        self.a8_mode = a8_mode
         self._a8 = False                       # set per forward() call: are this pass's projections fp8 x fp8?
         self.force_a8 = False                  # True: every pass multiplies fp8 x fp8 whatever its batch -- ONE row of a batch >= 3 engine
                                                # run restated at batch 1 (activation scales are per row: rows do not interact; bench.py)
@@ -404,7 +427,8 @@ class LlamaOracle:
         pl = 0 if past is None else past[0][0].shape[2]
         mask = self._mask(key_mask, T, pl)
         # fp8 mode: a prefill (more than one token per row, or nothing cached) runs every projection fp8 x fp8; a decode step from batch 3
-        self._a8 = self.fp8 and (past is None or T > 1 or x.shape[0] >= 3 or self.force_a8)
+        prefill = past is None or T > 1
+        self._a8 = self.fp8 and {"engine": prefill or x.shape[0] >= 3 or self.force_a8, "always": True, "never": False, "prefill": prefill}[self.a8_mode]
         new_past = []
         nl = self.cfg.layers if n_layers is None else n_layers
         for l in range(nl):
@@ -414,7 +438,7 @@ class LlamaOracle:
         h = self._rms(x, self.W["model.norm.weight"])
         hl = h if all_logits else h[:, -1:]
         # lm_head runs on the [B][H] last-position rows in prefill and decode alike: fp8 x fp8 from batch 3
-        logits = self._lin(hl, "lm_head.weight", a8=self.fp8 and (x.shape[0] >= 3 or self.force_a8))
+        logits = self._lin(hl, "lm_head.weight", a8=self.fp8 and {"engine": x.shape[0] >= 3 or self.force_a8, "always": True, "never": False, "prefill": False}[self.a8_mode])
         return logits, new_past, h
 
     def forced_logits(self, ids: torch.Tensor, qformer_embs: Optional[torch.Tensor], tokens: torch.Tensor, pad_id: int = 0) -> List[torch.Tensor]:

@@ -87,6 +87,7 @@ SYMBOLS = {
 # include/rdx_hooks.h: every symbol of librdx_hooks.so
 HOOK_SYMBOLS = {
     "rdx_attn_trace": (C.c_int, [_P, C.c_int, _P]),
+    "rdx_quant_test": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, _P, _P]),
     "rdx_gemv_trace": (C.c_int, [_P, C.c_int, C.c_int, _P, C.c_int]),
     "rdx_gemm_test": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_float, C.c_int]),
     "rdx_kernel_bench": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float), _P, C.c_int]),

@@ -26,6 +26,20 @@ extern "C" int rdx_attn_trace(rdx_ctx* c, int layer, long long* host) {
     return 0;
 }
 
+// Test hook: the fp8 path's activation quantisers on caller data. mode 0 = quant_rows_k (rows of X [M][K] -> e4m3 bytes [M][K] + scales [M][groups]),
+// mode 1 = RMSNorm -> e4m3 (rmsnorm4096_k / rmsnorm_k <T, 5>: bytes [M][K] + one scale per row; norm_w [K] in the model dtype, groups ignored).
+extern "C" int rdx_quant_test(rdx_ctx* c, const void* X, int M, int K, int groups, int mode, const void* norm_w, float eps, void* out8, float* scales) {
+    if (!c || !X || !out8 || !scales || M <= 0 || K <= 0 || K % 128) return fail(c, -1, "rdx_quant_test: bad arguments (K %% 128 == 0)");
+    if (mode == 0 && (groups < 1 || groups > 4)) return fail(c, -1, "rdx_quant_test: 1..4 K groups");
+    if (mode == 1 && !norm_w) return fail(c, -1, "rdx_quant_test: mode 1 needs the norm weight");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (mode == 0) launch_quant_rows(c->cfg.dtype, X, K, out8, scales, M, K, groups, c->stream);
+    else launch_rmsnorm_fp8(c->cfg.dtype, X, norm_w, out8, scales, M, K, eps, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return 0;
+}
+
 // Debug: one stand-alone decode GEMV (what = 1 gate/up, 2 qkv, 4 down, as in rdx_time) of `layer` with per-workgroup
 // timestamps: host[tile*8 + {0 entry, 1 weights issued, 2 activations staged, 3 K loop done, 4 all waves done, 5 end}].
 extern "C" int rdx_gemv_trace(rdx_ctx* c, int what, int layer, long long* host, int max_tiles) {

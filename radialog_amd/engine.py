@@ -275,6 +275,19 @@ class RdxEngine:
                                                eps, force), "rdx_gemm_test")
         return out
 
+    def quant_test(self, x, groups=1, norm_w=None, eps=1e-6):
+        """The fp8 path's activation quantisers on caller data (rdx_quant_test): x [M, K] model dtype -> (e4m3 codes uint8 [M, K], fp32 scales
+        [M, groups]); norm_w given: RMSNorm -> e4m3 with one scale per row (the prefill's rmsnorm -> fp8)."""
+        M, K = x.shape
+        x = x.to(self.device, self.tdtype).contiguous()
+        nw = None if norm_w is None else norm_w.to(self.device, self.tdtype).contiguous()
+        g = 1 if norm_w is not None else groups
+        out8 = torch.empty(M, K, dtype=torch.uint8, device=self.device)
+        sc = torch.empty(M, g, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        check(self.ctx, self.lib.rdx_quant_test(self.ctx, _ptr(x), M, K, g, 0 if norm_w is None else 1, _ptr(nw), eps, _ptr(out8), _ptr(sc)), "rdx_quant_test")
+        return out8, sc
+
     def set_option(self, name: str, value: int):
         """rdx_set_option: "flash_min" (batched prefill attention kernel choice), "pconv" (packed / row-major encoder kernels)."""
         check(self.ctx, self.lib.rdx_set_option(self.ctx, name.encode(), int(value)), "rdx_set_option")

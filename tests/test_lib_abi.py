@@ -38,7 +38,7 @@ def test_hooks_live_in_their_own_library_and_need_the_switch(monkeypatch):
     for name in _declared_symbols("rdx_hooks.h"):
         assert not hasattr(lib, name), f"librdx.so still exports the test hook {name}"
         assert hasattr(hooks, name), f"librdx_hooks.so does not export {name}"
-    assert len(_lib.HOOK_SYMBOLS) == 7
+    assert len(_lib.HOOK_SYMBOLS) == 8
     bound = _lib.load()
     assert _lib.hooks_enabled() and callable(bound.rdx_gemm_test) and getattr(bound.rdx_gemm_test, "argtypes", None)
     # the switch off: a fresh handle gets raising stubs

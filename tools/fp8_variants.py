@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""What does the fp8 configuration (BASELINE configs[4]) cost in model output, and which variant of it costs least? (VERDICT r5 "next" 6.)
+
+The reference has no fp8 mode; the engine's is defined by LlamaOracle(fp8=True) (oracle/ref_cpu.py: the reference math on fake-quantised operands).
+This study evaluates that restatement in four variants against the UN-quantised restatement on the bench's own weights and prompts, at full depth
+(32 layers, Vicuna-7B widths), teacher-forced with the un-quantised model's greedy tokens:
+
+  W8A8           e4m3 weights (one scale per output row), e4m3 activations (one scale per row and K group), LoRA-A rows e4m3 -- what the engine
+                 runs at batch >= 3 (the bench's fp8_b32)
+  W8A8-loraA16   the same with the LoRA-A matrices kept in the model dtype
+  W8A8p-A16d     fp8 x fp8 in the prefill, W8A16 (e4m3 weights expanded in registers, model-dtype activations) in every decode step and lm_head --
+                 what the engine runs at batch <= 2
+  W8A16          e4m3 weights, model-dtype activations everywhere (no engine path: the prefill GEMMs have no weight-expanding kernel)
+
+Every evaluation runs on the GPU through torch (LlamaOracle(device=...)): the restatement is the same op sequence wherever it runs, and the four
+full-depth fp32-weight copies do not fit a CPU box's patience. Prints a markdown table: argmax identity with the un-quantised model, median / worst
+logit error, against the median top-2 margin of the un-quantised model.   python tools/fp8_variants.py [--rows 3] [--steps 32] [--dtype bf16]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_cpu  # noqa: E402
+from radialog_amd import synth  # noqa: E402
+from radialog_amd.config import full_cfg  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--layers", type=int, default=32)
+    a = ap.parse_args()
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[a.dtype]
+    dev = torch.device("cuda", 0)
+    cfg = full_cfg()
+    lc = cfg.llama if a.layers == 32 else type(cfg.llama)(layers=a.layers)
+    specs = synth.llama_specs(lc, lora=True)
+    W32 = {name: gen(name, shape, dev) for name, (shape, gen) in specs.items()}          # fp32 source tensors, on the GPU (26 GB)
+    T = 160
+    ids = synth.synth_prompt_ids(a.rows, T, vocab=lc.vocab, pad_rows=False, seed=7)
+    qf = synth.synth("t.qf_fp8var", (a.rows, 32, lc.qformer_dim), -1.0, 1.0)
+    with torch.no_grad():
+        base = ref_cpu.LlamaOracle({k: v.to(dt) for k, v in W32.items()}, lc, dt, lora=True, device=dev)
+        ref = base.generate_greedy(ids, qf, max_new=a.steps, eos_id=-1)
+        del base
+        torch.cuda.empty_cache()
+        margin = float(ref["margins"].median())
+        print(f"fp8 variants against the un-quantised {a.dtype} model: {lc.layers} layers, {a.rows} prompts x {a.steps} teacher-forced steps, T = {T}; "
+              f"median top-2 margin of the un-quantised model {margin:.3g}\n")
+        print("| variant | argmax identical | median logit error | worst logit error |")
+        print("|---|---|---|---|")
+        variants = [("W8A8 (engine, batch >= 3)", dict(a8_mode="always", fp8_lora_a=True)),
+                    ("W8A8-loraA16", dict(a8_mode="always", fp8_lora_a=False)),
+                    ("W8A8p-A16d (engine, batch <= 2)", dict(a8_mode="prefill", fp8_lora_a=True)),
+                    ("W8A16", dict(a8_mode="never", fp8_lora_a=True)),
+                    ("W8A16-loraA16", dict(a8_mode="never", fp8_lora_a=False))]
+        for name, kw in variants:
+            # the e4m3 values come from the fp32 SOURCE tensors like the engine's pack_weight_fp8_k (not from their model-dtype rounding)
+            o = ref_cpu.LlamaOracle(W32, lc, dt, lora=True, fp8=True, device=dev, **kw)
+            rows = o.forced_logits(ids, qf, ref["tokens"])
+            del o
+            torch.cuda.empty_cache()
+            same = sum(int((r.float().argmax(-1) == ref["tokens"][:, s]).sum()) for s, r in enumerate(rows))
+            errs = torch.stack([(r.float() - ref["scores"][s].float()).abs().amax(-1) for s, r in enumerate(rows)]).flatten()
+            print(f"| {name} | {same}/{a.rows * a.steps} | {float(errs.median()):.3g} | {float(errs.max()):.3g} |", flush=True)
+
+
+if __name__ == "__main__":
+    main()
