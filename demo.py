@@ -43,11 +43,12 @@ def parse_args(argv=None):
     return args
 
 
-def load_image(path, crop=448):
+def load_image(path, crop=448, engine=None):
     """demo.py:205-218 (load_image / remap_to_uint8 -> PIL 'L') + the inference transform (ReportDataset.py:96-106, demo.py:144);
-    crop=488 gives the findings classifier's `cp_transforms` (demo.py:169)."""
+    crop=488 gives the findings classifier's `cp_transforms` (demo.py:169). With an engine the resize / crop / ToTensor run on its GPU (rdx_transform_image:
+    the same bytes as the PIL path, tests/test_gpu_api.py)."""
     from radialog_amd import transforms
-    return transforms.create_chest_xray_transform_for_inference(512, center_crop_size=crop)(transforms.load_image(path))
+    return transforms.create_chest_xray_transform_for_inference(512, center_crop_size=crop, engine=engine)(transforms.load_image(path))
 
 
 def init_blip(cfg):
@@ -101,10 +102,14 @@ def main(argv=None):
     cfg = Config(args)
     blip_model = init_blip(cfg).eval()
     lang_model, tok = init_vicuna(args)
-    image = load_image(args.image) if args.image else synth.synth_images(1, 448)[0]
+    tf_engine = None
+    if args.image:                                      # the image transform runs on the decoder context's GPU (it needs no weights)
+        lang_model._ensure_engine()
+        tf_engine = lang_model._engine
+    image = load_image(args.image, engine=tf_engine) if args.image else synth.synth_images(1, 448)[0]
     findings = args.findings
     if findings is None and not args.no_classifier:
-        cp_image = load_image(args.image, crop=488) if args.image else synth.synth_images(1, 488)[0]
+        cp_image = load_image(args.image, crop=488, engine=tf_engine) if args.image else synth.synth_images(1, 488)[0]
         findings = init_chexpert_predictor(args).predict_findings(cp_image[None].half().cuda())[0]
         print("predicted findings:", findings or "(none)")
     findings = findings or "no finding"

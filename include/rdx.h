@@ -77,6 +77,13 @@ enum { RDX_SRC_F32 = 0, RDX_SRC_F16 = 1, RDX_SRC_BF16 = 2 };
 int rdx_set_weight_typed(rdx_ctx* ctx, const char* name, const void* data, int src_dtype, int64_t rows, int64_t cols, int kind);
 int rdx_finalize_weights(rdx_ctx* ctx);            /* resolves names, checks completeness, allocates workspaces    */
 
+/* image transform -- replaces create_chest_xray_transform_for_inference(resize, center_crop_size)(pil_image) (model/lavis/data/ReportDataset.py:96-106;
+ * demo.py:144 / :251: 512 -> 448 for the report model, demo.py:169: 512 -> 488 for the findings classifier) = torchvision Resize(resize) -> CenterCrop(crop)
+ * -> ToTensor -> ExpandChannels on the 8-bit "L" image of demo.py:205-218. img: DEVICE uint8 [H][W] row-major; out: DEVICE float32 [3][crop][crop] in [0, 1].
+ * Resize on a PIL image is PIL.Image.resize(BILINEAR) (Pillow Resample.c: antialiased triangle filter, two fixed-point passes, uint8 in between): the output
+ * equals Pillow's bit for bit. Works on any context (no weights involved). Error: the resized image is smaller than the crop (torchvision would zero-pad). */
+int rdx_transform_image(rdx_ctx* ctx, const uint8_t* img, int H, int W, int resize, int crop, float* out);
+
 /* Blip2Qformer.forward_image (blip2_qformer.py:467-484): image float32[B,3,S,S] ->
  *   qformer_out float32[B,n_query,q_hidden] (last_hidden_state), image_embeds float32[B,P,v_proj] (nullable). */
 int rdx_encode_image(rdx_ctx* ctx, const float* image, int batch, float* qformer_out, float* image_embeds);

@@ -61,6 +61,7 @@ SYMBOLS = {
     "rdx_set_weight": (C.c_int, [_P, C.c_char_p, _P, C.c_int64, C.c_int64, C.c_int]),
     "rdx_set_weight_typed": (C.c_int, [_P, C.c_char_p, _P, C.c_int, C.c_int64, C.c_int64, C.c_int]),
     "rdx_finalize_weights": (C.c_int, [_P]),
+    "rdx_transform_image": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "rdx_encode_image": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "rdx_encode_image2": (C.c_int, [_P, _P, _P, C.c_int, _P, _P]),
     "rdx_classify_findings": (C.c_int, [_P, _P, C.c_int, _P]),

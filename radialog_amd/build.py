@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "librdx.so")
 OUT_HOOKS = os.path.join(HERE, "librdx_hooks.so")
 SOURCES = ["gemm.hip", "xstat32.hip", "xs16.hip", "gemm_dma.hip", "gemm8.hip", "attn.hip", "flash.hip", "chain.hip", "elem.hip", "beam.hip", "conv1x1.hip", "wsgemm.hip", "stem.hip", "wstat.hip", "pconv.hip",
-           "api.hip", "api_dispatch.hip", "api_encode.hip", "api_llama.hip", "api_comm.hip", "api_inspect.hip"]
+           "api.hip", "api_dispatch.hip", "api_encode.hip", "api_llama.hip", "api_comm.hip", "api_inspect.hip", "api_transform.hip"]
 HOOK_SOURCES = ["api_debug.hip"]
 HEADERS = ["rdx_common.h", "rdx_kernels.h", "rdx_ctx.h", "skinny_body.h", "attn_body.h", "handoff.h", os.path.join("..", "..", "include", "rdx.h"),
            os.path.join("..", "..", "include", "rdx_hooks.h")]

@@ -159,11 +159,13 @@ extern "C" int rdx_conv_test(rdx_ctx* c, const void* X, const float* W, const fl
         }
         if (!c->zero16 || !pconv_supported(pa, ksize * ksize, stride, epi)) { hipFree(buf); return fail(c, -1, "rdx_conv_test: shape not supported by pconv"); }
     }
+    bool refused = false;
     auto once = [&]() {
-        if (path && !launch_pconv(dt, pa, ksize * ksize, stride, epi, path == 2, c->stream)) { hipFree(buf); return fail(c, -1, "rdx_conv_test: pconv refused the tiling"); }
+        if (path) { if (!launch_pconv(dt, pa, ksize * ksize, stride, epi, path == 2, c->stream)) refused = true; }
         else conv_gemm(c, X, w, bias, need_res ? resid : nullptr, out, B, H, H, Cin, ksize, ksize, stride, ksize / 2, Ho, Ho, epi);
     };
     once();
+    if (refused) { hipStreamSynchronize(c->stream); hipFree(buf); return fail(c, -1, "rdx_conv_test: pconv refused the tiling (1 x 1 stride-1 with different input / output row tilings)"); }
     if (ms_host && iters > 0) {
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);

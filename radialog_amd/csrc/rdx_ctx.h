@@ -118,6 +118,8 @@ struct rdx_ctx {
     int *bm_tok = nullptr, *bm_src = nullptr; int32_t* bm_out = nullptr; void* bm_scratch = nullptr;
     size_t bm_scratch_bytes = 0; int bm_rows = 0, bm_new = 0;
 
+    void* tf_ws = nullptr; size_t tf_bytes = 0;      // rdx_transform_image: coefficient tables + the horizontal pass's uint8 rows (grown on demand)
+
     // ---- data-parallel collective (RCCL over xGMI): the one all-gather of generated token ids ----
     void* comm = nullptr; int comm_rank = 0, comm_world = 0;
 

@@ -114,6 +114,20 @@ class RdxEngine:
         self._finalized = True
 
     # ------------------------------------------------------------------------------------------------------------
+    def transform_image(self, image_u8, resize: int = 512, crop: int = 448) -> torch.Tensor:
+        """rdx_transform_image: the reference's inference transform on the GPU. image_u8: uint8 [H, W] (torch tensor or numpy array: the "L" image of
+        demo.py:205-218) -> float32 [3, crop, crop] on this device, bit for bit what Resize(resize) -> CenterCrop(crop) -> ToTensor -> ExpandChannels give
+        on the PIL image (ReportDataset.py:96-106)."""
+        t = torch.as_tensor(image_u8)
+        if t.dim() != 2 or t.dtype != torch.uint8:
+            raise ValueError(f"Expected input of shape [1, H, W], found {tuple(t.shape)} ({t.dtype}): one 8-bit channel")
+        t = t.to(self.device).contiguous()
+        out = torch.empty(3, crop, crop, dtype=torch.float32, device=self.device)
+        torch.cuda.synchronize(self.device)
+        check(self.ctx, self.lib.rdx_transform_image(self.ctx, _ptr(t), t.shape[0], t.shape[1], int(resize), int(crop), _ptr(out)), "rdx_transform_image")
+        self.sync()
+        return out
+
     def encode_image(self, image: torch.Tensor, want_image_embeds: bool = True, previous_image: Optional[torch.Tensor] = None):
         """image float32[B,3,S,S] on this device -> (qformer_out f32[B,nq,Hq], image_embeds f32[B,P,C] or None).
         `previous_image` (same shape) selects the BioViL-T two-image branch (ViT pooler difference features)."""

@@ -12,7 +12,8 @@ absent here), restated from their published arithmetic:
   ToTensor()         uint8 [H, W] -> float32 [1, H, W] / 255
   ExpandChannels()   repeat_interleave to 3 channels; anything but one input channel is a ValueError
 
-Benchmarks feed synthetic 448 x 448 tensors and bypass this file."""
+Round 6: with an engine the transform runs on the GPU (rdx_transform_image, api_transform.hip) -- same bytes; oracle/pil_resize.py is the numpy restatement of
+Pillow's algorithm both are tested against. Benchmarks feed synthetic 448 x 448 tensors and bypass this file."""
 from __future__ import annotations
 
 from typing import Tuple
@@ -45,13 +46,22 @@ class ExpandChannels:
 
 
 class ChestXrayInferenceTransform:
-    """Callable like the reference's Compose: PIL image (mode "L") -> float32 [3, crop, crop] in [0, 1]."""
+    """Callable like the reference's Compose: PIL image (mode "L") -> float32 [3, crop, crop] in [0, 1].
+    `engine` (an RdxEngine, at construction or per call): the transform runs on that engine's GPU (librdx rdx_transform_image: the two integer resampling passes
+    of Pillow's Resample.c + crop + /255 as HIP kernels, bit for bit the host result) and the tensor comes back on the device; without one it is the host path
+    below -- the library call the reference itself makes (torchvision's Resize on a PIL image is PIL.Image.resize)."""
 
-    def __init__(self, resize: int, center_crop_size: int):
-        self.resize, self.crop = int(resize), int(center_crop_size)
+    def __init__(self, resize: int, center_crop_size: int, engine=None):
+        self.resize, self.crop, self.engine = int(resize), int(center_crop_size), engine
 
-    def __call__(self, img) -> torch.Tensor:
+    def __call__(self, img, engine=None) -> torch.Tensor:
         from PIL import Image
+        engine = engine or self.engine
+        if engine is not None:
+            arr = np.asarray(img)
+            if arr.ndim != 2 or arr.dtype != np.uint8:
+                raise ValueError(f"Expected input of shape [1, H, W], found {arr.shape[::-1]}")
+            return engine.transform_image(torch.from_numpy(np.ascontiguousarray(arr)), self.resize, self.crop)
         w, h = img.size
         img = img.resize(resized_size(w, h, self.resize), Image.BILINEAR)
         img = img.crop(center_crop_box(*img.size, self.crop))
@@ -62,8 +72,8 @@ class ChestXrayInferenceTransform:
         return ExpandChannels()(x)
 
 
-def create_chest_xray_transform_for_inference(resize: int, center_crop_size: int) -> ChestXrayInferenceTransform:
-    return ChestXrayInferenceTransform(resize, center_crop_size)
+def create_chest_xray_transform_for_inference(resize: int, center_crop_size: int, engine=None) -> ChestXrayInferenceTransform:
+    return ChestXrayInferenceTransform(resize, center_crop_size, engine)
 
 
 def remap_to_uint8(array: np.ndarray) -> np.ndarray:

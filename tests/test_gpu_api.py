@@ -205,3 +205,34 @@ def test_public_surface_fp8_configuration_matches_the_engine_run_directly():
     assert torch.equal(outs[True][1].view(torch.int16), sc.cpu()[:N].view(torch.int16))
     assert not torch.equal(outs[True][1], outs[False][1])
     eng.close()
+
+
+@pytest.mark.parametrize("h,w", [(1000, 601), (601, 1000), (512, 512), (615, 512), (300, 400), (3056, 2544), (520, 700)])
+def test_gpu_image_transform_equals_pillow_bit_for_bit(h, w):
+    """SURVEY.md 8 row a1 on the GPU (round 6): rdx_transform_image -- Resize(512) / CenterCrop(448 | 488) / ToTensor / ExpandChannels of ReportDataset.py:96-106 as
+    HIP kernels (Pillow's two fixed-point resampling passes, coefficient tables computed in C doubles by librdx) -- against the host path (PIL.Image.resize, the call
+    torchvision's Resize makes) and the numpy restatement: identical float32 tensors, every element. Shapes: both orientations, up-scaling, a skipped pass, no
+    resize, a full-size radiograph."""
+    import numpy as np
+    from PIL import Image
+    from oracle import pil_resize as pr
+    from radialog_amd import transforms as T
+    from radialog_amd.config import small_cfg
+    from radialog_amd.engine import RdxEngine
+    eng = RdxEngine(small_cfg(), dtype="f16", device=0, max_batch=1, max_len=64, llama=False)       # no weights needed for the transform
+    rng = np.random.default_rng(h * 13 + w)
+    a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    a[: h // 9] = 0
+    a[-2:, :] = 255
+    pil = Image.fromarray(a)
+    for crop in (448, 488):
+        host = T.create_chest_xray_transform_for_inference(512, center_crop_size=crop)(pil)
+        dev = T.create_chest_xray_transform_for_inference(512, center_crop_size=crop, engine=eng)(pil)
+        assert dev.is_cuda and dev.shape == (3, crop, crop) and dev.dtype == torch.float32
+        assert torch.equal(dev.cpu(), host), f"{h}x{w} crop {crop}: {int((dev.cpu() != host).sum())} elements differ from the PIL path"
+        assert np.array_equal(dev.cpu().numpy(), pr.inference_transform(a, 512, crop))
+    with pytest.raises(Exception, match="smaller than"):
+        eng.transform_image(torch.zeros(100, 900, dtype=torch.uint8), 512, 448 + 4096)
+    with pytest.raises(ValueError):
+        eng.transform_image(torch.zeros(3, 64, 64, dtype=torch.uint8))
+    eng.close()

@@ -57,6 +57,29 @@ def test_demo_main_runs_one_request(tmp_path, monkeypatch, capsys, classifier):
     assert isinstance(res["prediction"], str) and len(res["prediction"].split()) >= 1
 
 
+def test_demo_main_on_an_image_file_runs_the_gpu_transform(tmp_path, monkeypatch, capsys):
+    """`demo.py --image x.png`: load_image / remap_to_uint8 (demo.py:173-218) on the host, then Resize(512) / CenterCrop(448 | 488) / ToTensor / ExpandChannels on the
+    GPU (rdx_transform_image through the decoder's context) for the report model AND the findings classifier; the tensors equal the host (PIL) path's."""
+    import numpy as np
+    from PIL import Image
+    monkeypatch.chdir(tmp_path)
+    demo = _load("demo")
+    rng = np.random.default_rng(11)
+    raw = (rng.random((760, 640)) * 3000 + 50).astype(np.uint16)
+    Image.fromarray(raw).save(tmp_path / "cxr.png")
+    res = demo.main(["--synthetic", "--max_new_tokens", "4", "--dtype", "f16", "--image", str(tmp_path / "cxr.png")])
+    out = capsys.readouterr().out
+    assert "predicted findings:" in out and res["n_scores"] == 4 and res["sequences"].shape[0] == 1
+    from radialog_amd.config import small_cfg
+    from radialog_amd.engine import RdxEngine
+    eng = RdxEngine(small_cfg(), dtype="f16", device=0, max_batch=1, max_len=64, llama=False)
+    for crop in (448, 488):
+        host = demo.load_image(str(tmp_path / "cxr.png"), crop=crop)
+        dev = demo.load_image(str(tmp_path / "cxr.png"), crop=crop, engine=eng)
+        assert dev.is_cuda and torch.equal(dev.cpu(), host)
+    eng.close()
+
+
 def test_demo_generate_equals_the_engine_on_the_same_inputs(tmp_path, monkeypatch):
     """The mirrors add nothing and lose nothing: demo.main's generated ids == RdxEngine.generate on the prompt ids and the Q-Former
     output read back from the hand-off file."""

@@ -46,3 +46,23 @@ def test_png_through_the_inference_transform(tmp_path):
         assert float(x.min()) >= 0.0 and float(x.max()) <= 1.0
     with pytest.raises(ValueError):
         T.ExpandChannels()(torch.zeros(3, 4, 4))
+
+
+@pytest.mark.parametrize("h,w", [(1000, 601), (601, 1000), (512, 512), (615, 512), (300, 400), (1500, 1240), (520, 700), (513, 1029)])
+def test_numpy_restatement_of_pillows_resample_equals_pillow_bit_for_bit(h, w):
+    """oracle/pil_resize.py -- Pillow's Resample.c restated (antialiased triangle filter, C-double coefficient tables, 22-bit fixed point, two uint8 passes) plus
+    torchvision's size / crop rules -- against the Pillow installed here, the library torchvision's Resize calls on a PIL image: down-scaling in both orientations,
+    up-scaling (300 x 400), the skipped pass (512 wide) and no resize at all. librdx's rdx_transform_image computes the same tables in C++ and is held to the same
+    bytes on the GPU (tests/test_gpu_api.py)."""
+    from PIL import Image
+    from oracle import pil_resize as pr
+    rng = np.random.default_rng(h * 7 + w)
+    a = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    a[: h // 7] = 0
+    a[-3:, :] = 255
+    nw, nh = pr.resized_size(w, h, 512)
+    assert (nw, nh) == T.resized_size(w, h, 512)
+    assert np.array_equal(pr.pil_resize_bilinear(a, nw, nh), np.asarray(Image.fromarray(a).resize((nw, nh), Image.BILINEAR)))
+    for crop in (448, 488):
+        x = T.create_chest_xray_transform_for_inference(512, center_crop_size=crop)(Image.fromarray(a)).numpy()
+        assert np.array_equal(x, pr.inference_transform(a, 512, crop))
