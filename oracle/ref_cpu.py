@@ -252,8 +252,9 @@ def fake_quant_e4m3(x: torch.Tensor, groups: int = 1) -> torch.Tensor:
         b = K if q == groups - 1 else (NB * (q + 1) // groups) * 128
         seg = xf[..., a:b]
         am = seg.abs().amax(dim=-1, keepdim=True)
-        inv = torch.where(am > 0, 448.0 / am, torch.ones_like(am))
-        sc = torch.where(am > 0, am / 448.0, torch.ones_like(am))
+        c448 = torch.full_like(am, 448.0)            # tensor / tensor: IEEE division like the engine's 448.0f / amax (torch evaluates scalar / tensor as reciprocal x scalar:
+        inv = torch.where(am > 0, c448 / am, torch.ones_like(am))        # one ulp off on some maxima, which flips a code at exact ties -- round 6, found by the code-level test)
+        sc = torch.where(am > 0, am / c448, torch.ones_like(am))
         out[..., a:b] = (seg * inv).to(torch.float8_e4m3fn).float() * sc
     return out
 
@@ -271,8 +272,9 @@ def quant_e4m3_codes(x: torch.Tensor, groups: int = 1) -> Tuple[torch.Tensor, to
         b = K if q == groups - 1 else (NB * (q + 1) // groups) * 128
         seg = xf[..., a:b]
         am = seg.abs().amax(dim=-1, keepdim=True)
-        inv = torch.where(am > 0, 448.0 / am, torch.ones_like(am))
-        scales[..., q] = torch.where(am > 0, am / 448.0, torch.ones_like(am))[..., 0]
+        c448 = torch.full_like(am, 448.0)            # (tensor / tensor = IEEE division, see fake_quant_e4m3)
+        inv = torch.where(am > 0, c448 / am, torch.ones_like(am))
+        scales[..., q] = torch.where(am > 0, am / c448, torch.ones_like(am))[..., 0]
         codes[..., a:b] = (seg * inv).to(torch.float8_e4m3fn).view(torch.uint8)
     return codes, scales
 
