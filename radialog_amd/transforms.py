@@ -61,7 +61,7 @@ class ChestXrayInferenceTransform:
             arr = np.asarray(img)
             if arr.ndim != 2 or arr.dtype != np.uint8:
                 raise ValueError(f"Expected input of shape [1, H, W], found {arr.shape[::-1]}")
-            return engine.transform_image(torch.from_numpy(np.ascontiguousarray(arr)), self.resize, self.crop)
+            return engine.transform_image(torch.from_numpy(np.array(arr, dtype=np.uint8)), self.resize, self.crop)      # (a writable copy: PIL hands out a read-only buffer)
         w, h = img.size
         img = img.resize(resized_size(w, h, self.resize), Image.BILINEAR)
         img = img.crop(center_crop_box(*img.size, self.crop))
