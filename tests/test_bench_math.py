@@ -2,6 +2,7 @@
 CPU only: the helpers are pure functions of the configuration."""
 import importlib.util
 import json
+import re
 import os
 import sys
 
@@ -165,3 +166,29 @@ def test_gpus_n_without_a_launcher_fails_loudly_when_the_gpus_are_not_there():
     env.update(RANK="0", WORLD_SIZE="4", LOCAL_RANK="0")                          # a launcher with the wrong rank count
     p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 2 and p.stdout.strip() == "" and "WORLD_SIZE" in p.stderr
+
+
+def test_committed_round6_line_is_compact_and_agrees_with_its_detail_record():
+    """Round 6: the stdout line is a < 4 KB extract of the full record (bench.compact_line); both are committed (profiles/r06_bench.json = the line the run printed,
+    r06_bench_detail.json = the record beside it). The extract must be reproducible from the record, self-consistent, and carry the BASELINE configs[2] / [4] numbers
+    as scalars -- top level AND inside `roofline`, whose scalars the driver's record keeps."""
+    b = _bench()
+    with open(os.path.join(REPO, "profiles", "r06_bench.json")) as f:
+        raw = f.read().strip().splitlines()[-1]
+    d = json.loads(raw)
+    with open(os.path.join(REPO, "profiles", "r06_bench_detail.json")) as f:
+        full = json.load(f)
+    assert len(raw) < 4096
+    assert d == json.loads(json.dumps(b.compact_line(full, d["detail"])))
+    assert d["unit"] == "reports/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "bf16"
+    assert abs(d["value"] - 1000.0 / d["ms_per_step"] * d["config"]["global_batch"]) < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["bytes_per_launch"] / r["us_per_launch"] / 1e3) < 1.0 and 0.95 < r["traffic"] / r["bytes_per_launch"] < 1.05
+    for key in ("b32", "fp8_b32", "b64", "b128", "fp8_b128"):
+        assert d[f"{key}_value"] > d["value"] and r[f"{key}_decode_avg_frac"] == d[f"{key}_frac"]
+        assert abs(d[f"{key}_value"] / full[key]["value"] - 1) < 1e-4
+    assert d["b32_global_batch"] == 32 and d["fp8_b32_value"] > d["b32_value"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert set(d["parity"]) >= {"bf16", "f16", "b32", "fp8", "e2e_f16"} and all(v["ok"] for v in d["parity"].values())
+    assert d["results_verified"] is True and d["oracle_checked"] is True and re.fullmatch(r"[0-9a-f]{16}", d["build_hash"])
