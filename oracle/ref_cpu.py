@@ -18,11 +18,14 @@ Pinning:
   * greedy loop (a19): third-party `transformers==4.28.1 GenerationMixin.greedy_search` (not vendored in the
     reference, and `generate` is not callable on the vendored class under the installed transformers) --
     rule restated from the published algorithm; the per-step forward it drives IS pinned (hand loop over the
-    reference's `prepare_inputs_for_generation` + `forward`, see make_golden.py). "parity unpinned" at the
-    loop level only.
+    reference's `prepare_inputs_for_generation` + `forward`, see make_golden.py). "parity unpinned" against
+    4.28.1 at the loop level; round 6: `greedy_rule` is held against the INSTALLED transformers' generate()
+    (tests/test_oracle_golden.py: identical token ids incl. EOS, pad fill and early stop).
   * ResNet-50 trunk / Bottleneck (a2): arithmetic lives in `torchvision==0.14.0` (requirements.txt:18), which
-    is absent here and un-vendored -> PARITY UNPINNED; restated from the published v1.5 architecture
-    (stride on the 3x3 conv) with `torch.nn.functional.conv2d / batch_norm` as ground truth.
+    is absent here and un-vendored -> PARITY UNPINNED against torchvision; restated from the published v1.5
+    architecture (stride on the 3x3 conv) with `torch.nn.functional.conv2d / batch_norm` as ground truth.
+    Round 6: held against an INDEPENDENT implementation of the same published network that is installed --
+    transformers' ResNetModel (bottleneck, v1.5) -- at the full widths and depths: <= 2e-5.
   * LoRA linear (peft@e536616, requirements.txt:20, absent) -> PARITY UNPINNED; restated:
     y = W x + (alpha/r) * B(A x), un-merged, dropout inactive in eval.
   * ViT pooler two-image mode (a3'): timm==0.4.12 `Mlp` absent -> PARITY UNPINNED, restated from
@@ -277,6 +280,28 @@ def quant_e4m3_codes(x: torch.Tensor, groups: int = 1) -> Tuple[torch.Tensor, to
         scales[..., q] = torch.where(am > 0, am / c448, torch.ones_like(am))[..., 0]
         codes[..., a:b] = (seg * inv).to(torch.float8_e4m3fn).view(torch.uint8)
     return codes, scales
+
+
+def greedy_rule(step_logits, ids: torch.Tensor, key_mask: torch.Tensor, max_new: int, eos_id: int = 2, pad_id: int = 0) -> torch.Tensor:
+    """transformers==4.28.1 GenerationMixin.greedy_search as a rule over ANY per-step forward (`step_logits(seq [B, T + n], mask [B, T + n]) -> last-position logits
+    [B, V]`): argmax; a row that has produced EOS gets pad from then on; the mask grows by ones; stop when every row is finished or after max_new tokens. Returns the
+    generated ids [B, n]. LlamaOracle.generate_greedy is this rule on the oracle's cached forward; tests/test_oracle_golden.py holds it against the installed
+    transformers' generate()."""
+    B = ids.shape[0]
+    seq, mask = ids.clone(), key_mask.clone()
+    unfinished = torch.ones(B, dtype=torch.long)
+    out = []
+    for _ in range(max_new):
+        nxt = step_logits(seq, mask).argmax(dim=-1)
+        if eos_id >= 0:
+            nxt = nxt * unfinished + pad_id * (1 - unfinished)
+            unfinished = unfinished * (nxt != eos_id).long()
+        out.append(nxt)
+        seq = torch.cat([seq, nxt[:, None]], dim=-1)
+        mask = torch.cat([mask, mask.new_ones(B, 1)], dim=-1)
+        if eos_id >= 0 and unfinished.max() == 0:
+            break
+    return torch.stack(out, dim=1)
 
 
 class LlamaOracle:

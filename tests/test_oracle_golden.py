@@ -165,3 +165,99 @@ def test_real_shape_qformer_matches_reference(golden_dir):
     with torch.no_grad():
         out = ref_cpu.qformer(img, W, q)
     np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=5e-6)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 6: the two "parity unpinned" restatements that CAN be held against an independent published implementation installed here
+# ----------------------------------------------------------------------------------------------------------------------
+def test_resnet50_trunk_restatement_matches_an_independent_implementation():
+    """the trunk's arithmetic lives in torchvision==0.14.0 (requirements.txt:18; absent, un-vendored) -- `ref_cpu.resnet50_trunk` restates the
+    published ResNet-50 v1.5 (stride on the 3 x 3 convolution; biovil_t/resnet.py:25-47 drops avgpool / fc) and stays "parity unpinned" against torchvision itself. What IS
+    installed is a second, independent implementation of the same published network: transformers' `ResNetModel` (layer_type "bottleneck", downsample_in_bottleneck
+    False = v1.5, the configuration of the torchvision-converted microsoft/resnet-50). Same synthetic weights under the two naming schemes, the full ResNet-50 widths and
+    depths (3-4-6-3, 64-wide stem, 2048 output channels) on 96 px images: the two evaluations agree to fp32 rounding."""
+    from transformers import ResNetConfig, ResNetModel
+    v = VisionCfg(img=96)
+    W = synth.make_weights(synth.vision_specs(v))
+    hf = ResNetModel(ResNetConfig(num_channels=3, embedding_size=v.stem, hidden_sizes=[4 * p for p in v.planes], depths=list(v.blocks), layer_type="bottleneck",
+                                  hidden_act="relu", downsample_in_first_stage=False, downsample_in_bottleneck=False)).eval()
+    P = "visual_encoder.encoder.encoder."
+    bn = {"weight": "weight", "bias": "bias", "running_mean": "running_mean", "running_var": "running_var"}
+    sd = {"embedder.embedder.convolution.weight": W[P + "conv1.weight"]}
+    sd.update({f"embedder.embedder.normalization.{a}": W[P + f"bn1.{b}"] for a, b in bn.items()})
+    for li, nb in enumerate(v.blocks):
+        for b in range(nb):
+            src, dst = f"{P}layer{li + 1}.{b}.", f"encoder.stages.{li}.layers.{b}."
+            for j in range(3):
+                sd[dst + f"layer.{j}.convolution.weight"] = W[src + f"conv{j + 1}.weight"]
+                sd.update({dst + f"layer.{j}.normalization.{a}": W[src + f"bn{j + 1}.{bb}"] for a, bb in bn.items()})
+            if b == 0:
+                sd[dst + "shortcut.convolution.weight"] = W[src + "downsample.0.weight"]
+                sd.update({dst + f"shortcut.normalization.{a}": W[src + f"downsample.1.{bb}"] for a, bb in bn.items()})
+    missing, unexpected = hf.load_state_dict(sd, strict=False)
+    assert not unexpected and all("num_batches_tracked" in k for k in missing), (missing, unexpected)
+    x = synth.synth_images(2, v.img, seed=3)
+    with torch.no_grad():
+        want = hf(x).last_hidden_state
+        got = ref_cpu.resnet50_trunk(x, W, v)
+    assert got.shape == want.shape == (2, 2048, 3, 3)
+    scale = float(want.abs().max())
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=2e-5 * max(1.0, scale))
+
+
+def test_greedy_loop_rule_matches_transformers_generate():
+    """the greedy loop is third-party `transformers==4.28.1 GenerationMixin.greedy_search` (call sites demo.py:290, test.py:339), not vendored, and
+    `generate` cannot be called on the reference's vendored Llama class under the installed transformers -- "parity unpinned" against 4.28.1. The rule the oracle restates
+    (argmax of the last position; once a row has produced EOS its next tokens are forced to pad; stop when every row is finished or max_new_tokens is reached; the
+    attention mask grows by ones; left-padded position ids) is, however, still what the INSTALLED transformers implements: a tiny HF LlamaForCausalLM driven by
+    `generate(do_sample=False)` against the oracle's loop run on the SAME per-step forward (the HF model's own, so only the loop differs). EOS is made reachable by
+    planting it: the token ids must agree exactly, including the pad fill after EOS and the early stop."""
+    from transformers import LlamaConfig, LlamaForCausalLM as HFLlama
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=2, max_position_embeddings=128,
+                      pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    m = HFLlama(cfg).eval()
+    with torch.no_grad():
+        m.lm_head.weight[2] *= 3.0                                  # EOS wins now and then -> rows finish at different steps
+    ids = torch.randint(3, 64, (4, 10))
+    ids[1, :3] = 0
+    ids[3, :6] = 0                                                  # left padding (pad id 0)
+    am = ids.ne(0).long()
+    N = 24
+    with torch.no_grad():
+        out = m.generate(input_ids=ids, attention_mask=am, do_sample=False, max_new_tokens=N, eos_token_id=2, pad_token_id=0, use_cache=True)
+    gen_hf = out[:, ids.shape[1]:]
+
+    def step_logits(seq, mask):                                     # the per-step forward both loops share: last-position logits of the HF model
+        with torch.no_grad():
+            pos = ref_cpu.positions_from_mask(mask)
+            return m(input_ids=seq, attention_mask=mask, position_ids=pos).logits[:, -1, :]
+
+    toks = ref_cpu.greedy_rule(step_logits, ids, am, max_new=N, eos_id=2, pad_id=0)
+    assert toks.shape[1] <= N and toks.shape[1] == gen_hf.shape[1], (toks.shape, gen_hf.shape)
+    assert torch.equal(toks, gen_hf), f"oracle loop {toks.tolist()} vs transformers {gen_hf.tolist()}"
+    assert (gen_hf == 2).any() and (gen_hf == 0).any()              # the interesting branches were exercised: an EOS, and pads behind it
+
+
+def test_oracle_greedy_loop_is_the_pinned_rule(llama_weights):
+    """LlamaOracle.generate_greedy (cached forward, what every GPU leg is compared with) produces the tokens of `greedy_rule` -- the loop held against transformers'
+    generate() above -- run on the oracle's own UN-cached forward: same EOS / pad / stop behaviour, and the KV-cached decode equals the full re-computation."""
+    c = golden_llama_cfg()
+    orc = ref_cpu.LlamaOracle(llama_weights, c, torch.float32, lora=False)
+    ids = synth.synth_prompt_ids(3, 40, vocab=c.vocab, img_offset=4, seed=5)
+    ids[1, :5] = 0
+    ids[1, 5] = 1
+    ids[ids == 32000] = 9                              # plain prompts: no image splice, so that a re-computed forward of the grown sequence is well defined
+    km = ids.ne(0).long()
+
+    def step_logits(seq, mask):
+        with torch.no_grad():
+            return orc.forward(orc.embed(seq, None), mask, ref_cpu.positions_from_mask(mask))[0][:, -1, :]
+
+    # an EOS that is actually reached: take the token the model picks at step 2 of row 0 as "EOS"
+    free = ref_cpu.greedy_rule(step_logits, ids, km, max_new=6, eos_id=-1)
+    eos = int(free[0, 2])
+    want = ref_cpu.greedy_rule(step_logits, ids, km, max_new=10, eos_id=eos, pad_id=0)
+    got = orc.generate_greedy(ids, None, max_new=10, eos_id=eos, pad_id=0, key_mask=km)["tokens"]
+    assert torch.equal(got, want), (got.tolist(), want.tolist())
+    assert (want[0, 3:] == 0).all()                    # row 0 stopped at its EOS and was padded from there on
