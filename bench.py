@@ -686,7 +686,7 @@ def compact_line(res, detail_name):
             out[k] = {"same": v["tokens_identical"], "n": v["tokens_compared"], "median_err": _sig(v["median_logit_err"], 3), "worst": _sig(v["worst_logit_err"], 3),
                       "median_margin": _sig(v["median_oracle_margin"], 3)}
     if "fp8_b32" in res:
-        out["fp8_statement"] = "no e4m3 variant keeps the un-quantised tokens on random-init weights: W8A8 27/96 .. W8A16 40/96 (profiles/r06_fp8_variants.md)"
+        out["fp8_statement"] = "no e4m3 variant keeps the un-quantised tokens on random-init weights: engine rule 30/96, W8A8 31/96 .. W8A16 39/96 (profiles/r06_fp8_variants.md)"
     out["tokens_ok"] = bool(res["token_check"]["ok"]) and sub_tokens_ok          # first 8 tokens of every timed configuration == tests/golden/bench_tokens.json
     for k in ("oracle_checked", "fixtures_match", "results_verified", "max_batch_per_gpu", "build_hash"):
         if k in res:

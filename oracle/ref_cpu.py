@@ -322,8 +322,8 @@ class LlamaOracle:
         has no fp8 mode -- this is the fake-quantised restatement its parity is defined against): the seven decoder projections
         (+ LoRA-A, fused into QKV by the engine) and lm_head use e4m3 weights with one scale per output row; their INPUT activations are
         e4m3 too -- one scale per row and K group (1 group behind an RMSNorm, 2 for o_proj, 4 for down_proj) -- wherever the engine multiplies
-        fp8 x fp8: every projection of a prefill, and decode / lm_head at batch >= 3 (batch <= 2 expands the weights in registers and keeps
-        model-dtype activations). Products of the quantised values are accumulated in fp32 and rounded once to `dtype`.
+        fp8 x fp8: every projection of a prefill, and QKV / gate-up / lm_head of a decode step at batch >= 3 (batch <= 2 expands the weights in registers and keeps
+        model-dtype activations; round 6: so do o_proj and down_proj of every decode step). Products of the quantised values are accumulated in fp32 and rounded once to `dtype`.
         Variants for the accuracy study of the fp8 configuration (tools/fp8_variants.py, round 6; the engine implements "engine" with fp8_lora_a = True):
         a8_mode "engine" = the rule above, "always" = every pass fp8 x fp8 (= force_a8), "never" = W8A16 everywhere (e4m3 weights, model-dtype
         activations), "prefill" = fp8 x fp8 in the prefill only, every decode step W8A16; fp8_lora_a False keeps the LoRA-A matrices in the model dtype."""
@@ -339,7 +339,8 @@ class LlamaOracle:
                                              (k.endswith("_proj.weight") or (fp8_lora_a and k.endswith("lora_A.weight")))):
                     self.W8[k] = fake_quant_e4m3(v.to(self.dev))
         self.a8_mode = a8_mode
-        self._a8 = False                       # set per forward() call: are this pass's projections fp8 x fp8?
+        self._a8 = False
+        self._a8_split = False                       # set per forward() call: are this pass's projections fp8 x fp8?
         self.force_a8 = False                  # True: every pass multiplies fp8 x fp8 whatever its batch -- ONE row of a batch >= 3 engine
                                                # run restated at batch 1 (activation scales are per row: rows do not interact; bench.py)
         self.lora = lora and any("lora_A" in k for k in W)
@@ -441,10 +442,10 @@ class LlamaOracle:
         s = torch.max(s, torch.tensor(torch.finfo(s.dtype).min, device=s.device))
         p = F.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
         o = self._mm(p, v).transpose(1, 2).reshape(B, T, H)
-        x = x + self._lin(o, L + "self_attn.o_proj.weight", groups=2)
+        x = x + self._lin(o, L + "self_attn.o_proj.weight", groups=2, a8=self._a8_split)
         h = self._rms(x, W[L + "post_attention_layernorm.weight"])
         g = F.silu(self._lin(h, L + "mlp.gate_proj.weight")) * self._lin(h, L + "mlp.up_proj.weight")
-        x = x + self._lin(g, L + "mlp.down_proj.weight", groups=4)
+        x = x + self._lin(g, L + "mlp.down_proj.weight", groups=4, a8=self._a8_split)
         return x, (k, v)
 
     def forward(self, x, key_mask, pos_ids, past=None, all_logits=False, n_layers=None):
@@ -456,6 +457,9 @@ class LlamaOracle:
         # fp8 mode: a prefill (more than one token per row, or nothing cached) runs every projection fp8 x fp8; a decode step from batch 3
         prefill = past is None or T > 1
         self._a8 = self.fp8 and {"engine": prefill or x.shape[0] >= 3 or self.force_a8, "always": True, "never": False, "prefill": prefill}[self.a8_mode]
+        # the K-split projections (o_proj, down_proj) of a DECODE step multiply W8A16 in the engine since round 6 (xstat32.hip: their consumer-side quantisation
+        # cost 3 us per launch and accuracy); in the prefill they are fp8 x fp8 like everything else. "always" keeps the pure W8A8 variant of the study.
+        self._a8_split = self._a8 and (prefill or self.a8_mode == "always")
         new_past = []
         nl = self.cfg.layers if n_layers is None else n_layers
         for l in range(nl):

@@ -274,7 +274,6 @@ __global__ __launch_bounds__(XS_THREADS) void xstat32_k(GemmArgs a) {
 template <typename T, int KC, int KGN, bool W8, int TPI, bool A8 = false, bool BLK = false>
 __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __restrict__ slab) {
     static_assert(!A8 || W8, "fp8 activations go with fp8 weights");
-    static_assert(!BLK || !W8 || A8, "row blocks with fp8 weights: fp8 x fp8 only");
     constexpr int SLOTS = XS_WAVES * KGN, CPW = (KC + SLOTS - 1) / SLOTS, FPL = W8 ? 2 : 1;   // fragments (MFMAs per row tile) per load
     extern __shared__ __attribute__((aligned(16))) unsigned char smx[];
     float* red = reinterpret_cast<float*>(smx);       // [2 bufs][TPI][8 waves][2 mt][256]
@@ -438,6 +437,16 @@ __global__ __launch_bounds__(XS_THREADS) void xsplit32_k(GemmArgs a, float* __re
 #undef XS_T
 }
 
+// Round 6: the K-split projections of the fp8 configuration's DECODE (o_proj, down_proj at 3-128 rows) multiply W8A16 -- the e4m3 weight fragments expanded to the model
+// dtype in registers (exact), the producer's model-dtype activation fragments as they are. Their fp8 x fp8 form (rounds 3-5; RDX_FP8_SPLIT_A8=1: the A/B leg) had every one
+// of the 256 workgroups load its K range of the model-dtype activations anyway, reduce the row maxima across its waves through LDS (two barriers) and convert -- ~3 us of a
+// 9.6-us o_proj whose weight stream is 16.8 MB -- and it is the less accurate of the two (profiles/r06_fp8_variants.md). The prefill and the activation-stationary
+// projections (QKV, gate/up, lm_head: their e4m3 rows come out of the RMSNorm launch for free) stay fp8 x fp8.
+static bool fp8_split_a8() {
+    static const bool a8 = getenv("RDX_FP8_SPLIT_A8") && atoi(getenv("RDX_FP8_SPLIT_A8")) == 1;
+    return a8;
+}
+
 // RDX_XDUP=0 (A/B leg): the padding rows of a 32-row block load their own lines
 static GemmArgs xs_env(GemmArgs a) {
     static const bool off = getenv("RDX_XDUP") && atoi(getenv("RDX_XDUP")) == 0;
@@ -471,11 +480,13 @@ void launch_xsplit32(int dtype, const GemmArgs& a_in, float* slab, hipStream_t s
     RDX_DISPATCH_T(dtype, T, {
         if (kgn == 4) {
             const int nts = std::min(nt, 256 / 4);
-            if (w8) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2, true>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
+            if (w8 && fp8_split_a8()) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2, true>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
+            else if (w8) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2, false>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
             else hipLaunchKernelGGL((xsplit32_k<T, 344, 4, false, 1>), dim3(nts * 4), dim3(XS_THREADS), smem, s, a, slab);
         } else if (kgn == 2) {
             const int nts = std::min(nt, 256 / 2);
-            if (w8) hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2, true>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
+            if (w8 && fp8_split_a8()) hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2, true>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
+            else if (w8) hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2, false>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
             else hipLaunchKernelGGL((xsplit32_k<T, 128, 2, false, 1>), dim3(nts * 2), dim3(XS_THREADS), smem, s, a, slab);
         }
     });
@@ -507,8 +518,13 @@ void launch_xsplit_blk8(int dtype, const GemmArgs& a_in, float* slab, hipStream_
     const GemmArgs a = xs_env(a_in);
     const size_t smem = (size_t)2 * 2 * XS_WAVES * 2 * 256 * 4;
     RDX_DISPATCH_T(dtype, T, {
-        if (a.K == 11008) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2, true, true>), dim3(256), dim3(XS_THREADS), smem, s, a, slab);
-        else hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2, true, true>), dim3(256), dim3(XS_THREADS), smem, s, a, slab);
+        if (fp8_split_a8()) {
+            if (a.K == 11008) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2, true, true>), dim3(256), dim3(XS_THREADS), smem, s, a, slab);
+            else hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2, true, true>), dim3(256), dim3(XS_THREADS), smem, s, a, slab);
+        } else {
+            if (a.K == 11008) hipLaunchKernelGGL((xsplit32_k<T, 172, 4, true, 2, false, true>), dim3(256), dim3(XS_THREADS), smem, s, a, slab);
+            else hipLaunchKernelGGL((xsplit32_k<T, 64, 2, true, 2, false, true>), dim3(256), dim3(XS_THREADS), smem, s, a, slab);
+        }
     });
 }
 

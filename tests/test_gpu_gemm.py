@@ -168,8 +168,8 @@ def test_fp8_weights_have_no_kernel_for_odd_batch3_shapes(eng):
     # batch 3-32 decode, fp8 x fp8 (xstat32_k<W8, A8>): the rows are RMS-normalised (or just re-laid) and quantised to e4m3 by rmsnorm -> fp8
     (32, 8224, 4096, 0, False, 4, 1), (25, 8208, 4096, 4, False, 4, 1), (32, 12304, 4096, 3, True, 4, 1), (4, 16400, 4096, 4, True, 4, 1),
     (3, 8208, 4096, 0, True, 4, 1),
-    # K-split slab path (force 6): every K-group workgroup quantises its range -- down_proj (4 groups) and o_proj (2 groups) shapes
-    (32, 4096, 11008, 3, False, 6, 4), (19, 4096, 4096, 3, False, 6, 2), (32, 2048, 11008, 3, False, 6, 4),
+    # K-split slab path (force 6), down_proj and o_proj shapes: round 6 -- W8A16 (e4m3 weights expanded in registers, model-dtype activations; groups 0 = none quantised)
+    (32, 4096, 11008, 3, False, 6, 0), (19, 4096, 4096, 3, False, 6, 0), (32, 2048, 11008, 3, False, 6, 0),
     # prefill, fp8 x fp8 (gemm8.hip; force 9 / 10 / 11 = 1 / 2 / 4 K groups): single prompt (128 x 128 blocks), batched (256 x 256 blocks), ragged
     # M and N, an odd number of 128-deep blocks with uneven groups (the small config's inter = 1408 = 11 blocks), every epilogue
     (160, 12304, 4096, 0, True, 9, 1), (160, 4096, 4096, 3, False, 10, 2), (160, 22016, 4096, 4, True, 9, 1), (160, 4096, 11008, 3, False, 11, 4),
@@ -177,7 +177,8 @@ def test_fp8_weights_have_no_kernel_for_odd_batch3_shapes(eng):
     (216, 512, 1408, 3, False, 11, 4), (50, 2832, 512, 4, True, 9, 1), (3, 528, 512, 0, True, 9, 1), (257, 144, 768, 0, False, 10, 2)])
 def test_fp8_x_fp8_gemm_matches_fake_quantised_fp32(eng, M, N, K, epi, norm, force, groups):
     """BASELINE configs[4]: e4m3 weights (one scale per output row) x e4m3 activations (one scale per row and K group) on
-    the fp8 MFMAs -- prefill (gemm8.hip: v_mfma_f32_32x32x64_f8f6f4 / 16x16x128) and batch 3-32 decode (xstat32.hip: v_mfma_f32_16x16x32_fp8_fp8). Reference = fp32 math on the fake-quantised
+    the fp8 MFMAs -- prefill (gemm8.hip: v_mfma_f32_32x32x64_f8f6f4 / 16x16x128) and batch 3-32 decode (xstat32.hip: v_mfma_f32_16x16x32_fp8_fp8; the K-split o_proj / down_proj
+    of a decode step are W8A16 since round 6: groups 0). Reference = fp32 math on the fake-quantised
     operands. The quantisation grid makes the comparison discontinuous (an activation one model-dtype ulp away can land on the next
     e4m3 code, 6 % apart), so the bar is 2 x the model-dtype tolerance on the largest output, and at least 1.25e-2 x that behind an
     RMSNorm (whose output is where the two sides differ by an ulp)."""

@@ -14,13 +14,15 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     out = {"_note": "first 8 greedy tokens of row 0 of bench.py's timed configurations, written by tools/make_bench_fixture.py on an MI355X"}
     for extra in ([], ["--dtype", "f16", "--no-fp8"]):
+        detail = os.path.join("/tmp", f"rdx_fixture_detail_{os.getpid()}.json")        # round 6: the nested records are in the detail file, the stdout line is their extract
         p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline"] + extra,
-                           capture_output=True, text=True)
-        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
-        if not line:
+                           capture_output=True, text=True, env=dict(os.environ, RDX_BENCH_DETAIL=detail))
+        if not os.path.exists(detail) or not [l for l in p.stdout.splitlines() if l.startswith("{")]:
             sys.stderr.write(p.stderr[-4000:])
             raise SystemExit("bench.py printed no JSON line")
-        d = json.loads(line[-1])
+        with open(detail) as f:
+            d = json.load(f)
+        os.remove(detail)
         for obj in [d] + [d[k] for k in ("b32", "fp8_b32", "b64", "b128", "fp8_b128", "f16_b1") if k in d]:
             tc = obj["token_check"]
             out[tc["key"]] = tc["tokens"]
