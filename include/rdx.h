@@ -179,7 +179,11 @@ int rdx_hidden_read(rdx_ctx* ctx, void* dst /*model dtype [B][hidden]: decoder o
 int rdx_time(rdx_ctx* ctx, int what, int iters, float* ms_host);
 /* test / experiment switches of one context (defaults come from the environment at rdx_create): "flash_min" = 64-query workgroups from which the
  * batched prefill attention takes the flash-style kernel (0 never, 1 always; RDX_FLASH_MIN, default 512), "pconv" = the image encoder on
- * fragment-packed activations (1, default) or on the row-major kernels of rounds 1-3 (0; RDX_PCONV). No reference counterpart. */
+ * fragment-packed activations (1, default) or on the row-major kernels of rounds 1-3 (0; RDX_PCONV), "xs16" = batch 3-16 decode on the one-row-tile
+ * family of xs16.hip (1, default) or on the 32-row family (0; RDX_XS16), "prompt_blk" = one prompt's K = 4096 projections on 32-row blocks (1, default) or on
+ * the weight-stationary kernel (0; RDX_PBLK). Unknown names return -1. No reference counterpart.
+ * At batch 3-16 on the xs16 family rdx_time units 1-5 time THOSE kernels (the RMSNorm is their prologue); max_batch > 32 needs the Vicuna-7B widths
+ * (hidden 4096, inter 11008): rdx_finalize_weights refuses other models with more than 32 rows. */
 int rdx_set_option(rdx_ctx* ctx, const char* name, int value);
 
 #ifdef __cplusplus
