@@ -1,6 +1,7 @@
 #!/bin/bash
 # Round-6 profiling passes (run on the GPU box from the repo root); text summaries only -> gpurun_out/prof/.
 #   bash tools/profile_r06.sh dec N      kernel table of a 256-token decode at batch N
+#   bash tools/profile_r06.sh decfp8 N   the same with fp8 weights (round 6: o_proj / down_proj of decode steps W8A16)
 #   bash tools/profile_r06.sh bench      kernel table of the default bench command
 set -u
 ROOT=$PWD
@@ -17,6 +18,9 @@ trace() {  # name, iterations (0 = none), command...
 what=${1:-dec}
 if [ $what = dec ]; then
   trace dec_b$2 0 python $ROOT/tools/decode_only.py $2 256 1
+fi
+if [ $what = decfp8 ]; then
+  trace dec_fp8_b$2 0 python $ROOT/tools/decode_only.py $2 256 1 1
 fi
 if [ $what = bench ]; then
   trace bench_default 0 python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline
